@@ -1,0 +1,162 @@
+"""Pin the CPU oracle (oracle/awfl_oracle.c) before anything is compared with it.
+
+The reference holds no golden vector for the AWFL path, and it cannot be built
+in this image (YAKL absent).  What exists are the reference-arithmetic probe values recorded in
+SURVEY.md Appendix B (produced from the reference headers during the survey) plus analytic properties
+borrowed from the reference's stale unit tests (dynamics/awfl/unit/recon_regular/recon_regular.cpp:
+convergence order :111-122, overshoot :127-154; recon_irregular.cpp:28-37 irregular grid).
+"""
+import numpy as np
+import pytest
+
+from oracle import awfl_oracle as ao
+from oracle import gen_constants as gc
+from pam_amd import idealized as idz
+
+
+def test_ideal_weights_sigma_bit_exact():
+    # SURVEY.md Appendix B row 1 (WenoLimiter.h:39-44,94)
+    idl, sigma = ao.ideal_sigma()
+    assert sigma == float("0.73564225445964004")
+    exp = [float("0.00060224368852556992"), float("0.044303590476103952"), float("0.00060224368852556992"),
+           float("0.95449192214684486")]
+    assert list(idl) == exp
+
+
+def test_reconstruct_kat_bit_exact():
+    # SURVEY.md Appendix B rows 2-3 (Dycore.h:591-604 on constant matrices)
+    assert ao.reconstruct([0, 0, 0.85, 1, 1], 0) == float("0.58122938412882086")
+    assert ao.reconstruct([0, 0, 0.85, 1, 1], 1) == float("1.0195943293936724")
+    s = np.sin(0.3 * np.arange(5) + 0.1)
+    assert ao.reconstruct(s, 0) == float("0.52468366660293864")
+    assert ao.reconstruct(s, 1) == float("0.75407502647782132")
+
+
+def test_constants_rederived():
+    c = gc.build()
+    text = gc.emit(c)
+    assert text == open(ao._HERE + "/awfl_constants.h").read(), "awfl_constants.h is stale: run oracle/gen_constants.py"
+    assert text == open(ao._HERE + "/../pam_amd/csrc/awfl_constants.h").read()
+    # spot values of the reference literals (TransformMatrices.h:971,981,1219,1226)
+    assert float(c["S5"][0][0]) == 0.0046875 and float(c["S5"][2][0]) == float("1.1114583333333333333333")
+    assert float(c["W3"][0][2][0]) == float("0.95833333333333333333333")
+
+
+def test_variable_matrices_reduce_to_constants_on_uniform_grid():
+    # ~1e-15 agreement
+    s2c, wrl = ao.variable_matrices(np.arange(6) - 2.5)
+    c = gc.build()
+    S5 = np.array([[float(x) for x in r] for r in c["S5"]])
+    W3 = np.array([[[float(x) for x in r] for r in m] for m in c["W3"]])
+    assert np.abs(s2c - S5).max() < 1e-14
+    assert np.abs(wrl - W3).max() < 1e-14
+
+
+def test_weno_overshoot_smaller_than_unlimited():
+    # idea of recon_regular.cpp:127-154: on {0,0,0.85,1,1} WENO must overshoot less than the plain
+    # 5th-order polynomial
+    c = gc.build()
+    S5 = np.array([[float(x) for x in r] for r in c["S5"]])
+    u = np.array([0, 0, 0.85, 1, 1.0])
+    a_hi = u @ S5
+    right_unlimited = sum(a_hi[p] * 0.5 ** p for p in range(5))
+    right_weno = ao.reconstruct(u, 1)
+    assert abs(right_weno - 1.0) < abs(right_unlimited - 1.0) or abs(right_weno - 1.0) < 0.05
+
+
+def test_weno_convergence_order():
+    # idea of recon_regular.cpp:6-8,111-122: order >= ord-0.1 on cos(2 pi x - pi/10)
+    def err(n):
+        dx = 1.0 / n
+        F = lambda x: np.sin(2 * np.pi * x - np.pi / 10) / (2 * np.pi)   # antiderivative
+        e = 0.0
+        for i in range(n):
+            edges = (i - 2 + np.arange(6)) * dx
+            avg = (F(edges[1:]) - F(edges[:-1])) / dx
+            xr = (i + 1) * dx
+            e = max(e, abs(ao.reconstruct(avg, 1) - np.cos(2 * np.pi * xr - np.pi / 10)))
+        return e
+    e1, e2 = err(40), err(80)
+    assert np.log2(e1 / e2) > 4.9
+
+
+def test_irregular_grid_reproduces_quartic():
+    # recon_irregular.cpp:28-37 idea: dx ratio 1.5; the high-order matrix must be exact for quartics
+    widths = np.array([1.0, 1.5, 1.0, 1.5, 1.0]) / 1.0
+    edges = np.concatenate([[0], np.cumsum(widths)])
+    mid = 0.5 * (edges[2] + edges[3])
+    locs = (edges - mid) / widths[2]
+    s2c, _ = ao.variable_matrices(locs)
+    coef = np.array([0.3, -1.2, 0.7, 0.25, -0.4])
+    P = lambda x: sum(coef[p] * x ** (p + 1) / (p + 1) for p in range(5))
+    avg = (P(locs[1:]) - P(locs[:-1])) / (locs[1:] - locs[:-1])
+    assert np.allclose(avg @ s2c, coef, rtol=0, atol=1e-12)
+
+
+def _bubble(mode_a):
+    nens, nx, ny, nz = 2, 32, 1, 60
+    zint = idz.uniform_interfaces(nz, 10000.0)
+    names, pos, mass, idwv = idz.tracer_flags(idz.TRACERS_NONE)
+    f = idz.dry_bubble_fields(nens, nx, ny, nz, 20000.0, 20000.0, zint, amp0=2.0, damp=0.1)
+    o = ao.OracleDycore(nens, nx, ny, nz, 20000.0, 20000.0, np.diff(zint), pos, mass, idwv)
+    o.set_grav_balance(mode_a)
+    o.declare_current_profile_as_hydrostatic(f)
+    for _ in range(5):
+        n, dt = o.time_step(f, 1.0)
+    assert n == 3
+    return np.abs(f["wvel"]).max(), f
+
+
+def test_bubble_end_to_end_against_reference_probe():
+    # "Bubble, nens=2 (amplitudes 2.0, 2.1 K at cell centres), 32x1x60 uniform dz,
+    # zlen=10 km, crm_dt=1, 5 steps": reference headers gave max|w| = 0.64954263988863503 (mode A, with the
+    # order-independent ghost kernel) and 0.64953962145989119 (mode B).  15 SSPRK3 sub-steps of the whole path.
+    # Tolerance 1e-11: the vertical matrices go through a third-party inverse (yakl matinv_ge, unpinned).
+    wa, fa = _bubble(True)
+    wb, fb = _bubble(False)
+    assert abs(wa - 0.64954263988863503) < 1e-11 * 0.65
+    assert abs(wb - 0.64953962145989119) < 1e-11 * 0.65
+    assert np.isfinite(fa["temp"]).all() and np.isfinite(fb["temp"]).all()
+
+
+def test_resting_column_hydrostatic_balance():
+    # resting theta=300 column, dz=500 m, mode A -> variable_gravity = 9.81 at every
+    # level, w-tendency <= 1.8e-15, rho-tendency <= ~6e-11
+    nz, nens, nx, ny = 20, 1, 4, 1
+    zint = idz.uniform_interfaces(nz, 10000.0)
+    names, pos, mass, idwv = idz.tracer_flags(idz.TRACERS_NONE)
+    f = idz.dry_bubble_fields(nens, nx, ny, nz, 4000.0, 4000.0, zint, amp0=0.0, damp=0.0)
+    o = ao.OracleDycore(nens, nx, ny, nz, 4000.0, 4000.0, np.diff(zint), pos, mass, idwv)
+    o.declare_current_profile_as_hydrostatic(f)
+    assert np.allclose(o.variable_gravity, 9.81, rtol=0, atol=1e-9)  # 5th-order truncation error ~1e-11
+    st, tr = o.convert_coupler_to_dynamics(f)
+    seed = tr[:, 3:-3, 3:-3, 3:-3, :].copy()
+    tend, _ = o.compute_tendencies(st, tr, seed, 1.0)
+    assert np.abs(tend[3]).max() <= 4e-15
+    assert np.abs(tend[0]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("ny", [1, 6])
+def test_mass_conservation_per_step(ny):
+    # the reference's own runtime invariant (Dycore.h:136-138,224-251: relative 1e-10 per timeStep)
+    nens, nx, nz = 2, 8, 12
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    tr = idz.TRACERS_KESSLER_SHOC
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr)
+    idz.add_tracer_blobs(f, tr, 8000.0, 8000.0, zint)
+    o = ao.OracleDycore(nens, nx, ny, nz, 8000.0, 8000.0, np.diff(zint), pos, mass, idwv)
+    o.declare_current_profile_as_hydrostatic(f)
+    dz = np.diff(zint)[:, None, None, None]
+
+    def masses(ff):
+        st, trc = o.convert_coupler_to_dynamics(ff)
+        i = (slice(3, -3),) * 3
+        return [(st[0][i] * dz).sum(axis=(0, 1, 2)), (st[4][i] * dz).sum(axis=(0, 1, 2))] + \
+               [(trc[t][i] * dz).sum(axis=(0, 1, 2)) for t in range(len(tr))]
+    m0 = masses(f)
+    o.time_step(f, 2.0)
+    m1 = masses(f)
+    for a, b in zip(m0, m1):
+        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-10)
+    assert (f["tracers"] >= 0).all()
