@@ -1,0 +1,129 @@
+/*
+ * pam_amd_awfl.h -- C ABI of the MI355X-native AWFL dynamical-core step (libpam_amd_awfl.so).
+ *
+ * The reference plug-in boundary for this path is the compile-time duck-typed C++ class `Dycore`
+ * (E3SM-Project/PAM dynamics/awfl/Dycore.h) called by the host model through a `pam::PamCoupler`.
+ * Each entry point below replaces one member of that class; the thin C++ `class Dycore` a PAM maintainer
+ * drops into dynamics/awfl_amd/  forwards to these with the raw device pointers it gets
+ * from the coupler's DataManager.  Plain pointers and sizes only; every array is fp64 (`typedef double real`,
+ * pam_core/pam_const.h:22) on the device, row-major with nens fastest, exactly as the coupler stores it
+ * (pam_core/pam_coupler.h:259-266).
+ *
+ * Error convention: the reference's `endrun()` prints to stderr and throws (pam_core/pam_const.h:249-252).
+ * Here every function returns 0 on success or a negative PAM_AMD_E* code; pam_amd_awfl_last_error() returns
+ * the message (thread-local).  The C++ adaptor turns a non-zero return into `endrun(message)`.
+ *
+ * Threading: one handle per coupler, used from one host thread at a time (as pam_interface.h:26-32 keeps
+ * one coupler per thread).  All kernels are enqueued on the handle's HIP stream; calls that return a value
+ * to the host (compute_time_step, and time_step when it derives dt itself) synchronise that stream.
+ */
+#ifndef PAM_AMD_AWFL_H
+#define PAM_AMD_AWFL_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAM_AMD_AWFL_ABI_VERSION 1
+
+#define PAM_AMD_OK 0
+#define PAM_AMD_EINVAL (-1)   /* bad argument / inconsistent dimensions (reference: endrun) */
+#define PAM_AMD_ENOGPU (-2)   /* no HIP device, or a HIP runtime call failed */
+#define PAM_AMD_ENOMEM (-3)   /* device allocation failed */
+#define PAM_AMD_ESTATE (-4)   /* call sequence violated (e.g. time_step before init) */
+
+typedef struct pam_amd_awfl pam_amd_awfl_t; /* opaque dycore handle */
+
+/* Grid, tracer registry and physical constants the dycore reads from the coupler in Dycore::init
+ * (dynamics/awfl/Dycore.h:835-984).  A constant given as NaN takes the default of Dycore.h:871-876. */
+typedef struct pam_amd_awfl_config {
+  int nens, nx, ny, nz;                 /* coupler.get_nens/nx/ny/nz (pam_coupler.h:70-91) */
+  int num_tracers;                      /* coupler.get_num_tracers() (>=1: water_vapor) */
+  double xlen, ylen;                    /* coupler.get_xlen/ylen (m) */
+  double R_d, cp_d, R_v, cp_v, p0, grav;/* options of the same names (Dycore.h:871-876) */
+  int idWV;                             /* index of tracer "water_vapor" (Dycore.h:969,974) */
+  const unsigned char *tracer_positive; /* host, num_tracers flags (coupler.get_tracer_info, Dycore.h:963-970) */
+  const unsigned char *tracer_adds_mass;/* host, num_tracers flags */
+  const double *vertical_cell_dz;       /* DEVICE, (nz,nens): coupler entry "vertical_cell_dz" (Dycore.h:894) */
+  void *stream;                         /* hipStream_t to enqueue on (NULL = default stream) */
+} pam_amd_awfl_config_t;
+
+/* The coupler fields the dycore reads and writes (Dycore.h:1301-1310, :1357-1366), all DEVICE (nz,ny,nx,nens). */
+typedef struct pam_amd_awfl_fields {
+  double *density_dry, *uvel, *vvel, *wvel, *temp;
+  double *const *tracers;               /* host array of num_tracers device pointers, coupler registration order */
+} pam_amd_awfl_fields_t;
+
+/* GCM columns for declare_current_profile_as_hydrostatic(use_gcm_data=true) (Dycore.h:1416-1420), DEVICE (nz,nens) */
+typedef struct pam_amd_awfl_gcm_columns {
+  const double *gcm_density_dry, *gcm_temp, *gcm_water_vapor, *gcm_cloud_water, *gcm_cloud_ice;
+} pam_amd_awfl_gcm_columns_t;
+
+int pam_amd_awfl_abi_version(void);
+const char *pam_amd_awfl_last_error(void);
+
+/* Dycore::init (Dycore.h:835).  Allocates every scratch array once (the reference re-allocates ~13 arrays per
+ * sub-cycle, Dycore.h:149-152,307,325-330), builds the per-level vertical WENO matrices (Dycore.h:897-940) and
+ * sets option balance_hydrostasis_with_gravity = true (Dycore.h:866). */
+int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out);
+
+/* Dycore::finalize (Dycore.h:1548) + release of the handle. */
+int pam_amd_awfl_finalize(pam_amd_awfl_t *h);
+
+/* Dycore::dycore_name (Dycore.h:1544). */
+const char *pam_amd_awfl_dycore_name(const pam_amd_awfl_t *h);
+
+/* Options the dycore owns or derives (Dycore.h:866-891): "R_d","R_v","cp_d","cp_v","p0","grav","cv_d","cv_v",
+ * "gamma_d","kappa_d","C0" (real) and "balance_hydrostasis_with_gravity","idWV" (returned as 0/1 resp. index). */
+int pam_amd_awfl_get_option(const pam_amd_awfl_t *h, const char *key, double *value);
+/* coupler.set_option<bool>("balance_hydrostasis_with_gravity", v) after init() selects mode B. */
+int pam_amd_awfl_set_balance_hydrostasis_with_gravity(pam_amd_awfl_t *h, int value);
+
+/* Dycore-owned DataManager entries (Dycore.h:868,897-898,983-984): "variable_gravity", "hy_dens_cells",
+ * "hy_pressure_cells" (nz,nens); "vert_sten_to_coefs" (nz+2,5,5,nens); "vert_weno_recon_lower" (nz+2,3,3,3,nens).
+ * Returns the DEVICE pointer and the dimensions so the host model can register them in its DataManager. */
+int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_ptr, int dims[5], int *ndims);
+
+/* Dycore::declare_current_profile_as_hydrostatic(coupler, use_gcm_data) (Dycore.h:1392).  gcm == NULL is
+ * use_gcm_data=false. */
+int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields,
+                                                        const pam_amd_awfl_gcm_columns_t *gcm);
+
+/* Dycore::compute_time_step(coupler, cfl) (Dycore.h:65): min over every cell and ensemble member held by THIS
+ * handle.  When the ensemble is sharded over several GPUs the caller min-reduces the shard values (8 bytes)
+ * and passes the result to time_step as dt_dyn_hint, so that all shards sub-cycle identically (Dycore.h:141-145). */
+int pam_amd_awfl_compute_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double cfl, double *dt);
+
+/* Dycore::timeStep(coupler) (Dycore.h:107).  crm_dt = option "crm_dt" (Dycore.h:120).  dt_dyn_hint <= 0: derive
+ * the dynamics step from compute_time_step(cfl=0.8) on this handle's members (one stream synchronisation);
+ * > 0: use it (no host synchronisation).  Outputs (may be NULL): number of sub-cycles and the dt used. */
+int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double crm_dt, double dt_dyn_hint,
+                           int *ncycles, double *dt_dyn);
+
+/* Dycore::convert_coupler_to_dynamics / convert_dynamics_to_coupler (Dycore.h:1336, :1281) on the dycore's
+ * resident state (density-divided form). */
+int pam_amd_awfl_convert_coupler_to_dynamics(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields);
+int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields);
+
+/* --- measurement hooks (not in the reference; cf. its -DPAM_FUNCTION_TIMERS, pam_coupler.h:144-150) ------------ */
+/* Enable HIP-event timing of every kernel launch on the handle's stream (off by default: zero overhead). */
+int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
+/* Accumulated device time (ms) and launch count of kernel `name` ("flux","fct_mult","update","init_prim",
+ * "finalize","cfl","hydro") since the last reset; synchronises the stream. */
+int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
+int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
+/* faces per flux-kernel segment (tuning knob, default 8; 1..32) */
+int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
+
+/* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
+/* name: "prim0","prim1","flux_x","flux_y","flux_z","seed","mult". */
+int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem);
+/* flux + FCT multiplier of stage input prim0 with stage time step dt (Dycore.h:334-550); no update. */
+int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

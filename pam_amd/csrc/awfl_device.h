@@ -1,0 +1,690 @@
+// awfl_device.h -- device-side arithmetic of the MI355X-native AWFL dycore step (gfx950, fp64).
+//
+// Kernel BODIES live here as device functions taking explicit (block, thread, LDS) coordinates; the
+// __global__ wrappers are in awfl_kernels.hip.  The same bodies are compiled by g++ into the host-side
+// emulation harness under tests/emu/ (test infrastructure only: it lets the index logic be checked against
+// the oracle without a GPU; the product library never contains or calls it).
+//
+// What is computed (reference: E3SM-Project/PAM dynamics/awfl/Dycore.h, WenoLimiter.h):
+//   * weno5_*            WenoLimiter.h:98-181 compute_weno_coefs<5> + Dycore.h:591-604 reconstruct, restated as
+//                        ONE polynomial per cell evaluated at both cell edges (the reference evaluates the same
+//                        polynomial twice, once from each adjacent face, Dycore.h:345-359).
+//   * flux_line_body     Dycore.h:334-519: acoustic characteristic upwind + advective upwind fluxes.
+//   * fct_mult_body      Dycore.h:525-550: FCT positivity limiter, expressed as a per-cell multiplier.
+//   * update_body        Dycore.h:553-584 (flux divergence + gravity), :162-221 (SSPRK3 combines, clipping,
+//                        next FCT seed), fused with the NEXT stage's Dycore.h:310-321 (pressure, divide by rho)
+//                        and :662-710 (vertical ghost cells).
+//   * init_prim_body     Dycore.h:1370-1387 (coupler -> dycore state), :130-134 (clip), fused with :310-321,:662-710.
+//   * finalize_body      Dycore.h:1313-1330 (dycore state -> coupler).
+//   * cfl_body           Dycore.h:86-101.
+//   * pint_body / hydro_mean_body   Dycore.h:1450-1501 (declare_current_profile_as_hydrostatic).
+//
+// Data layout (all fp64, nens fastest, as the coupler: pam_coupler.h:259-263):
+//   prim[f][kz][j][i][e]   f: 0 rho, 1 pressure, 2 u, 3 v, 4 w, 5 theta, 6.. tracer mixing ratios (rho_t/rho)
+//                          kz in [0, nz+6): 3 ghost levels below and above (x,y are periodic: index wrap, no halo)
+//   flux_d[l][face][..][e] l: 0 mass flux, 1 u, 2 v, 3 w, 4 theta, 5.. tracers.  x: nx faces (face nx == face 0),
+//                          y: ny faces, z: nz+1 faces.
+//   seed[t][k][j][i][e]    FCT "mass available" seed (Dycore.h:156-159,173,197) -- also the exact conserved rho_t.
+//   mult[t][k][j][i][e]    FCT multiplier of the cell (1 when not limited).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include "awfl_constants.h"
+
+#if defined(__HIPCC__)
+#define PAMA_D __device__ __forceinline__
+#else
+#define PAMA_D inline
+#endif
+
+namespace pama {
+
+constexpr int HS = 3;          // ghost levels (Dycore.h:23)
+constexpr int MAXT = 50;       // pam_const.h:24 max_fields
+constexpr int FLUX_THREADS = 256;
+constexpr int VZ_STRIDE = 52;  // per-level vertical table: 27 (lower) + 25 (bridged upper)
+
+enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
+
+struct TracerPtrs { double *p[MAXT]; };
+
+struct Params {
+  int nens, nx, ny, nz, nt;
+  int sim2d;          // ny == 1 (Dycore.h:279)
+  int grav_balance;   // option balance_hydrostasis_with_gravity (Dycore.h:284)
+  int vz_per_ens;     // 0: vertical matrices identical for every ensemble member (wave-uniform table)
+  int seg;            // faces per flux-kernel segment
+  double dx, dy, rdx, rdy;
+  double C0, gamma, grav, R_d, R_v;
+  long long sx, sy, sz;   // cell strides in doubles: nens, nx*nens, ny*nx*nens
+  long long prim_fs;      // (nz+6)*sz
+  long long ncell;        // nz*sz
+  long long fz_fs;        // (nz+1)*sz
+  const double *dz;       // (nz,nens)
+  const double *grav_var; // (nz,nens)
+  const double *hy_dens;  // (nz,nens)
+  const double *hy_pres;  // (nz,nens)
+  const double *vz;       // vertical matrices: (nz+2,52) or (nz+2,52,nens)
+  unsigned long long pos_mask, mass_mask;  // tracer_positive / tracer_adds_mass bit sets
+  int idWV;
+};
+
+// ------------------------------------------------------------------------------------------------
+// reciprocal: v_rcp_f64 seed + two Newton steps (error ~1 ulp); the host emulation uses a true divide.
+PAMA_D double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double r = fma(-x, y, 1.0);
+  y = fma(y, r, y);
+  r = fma(-x, y, 1.0);
+  y = fma(y, r, y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// Convexified ideal weights (WenoLimiter.h:39-44 + :94), sigma, and derived constants.
+struct WenoConsts {
+  double idl[4], sigma, ridl3;
+  double c0[4], c1[4], c2[4], idl3x[4];   // map_weights pieces: idl+idl^2, 1-2idl, idl^2, 3*idl
+};
+PAMA_D WenoConsts weno_consts() {
+  WenoConsts w;
+  const double raw[4] = AWFL_WENO_IDL_INIT;
+  double sum = ((raw[0] + raw[1]) + raw[2]) + raw[3];
+  for (int i = 0; i < 4; i++) w.idl[i] = raw[i] / (sum + 1.0e-20);
+  w.sigma = AWFL_WENO_SIGMA;
+  w.ridl3 = 1.0 / w.idl[3];
+  for (int i = 0; i < 4; i++) {
+    w.c0[i] = w.idl[i] + w.idl[i] * w.idl[i];
+    w.c1[i] = 1.0 - 2.0 * w.idl[i];
+    w.c2[i] = w.idl[i] * w.idl[i];
+    w.idl3x[i] = 3.0 * w.idl[i];
+  }
+  return w;
+}
+
+// Non-linear part shared by the constant- and table-matrix variants: candidate polynomials in, blended
+// polynomial evaluated at the left (x=-1/2) and right (x=+1/2) edge out.
+// (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum;
+//  Dycore.h:601-603 edge evaluation with coefs_to_gll_lower = (+-1/2)^p.)
+PAMA_D void weno5_blend(const double alo[3][3], const double ah[5], const WenoConsts &wc, double &left, double &right) {
+  double tv[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) tv[i] = alo[i][1] * alo[i][1] + AWFL_TV3_A2A2 * (alo[i][2] * alo[i][2]);
+  tv[3] = ah[1] * ah[1] + AWFL_TV5_A2A2 * (ah[2] * ah[2]) + AWFL_TV5_A1A3 * ah[1] * ah[3] +
+          AWFL_TV5_A3A3 * (ah[3] * ah[3]) + AWFL_TV5_A2A4 * ah[2] * ah[4] + AWFL_TV5_A4A4 * (ah[4] * ah[4]);
+  double lo_avg = (tv[0] + tv[1] + tv[2]) * (1.0 / 3.0);
+  tv[3] = lo_avg + (tv[3] - lo_avg) * wc.sigma;
+  // w_i = idl_i/(tv_i^2+eps), then convexify: w_i /= (sum_k w_k + eps) (WenoLimiter.h:163-166).  One reciprocal,
+  // through products of the denominators d_i.  The eps added to the SUM matters when the TVs are large (pressure
+  // stencils: sum ~ 1e-17), so it is kept: numerator and denominator are both scaled by d0*d1*d2*d3.
+  double d0 = tv[0] * tv[0] + 1.0e-20, d1 = tv[1] * tv[1] + 1.0e-20;
+  double d2 = tv[2] * tv[2] + 1.0e-20, d3 = tv[3] * tv[3] + 1.0e-20;
+  double p01 = d0 * d1, p23 = d2 * d3;
+  double n0 = wc.idl[0] * (d1 * p23), n1 = wc.idl[1] * (d0 * p23);
+  double n2 = wc.idl[2] * (d3 * p01), n3 = wc.idl[3] * (d2 * p01);
+  double rs = fast_rcp((((n0 + n1) + n2) + n3) + 1.0e-20 * (p01 * p23));
+  double w[4] = {n0 * rs, n1 * rs, n2 * rs, n3 * rs};
+  // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal
+  double num[4], den[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    num[i] = w[i] * (wc.c0[i] + w[i] * (w[i] - wc.idl3x[i]));
+    den[i] = wc.c2[i] + w[i] * wc.c1[i];
+  }
+  double q01 = den[0] * den[1], q23 = den[2] * den[3];
+  double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
+  double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
+  double rm = fast_rcp(((m0 + m1) + m2) + m3);
+  m0 *= rm; m1 *= rm; m2 *= rm; m3 *= rm;
+  // blended coefficients
+  double a0 = m3 * ah[0] + (m0 * alo[0][0] + (m1 * alo[1][0] + m2 * alo[2][0]));
+  double a1 = m3 * ah[1] + (m0 * alo[0][1] + (m1 * alo[1][1] + m2 * alo[2][1]));
+  double a2 = m3 * ah[2] + (m0 * alo[0][2] + (m1 * alo[1][2] + m2 * alo[2][2]));
+  double a3 = m3 * ah[3];
+  double a4 = m3 * ah[4];
+  double even = a0 + (0.25 * a2 + 0.0625 * a4);
+  double odd = 0.5 * a1 + 0.125 * a3;
+  left = even - odd;
+  right = even + odd;
+}
+
+// Horizontal directions: constant matrices (TransformMatrices.h:970, :1218), zero entries skipped at
+// compile time, bridge polynomial (WenoLimiter.h:128-136) folded into a constant 5x5 matrix.
+PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
+  constexpr double S5[5][5] = AWFL_STEN_TO_COEFS_INIT;
+  constexpr double W3[3][3][3] = AWFL_WENO_LOWER_INIT;
+  double alo[3][3], ah[5];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int ii = 0; ii < 3; ii++) {
+      double t = 0.0;
+      bool first = true;
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        if (W3[i][s][ii] != 0.0) {
+          t = first ? W3[i][s][ii] * u[i + s] : t + W3[i][s][ii] * u[i + s];
+          first = false;
+        }
+      }
+      alo[i][ii] = t;
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < 5; ii++) {
+    double t = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      // bridged coefficient: (S5[s][ii] - sum_i idl_i * W3[i][s-i][ii]) / idl_3
+      double b = S5[s][ii];
+      if (ii < 3) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (s - i >= 0 && s - i < 3) b -= wc.idl[i] * W3[i][s - i][ii];
+      }
+      b *= wc.ridl3;
+      if (!(ii >= 3 && S5[s][ii] == 0.0)) {
+        t = first ? b * u[s] : t + b * u[s];
+        first = false;
+      }
+    }
+    ah[ii] = t;
+  }
+  weno5_blend(alo, ah, wc, left, right);
+}
+
+// Vertical direction: per-level matrices built at init from the cell-edge locations
+// (Dycore.h:904-937 + TransformMatrices_variable.h), used as Dycore.h:454-469.
+// tab points at 52 doubles with element stride `ts` (1 for the ensemble-uniform table, nens otherwise):
+//   [0..26]  lower matrices  [i][s][ii]
+//   [27..51] bridged upper matrix [s][ii]
+PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, const WenoConsts &wc, double &left,
+                        double &right) {
+  double alo[3][3], ah[5];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int ii = 0; ii < 3; ii++) {
+      double t = tab[((i * 3 + 0) * 3 + ii) * ts] * u[i];
+      t += tab[((i * 3 + 1) * 3 + ii) * ts] * u[i + 1];
+      t += tab[((i * 3 + 2) * 3 + ii) * ts] * u[i + 2];
+      alo[i][ii] = t;
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < 5; ii++) {
+    double t = tab[(27 + 0 * 5 + ii) * ts] * u[0];
+#pragma unroll
+    for (int s = 1; s < 5; s++) t += tab[(27 + s * 5 + ii) * ts] * u[s];
+    ah[ii] = t;
+  }
+  weno5_blend(alo, ah, wc, left, right);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flux kernel geometry.  One "line" = the cells along the sweep direction for fixed other indices and
+// ensemble member; an "item" = (line, iens) flattened with iens fastest so that a wavefront's 64 lanes read
+// 64 consecutive doubles (512 B, fully coalesced) for nens >= 64.  A thread sweeps one segment of `seg` faces
+// of its line; the 4 wavefronts of a workgroup take 4 consecutive segments of the same 64 items, so the
+// 5 overlap cells between neighbouring segments are L1/L2 hits.
+struct LineGeom {
+  int dir;             // 0 x, 1 y, 2 z
+  int n;               // cells along the line
+  int nfaces;          // x,y: n (periodic); z: n+1
+  long long cs;        // cell stride along the line (doubles)
+  long long fs_flux;   // field stride of this direction's flux array
+};
+
+PAMA_D LineGeom line_geom(const Params &P, int dir) {
+  LineGeom g;
+  g.dir = dir;
+  if (dir == 0) { g.n = P.nx; g.nfaces = P.nx; g.cs = P.sx; g.fs_flux = P.ncell; }
+  else if (dir == 1) { g.n = P.ny; g.nfaces = P.ny; g.cs = P.sy; g.fs_flux = P.ncell; }
+  else { g.n = P.nz; g.nfaces = P.nz + 1; g.cs = P.sz; g.fs_flux = P.fz_fs; }
+  return g;
+}
+
+PAMA_D int wrap(int c, int n) {
+  c %= n;
+  return c < 0 ? c + n : c;
+}
+
+// Body of the reconstruction + flux kernel for one thread.
+//   dir      sweep direction; item = flattened (line, iens); f0 = first face of this thread's segment
+//   lds      per-thread private slots: lds[(2*s+0)*lstride + tid] = mass flux of face f0+s, (2*s+1) = pressure
+// Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
+// with vertical ghosts already filled (Dycore.h:662-710).
+template <int DIR, bool VZ_PER_ENS>
+PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux,
+                           long long item, int f0, double *lds, int lstride, int tid) {
+  const LineGeom g = line_geom(P, DIR);
+  const WenoConsts wc = weno_consts();
+  const int e = (int)(item % P.nens);
+  const long long line = item / P.nens;
+  // base offset of the line's cell 0 inside a prim field, and of its face 0 inside a flux field
+  long long pbase, fbase;
+  if (DIR == 0) {  // line = k*ny + j
+    long long k = line / P.ny, j = line % P.ny;
+    pbase = (k + HS) * P.sz + j * P.sy + e;
+    fbase = k * P.sz + j * P.sy + e;
+  } else if (DIR == 1) {  // line = k*nx + i
+    long long k = line / P.nx, i = line % P.nx;
+    pbase = (k + HS) * P.sz + i * P.sx + e;
+    fbase = k * P.sz + i * P.sx + e;
+  } else {  // line = j*nx + i ; cell c lives at kz = c + HS
+    pbase = (long long)HS * P.sz + line * P.sx + e;
+    fbase = line * P.sx + e;
+  }
+  const int flast = (f0 + P.seg < g.nfaces) ? f0 + P.seg : g.nfaces;  // exclusive
+  const double cs = 350.0, rcs = 1.0 / 350.0;                        // Dycore.h:335
+  const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
+
+  auto cell_off = [&](int c) -> long long {
+    if (DIR == 2) return pbase + (long long)(c > P.nz + 2 ? P.nz + 2 : c) * g.cs;   // ghosts exist for c in [-3, nz+2]
+    return pbase + (long long)wrap(c, g.n) * g.cs;                     // periodic (Dycore.h:629-657)
+  };
+  auto vtab = [&](int c) -> const double * {                           // matrices of cell c: level index c+1
+    return VZ_PER_ENS ? P.vz + ((long long)(c + 1) * VZ_STRIDE) * P.nens + e : P.vz + (long long)(c + 1) * VZ_STRIDE;
+  };
+  const long long vts = VZ_PER_ENS ? (long long)P.nens : 1;
+
+  // ---------------- acoustic part: mass flux and pressure at the faces (Dycore.h:341-366) -------------
+  {
+    const double *pr = prim + (long long)P_RHO * P.prim_fs;
+    const double *pn = prim + (long long)ncomp * P.prim_fs;
+    const double *pp = prim + (long long)P_PRES * P.prim_fs;
+    double wm[5], wp[5];   // windows: rho*u_n product and pressure, cells c-2..c+2
+    int c = f0 - 1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      long long o = cell_off(c - 2 + s);
+      wm[s] = pr[o] * pn[o];
+      wp[s] = pp[o];
+    }
+    double prevR_m = 0.0, prevR_p = 0.0;
+    for (; c < flast; c++) {
+      // prefetch the next cell entering the window
+      long long on = cell_off(c + 3);
+      double nm = pr[on] * pn[on], np_ = pp[on];
+      double Lm, Rm, Lp, Rp;
+      if (DIR == 2) {
+        weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
+        weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
+      } else {
+        weno5_const(wm, wc, Lm, Rm);
+        weno5_const(wp, wc, Lp, Rp);
+      }
+      if (c >= f0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
+        double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
+        bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
+        if (wall) { ru_L = 0.0; ru_R = 0.0; }
+        double w1 = 0.5 * (pp_R - cs * ru_R);
+        double w2 = 0.5 * (pp_L + cs * ru_L);
+        double ppf = w1 + w2;
+        double ruf = (w2 - w1) * rcs;
+        if (wall) ruf = 0.0;
+        flux[fbase + (long long)c * g.cs] = ruf;            // flux field 0
+        lds[(2 * (c - f0) + 0) * lstride + tid] = ruf;
+        lds[(2 * (c - f0) + 1) * lstride + tid] = ppf;
+      }
+      prevR_m = Rm; prevR_p = Rp;
+#pragma unroll
+      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; }
+      wm[4] = nm; wp[4] = np_;
+    }
+  }
+  // ---------------- advected quantities, one field at a time (Dycore.h:367-385) -----------------------
+  const int nadv = 4 + P.nt;
+  for (int a = 0; a < nadv; a++) {
+    const int pf = P_U + a;                 // prim field
+    const double *q = prim + (long long)pf * P.prim_fs;
+    double *fl = flux + (long long)(1 + a) * g.fs_flux;
+    const bool addp = (pf == ncomp);
+    double w[5];
+    int c = f0 - 1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
+    double prevR = 0.0;
+    for (; c < flast; c++) {
+      double nq = q[cell_off(c + 3)];
+      double L, R;
+      if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
+      else weno5_const(w, wc, L, R);
+      if (c >= f0) {
+        double ruf = lds[(2 * (c - f0) + 0) * lstride + tid];
+        double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
+        double f = ruf * val;
+        if (addp) f += lds[(2 * (c - f0) + 1) * lstride + tid];
+        fl[fbase + (long long)c * g.cs] = f;
+      }
+      prevR = R;
+#pragma unroll
+      for (int s = 0; s < 4; s++) w[s] = w[s + 1];
+      w[4] = nq;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stores of one cell's density-divided variables (Dycore.h:310-321) and, for the first/last level, of the 3 ghost
+// levels below/above (Dycore.h:662-710, intended semantics: ghost theta = theta of the boundary cell).
+// Fields are stored one at a time as they are produced, so no per-thread array is needed (no scratch).
+PAMA_D void store_adv(const Params &P, double *prim, int pf, int k, long long c2, double val, double ghost_val) {
+  double *f = prim + (long long)pf * P.prim_fs;
+  f[(long long)(k + HS) * P.sz + c2] = val;
+  if (k == 0)
+    for (int kk = 0; kk < HS; kk++) f[(long long)(HS - 1 - kk) * P.sz + c2] = ghost_val;     // Dycore.h:670,675
+  if (k == P.nz - 1)
+    for (int kk = 0; kk < HS; kk++) f[(long long)(HS + P.nz + kk) * P.sz + c2] = ghost_val;  // Dycore.h:671,676
+}
+
+// density and pressure of the cell + their hydrostatically extrapolated ghosts (Dycore.h:682-709)
+PAMA_D void store_rho_pres(const Params &P, double *prim, int k, long long c2, int e, double rho, double th,
+                           double rho_theta, bool subtract_hy) {
+  double *fr = prim + (long long)P_RHO * P.prim_fs, *fp = prim + (long long)P_PRES * P.prim_fs;
+  const long long o = (long long)(k + HS) * P.sz + c2;
+  double pres = P.C0 * pow(rho_theta, P.gamma);
+  if (subtract_hy) pres -= P.hy_pres[(long long)k * P.nens + e];
+  fr[o] = rho;
+  fp[o] = pres;
+  const bool bot = (k == 0), top = (k == P.nz - 1);
+  if (bot || top) {
+    const double gm1 = P.gamma - 1.0;
+    const double rho0_gm1 = pow(rho, gm1);
+    const double theta0_g = pow(th, P.gamma);
+    const double dzk = P.dz[(long long)k * P.nens + e];
+    const double coef = P.grav * gm1 * dzk / (P.gamma * P.C0 * theta0_g);
+    for (int kk = 0; kk < HS; kk++) {
+      const int kz = bot ? (HS - 1 - kk) : (HS + P.nz + kk);
+      const long long og = (long long)kz * P.sz + c2;
+      const double arg = bot ? rho0_gm1 + coef * (kk + 1) : rho0_gm1 - coef * (kk + 1);
+      const double rho_g = pow(arg, 1.0 / gm1);
+      double p_g = pres;                                          // mode B: copy (Dycore.h:678-681)
+      if (P.grav_balance) p_g = P.C0 * pow(rho_g * th, P.gamma);    // mode A (Dycore.h:691-694)
+      fr[og] = rho_g;
+      fp[og] = p_g;
+    }
+  }
+}
+
+// decompose a flattened cell index (nens fastest) -> k, j, i, e
+PAMA_D void cell_coords(const Params &P, long long idx, int &k, int &j, int &i, int &e) {
+  e = (int)(idx % P.nens);
+  long long r = idx / P.nens;
+  i = (int)(r % P.nx); r /= P.nx;
+  j = (int)(r % P.ny);
+  k = (int)(r / P.ny);
+}
+
+// Coupler fields -> prim (+ghosts) and seed.  Dycore.h:1370-1387, :130-134.
+// gcm != nullptr selects the use_gcm_data branch of declare_current_profile_as_hydrostatic (Dycore.h:1415-1434):
+// gcm[0..4] = gcm_density_dry, gcm_temp, gcm_water_vapor, gcm_cloud_water, gcm_cloud_ice, each (nz,nens).
+PAMA_D void init_prim_body(const Params &P, const double *__restrict__ rho_d_c, const double *__restrict__ u_c,
+                           const double *__restrict__ v_c, const double *__restrict__ w_c,
+                           const double *__restrict__ temp_c, const TracerPtrs &trc, const double *const *gcm,
+                           double *__restrict__ prim, double *__restrict__ seed, bool subtract_hy, long long idx) {
+  int k, j, i, e;
+  cell_coords(P, idx, k, j, i, e);
+  const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+  double rho, ru, rv, rw, rt;
+  if (gcm) {
+    const long long c = (long long)k * P.nens + e;
+    double rho_d = gcm[0][c], rho_v = gcm[2][c];
+    rho = gcm[0][c] + gcm[2][c] + gcm[3][c] + gcm[4][c];
+    double p = (rho_d * P.R_d + rho_v * P.R_v) * gcm[1][c];
+    ru = 0; rv = 0; rw = 0;
+    rt = pow(p / P.C0, 1.0 / P.gamma);
+  } else {
+    double rho_d = rho_d_c[idx], temp = temp_c[idx];
+    double rho_v = trc.p[P.idWV][idx];
+    double press = rho_d * P.R_d * temp + rho_v * P.R_v * temp;
+    rho = rho_d;
+    for (int t = 0; t < P.nt; t++)
+      if ((P.mass_mask >> t) & 1ull) rho += trc.p[t][idx];
+    double theta = pow(press / P.C0, 1.0 / P.gamma) / rho;
+    ru = rho * u_c[idx]; rv = rho * v_c[idx]; rw = rho * w_c[idx]; rt = rho * theta;
+  }
+  const double rrho = fast_rcp(rho);
+  const double th = rt * rrho;
+  store_rho_pres(P, prim, k, c2, e, rho, th, rt, subtract_hy);
+  store_adv(P, prim, P_U, k, c2, ru * rrho, ru * rrho);
+  store_adv(P, prim, P_V, k, c2, rv * rrho, rv * rrho);
+  store_adv(P, prim, P_W, k, c2, rw * rrho, 0.0);
+  store_adv(P, prim, P_THETA, k, c2, th, th);
+  for (int t = 0; t < P.nt; t++) {
+    double r = 0.0;
+    if (!gcm) {
+      r = trc.p[t][idx];
+      if ((P.pos_mask >> t) & 1ull) r = fmax(0.0, r);           // Dycore.h:130-134
+    }
+    seed[(long long)t * P.ncell + idx] = r;                      // Dycore.h:156-159
+    store_adv(P, prim, P_TR0 + t, k, c2, r * rrho, r * rrho);
+  }
+}
+
+// prim + seed -> coupler fields.  Dycore.h:1313-1330.
+PAMA_D void finalize_body(const Params &P, const double *__restrict__ prim, const double *__restrict__ seed,
+                          double *__restrict__ rho_d_c, double *__restrict__ u_c, double *__restrict__ v_c,
+                          double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc, long long idx) {
+  int k, j, i, e;
+  cell_coords(P, idx, k, j, i, e);
+  const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
+  double rho = prim[P_RHO * P.prim_fs + o];
+  double theta = prim[P_THETA * P.prim_fs + o];
+  double press = P.C0 * pow(rho * theta, P.gamma);
+  double rho_v = seed[(long long)P.idWV * P.ncell + idx];
+  double rho_d = rho;
+  for (int t = 0; t < P.nt; t++) {
+    double r = seed[(long long)t * P.ncell + idx];
+    if ((P.mass_mask >> t) & 1ull) rho_d -= r;
+    trc.p[t][idx] = r;
+  }
+  rho_d_c[idx] = rho_d;
+  u_c[idx] = prim[P_U * P.prim_fs + o];
+  v_c[idx] = prim[P_V * P.prim_fs + o];
+  w_c[idx] = prim[P_W * P.prim_fs + o];
+  temp_c[idx] = press / (rho_d * P.R_d + rho_v * P.R_v);
+}
+
+// CFL time step of one cell (Dycore.h:86-99); the caller min-reduces.
+PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, const double *__restrict__ u_c,
+                       const double *__restrict__ v_c, const double *__restrict__ w_c,
+                       const double *__restrict__ temp_c, const double *__restrict__ rho_v_c, double cfl, long long idx) {
+  int k, j, i, e;
+  cell_coords(P, idx, k, j, i, e);
+  double rho_d = rho_d_c[idx], rho_v = rho_v_c[idx], temp = temp_c[idx];
+  double rho = rho_d + rho_v;
+  double p = (rho_d * P.R_d + rho_v * P.R_v) * temp;
+  double cs = sqrt(P.gamma * p / rho);
+  double dtx = cfl * P.dx / (fabs(u_c[idx]) + cs);
+  double dty = cfl * P.dy / (fabs(v_c[idx]) + cs);
+  double dtz = cfl * P.dz[(long long)k * P.nens + e] / (fabs(w_c[idx]) + cs);
+  return fmin(fmin(dtx, dty), dtz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
+PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const double *__restrict__ fy,
+                          const double *__restrict__ fz, const double *__restrict__ seed, double *__restrict__ mult,
+                          double dt, long long idx) {
+  int k, j, i, e;
+  cell_coords(P, idx, k, j, i, e);
+  const double dzk = P.dz[(long long)k * P.nens + e];
+  const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
+  const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
+  for (int t = 0; t < P.nt; t++) {
+    double m = 1.0;
+    if ((P.pos_mask >> t) & 1ull) {
+      const double *tx = fx + (long long)(5 + t) * P.ncell;
+      const double *ty = fy + (long long)(5 + t) * P.ncell;
+      const double *tz = fz + (long long)(5 + t) * P.fz_fs;
+      double mass_available = fmax(seed[(long long)t * P.ncell + idx], 0.0) * P.dx * P.dy * dzk;
+      double flux_out_x = (fmax(tx[ip1], 0.0) - fmin(tx[idx], 0.0)) / P.dx;
+      double flux_out_y = P.sim2d ? 0.0 : (fmax(ty[jp1], 0.0) - fmin(ty[idx], 0.0)) / P.dy;
+      double flux_out_z = (fmax(tz[idx + P.sz], 0.0) - fmin(tz[idx], 0.0)) / dzk;
+      double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
+      if (mass_out > mass_available) m = mass_available / mass_out;
+    }
+    mult[(long long)t * P.ncell + idx] = m;
+  }
+}
+
+// Limited tracer flux through a face, given the raw flux F, the multipliers of the cell on the low side (ml) and
+// on the high side (mh) of the face.  `seam`: the face is the periodic duplicate pair (face 0 == face n), where the
+// reference reconciles the two copies with min() (Dycore.h:574-579): a negative flux stays unlimited there (quirk Q4).
+PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
+  if (F > 0.0) return F * ml;
+  if (F < 0.0) return seam ? F : F * mh;
+  return F;
+}
+
+// Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
+// FCT seed, then the next stage's pressure / division by rho / vertical ghosts (store_adv, store_rho_pres).
+//   STAGE 1: out = in' + dt T                      seed = 3/4 in' + 1/4 out
+//   STAGE 2: out = 3/4 q0' + 1/4 in' + 1/4 dt T    seed = 1/3 q0' + 2/3 out
+//   STAGE 3: out = 1/3 q0' + 2/3 in' + 2/3 dt T    seed = out (exact conserved tracer mass for the next sub-step)
+// in' / q0' are the conserved values re-formed as (m/rho)*rho exactly as the reference's in-place round trip
+// (Dycore.h:316-320,527-532).  prim_in is the stage input, prim0 the sub-step start (STAGE>1).
+template <int STAGE>
+PAMA_D double rk_combine(double m_0, double m_in, double dt_dyn, double tend) {
+  if (STAGE == 1) return m_in + dt_dyn * tend;
+  if (STAGE == 2) return (3.0 / 4.0) * m_0 + (1.0 / 4.0) * m_in + (1.0 / 4.0) * dt_dyn * tend;
+  return (1.0 / 3.0) * m_0 + (2.0 / 3.0) * m_in + (2.0 / 3.0) * dt_dyn * tend;
+}
+
+// prim_out may alias prim_in (stage 2) or prim0 (stage 3): the update is pointwise (every input of the cell is read
+// before its outputs are written), so no __restrict__ on those.
+template <int STAGE>
+PAMA_D void update_body(const Params &P, const double *prim_in, const double *prim0,
+                        double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
+                        const double *__restrict__ fz, const double *__restrict__ mult, double *__restrict__ seed,
+                        double dt_dyn, long long idx) {
+  int k, j, i, e;
+  cell_coords(P, idx, k, j, i, e);
+  const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+  const long long o = (long long)(k + HS) * P.sz + c2;
+  const long long ke = (long long)k * P.nens + e;
+  const double dzk = P.dz[ke];
+  const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
+  const long long im1 = idx + ((i == 0) ? (long long)(P.nx - 1) * P.sx : -P.sx);
+  const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
+  const long long jm1 = idx + ((j == 0) ? (long long)(P.ny - 1) * P.sy : -P.sy);
+  const double rho_in = prim_in[P_RHO * P.prim_fs + o];
+  const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
+  // state variables: l = 0 rho, 1 rho u, 2 rho v, 3 rho w, 4 rho theta (all inputs read before any store)
+  double qs[5];
+#pragma unroll
+  for (int l = 0; l < 5; l++) {
+    const double *sx_ = fx + (long long)l * P.ncell, *sy_ = fy + (long long)l * P.ncell, *sz_ = fz + (long long)l * P.fz_fs;
+    double tend = -(sx_[ip1] - sx_[idx]) / P.dx;
+    if (!P.sim2d) tend = tend - (sy_[jp1] - sy_[idx]) / P.dy;
+    tend = tend - (sz_[idx + P.sz] - sz_[idx]) / dzk;
+    if (l == 3) {
+      if (P.grav_balance) tend += -P.grav_var[ke] * rho_in;
+      else tend += -P.grav * (rho_in - P.hy_dens[ke]);
+    }
+    if (l == 2 && P.sim2d) tend = 0.0;
+    const int pf = (l == 0) ? P_RHO : P_U + (l - 1);
+    double m_in = prim_in[pf * P.prim_fs + o];
+    if (l > 0) m_in *= rho_in;
+    double m_0 = 0.0;
+    if (STAGE > 1) {
+      m_0 = prim0[pf * P.prim_fs + o];
+      if (l > 0) m_0 *= rho_0;
+    }
+    qs[l] = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+  }
+  const double rrho = fast_rcp(qs[0]);
+  const double th = qs[4] * rrho;
+  // tracers (loads of prim_in/prim0 for tracer t happen before the store of tracer t: pointwise, alias-safe)
+  for (int t = 0; t < P.nt; t++) {
+    const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
+    const double *tz = fz + (long long)(5 + t) * P.fz_fs;
+    const double *mt = mult + (long long)t * P.ncell;
+    const double m_c = mt[idx];
+    double f_x = limited_flux(tx[idx], mt[im1], m_c, i == 0);
+    double f_xp1 = limited_flux(tx[ip1], m_c, mt[ip1], i == P.nx - 1);
+    double tend = -(f_xp1 - f_x) / P.dx;
+    if (!P.sim2d) {
+      double f_y = limited_flux(ty[idx], mt[jm1], m_c, j == 0);
+      double f_yp1 = limited_flux(ty[jp1], m_c, mt[jp1], j == P.ny - 1);
+      tend = tend - (f_yp1 - f_y) / P.dy;
+    }
+    // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
+    double f_z = limited_flux(tz[idx], (k > 0) ? mt[idx - P.sz] : 1.0, m_c, false);
+    double f_zp1 = limited_flux(tz[idx + P.sz], m_c, (k < P.nz - 1) ? mt[idx + P.sz] : 1.0, false);
+    tend = tend - (f_zp1 - f_z) / dzk;
+    const int pf = P_TR0 + t;
+    const double m_in = prim_in[pf * P.prim_fs + o] * rho_in;
+    double m_0 = 0.0;
+    if (STAGE > 1) m_0 = prim0[pf * P.prim_fs + o] * rho_0;
+    double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+    if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
+    double s = v;                                                   // stage 3: exact conserved mass
+    if (STAGE == 1) s = (3.0 / 4.0) * m_in + (1.0 / 4.0) * v;       // Dycore.h:173-174
+    if (STAGE == 2) s = (1.0 / 3.0) * m_0 + (2.0 / 3.0) * v;        // Dycore.h:197-198
+    seed[(long long)t * P.ncell + idx] = s;
+    store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
+  }
+  store_rho_pres(P, prim_out, k, c2, e, qs[0], th, qs[4], !P.grav_balance);
+  store_adv(P, prim_out, P_U, k, c2, qs[1] * rrho, qs[1] * rrho);
+  store_adv(P, prim_out, P_V, k, c2, qs[2] * rrho, qs[2] * rrho);
+  store_adv(P, prim_out, P_W, k, c2, qs[3] * rrho, 0.0);
+  store_adv(P, prim_out, P_THETA, k, c2, th, th);
+}
+
+// ------------------------------------------------------------------------------------------------
+// declare_current_profile_as_hydrostatic (Dycore.h:1439-1501).
+// interface pressure 0.5*(p_L + p_R) at face k of column (j,i,e) from the vertical WENO (Dycore.h:1457-1482)
+template <bool VZ_PER_ENS>
+PAMA_D double pint_body(const Params &P, const double *__restrict__ prim, int kf, long long c2, int e) {
+  const WenoConsts wc = weno_consts();
+  const double *pp = prim + (long long)P_PRES * P.prim_fs;
+  const long long vts = VZ_PER_ENS ? (long long)P.nens : 1;
+  double w[5], L, R, Rl, Lr;
+  // left state: right edge of cell kf-1 (stencil kf-3..kf+1); right state: left edge of cell kf
+  for (int s = 0; s < 5; s++) w[s] = pp[(long long)(kf - 3 + s + HS) * P.sz + c2];
+  const double *t0 = VZ_PER_ENS ? P.vz + ((long long)kf * VZ_STRIDE) * P.nens + e : P.vz + (long long)kf * VZ_STRIDE;
+  weno5_table(w, t0, vts, wc, L, Rl);
+  for (int s = 0; s < 5; s++) w[s] = pp[(long long)(kf - 2 + s + HS) * P.sz + c2];
+  const double *t1 = VZ_PER_ENS ? P.vz + ((long long)(kf + 1) * VZ_STRIDE) * P.nens + e : P.vz + (long long)(kf + 1) * VZ_STRIDE;
+  weno5_table(w, t1, vts, wc, Lr, R);
+  return 0.5 * (Rl + Lr);
+}
+
+// horizontal means for level k, member e, accumulated in the reference's serial order (j outer, i inner), which
+// makes the result deterministic (the reference uses atomicAdd, Dycore.h:1487,1499-1500).
+template <bool VZ_PER_ENS>
+PAMA_D void hydro_mean_body(const Params &P, const double *__restrict__ prim, double *__restrict__ grav_var,
+                            double *__restrict__ hy_dens, double *__restrict__ hy_pres, int k, int e) {
+  const double r_nx_ny = 1. / (P.nx * P.ny);
+  const long long ke = (long long)k * P.nens + e;
+  if (P.grav_balance) {
+    double g = 0.0;
+    const double dzk = P.dz[ke];
+    for (int j = 0; j < P.ny; j++)
+      for (int i = 0; i < P.nx; i++) {
+        const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+        double dens = prim[P_RHO * P.prim_fs + (long long)(k + HS) * P.sz + c2];
+        double pu = pint_body<VZ_PER_ENS>(P, prim, k + 1, c2, e), pl = pint_body<VZ_PER_ENS>(P, prim, k, c2, e);
+        g += -(pu - pl) / (dens * dzk) * r_nx_ny;
+      }
+    grav_var[ke] = g;
+  } else {
+    double hp = 0.0, hd = 0.0;
+    for (int j = 0; j < P.ny; j++)
+      for (int i = 0; i < P.nx; i++) {
+        const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
+        hp += prim[P_PRES * P.prim_fs + o] * r_nx_ny;
+        hd += prim[P_RHO * P.prim_fs + o] * r_nx_ny;
+      }
+    hy_pres[ke] = hp;
+    hy_dens[ke] = hd;
+  }
+}
+
+}  // namespace pama

@@ -1,0 +1,594 @@
+// awfl_kernels.hip -- gfx950 kernels, host orchestration and C ABI of the MI355X-native AWFL dycore step.
+//
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -fPIC -shared ... -o libpam_amd_awfl.so
+// Declared in include/pam_amd_awfl.h.  There is no CPU fallback: without a HIP device every compute entry point
+// returns PAM_AMD_ENOGPU.
+//
+// Launch structure of one SSPRK3 sub-step (reference: 3 x Dycore::compute_tendencies + 3 combines, Dycore.h:147-222;
+// ~18 launches and ~13 allocations there):
+//     per stage:  awfl_flux_kernel   (x, y and z sweeps in ONE launch; Dycore.h:334-519)
+//                 awfl_fct_kernel    (FCT multiplier; Dycore.h:525-550)
+//                 awfl_update_kernel (divergence+gravity+RK combine+next stage's pressure/divide/ghosts;
+//                                     Dycore.h:553-584,162-221,310-321,662-710)
+// All scratch is allocated once in init.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pam_amd_awfl.h"
+#include "awfl_device.h"
+#include "awfl_vertical.h"
+
+using namespace pama;
+
+// ------------------------------------------------------------------------------------------------ kernels
+// grid: [0,nbx) x-sweep blocks, [nbx,nbx+nby) y-sweep, rest z-sweep.  Within a sweep: block -> (item block of 64
+// items, group of 4 segments); wavefront w of the block takes segment 4*group+w.
+struct FluxGrid { int nbx, nby, nbz; int sgx, sgy, sgz; /* segment groups (of 4) per line */ };
+
+template <bool VZ_PER_ENS>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxGrid G, const double *__restrict__ prim,
+                                                                  double *__restrict__ fx, double *__restrict__ fy,
+                                                                  double *__restrict__ fz) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  if (b < G.nbx) {
+    const int grp = b % G.sgx, ib = b / G.sgx;
+    const int f0 = (grp * 4 + wave) * P.seg;
+    const long long item = (long long)ib * 64 + lane;
+    if (f0 < P.nx && item < (long long)P.nz * P.ny * P.nens)
+      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, item, f0, lds, FLUX_THREADS, tid);
+  } else if (b < G.nbx + G.nby) {
+    b -= G.nbx;
+    const int grp = b % G.sgy, ib = b / G.sgy;
+    const int f0 = (grp * 4 + wave) * P.seg;
+    const long long item = (long long)ib * 64 + lane;
+    if (f0 < P.ny && item < (long long)P.nz * P.nx * P.nens)
+      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, item, f0, lds, FLUX_THREADS, tid);
+  } else {
+    b -= G.nbx + G.nby;
+    const int grp = b % G.sgz, ib = b / G.sgz;
+    const int f0 = (grp * 4 + wave) * P.seg;
+    const long long item = (long long)ib * 64 + lane;
+    if (f0 < P.nz + 1 && item < (long long)P.ny * P.nx * P.nens)
+      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, item, f0, lds, FLUX_THREADS, tid);
+  }
+}
+
+__global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, const double *__restrict__ fx,
+                                                       const double *__restrict__ fy, const double *__restrict__ fz,
+                                                       const double *__restrict__ seed, double *__restrict__ mult,
+                                                       double dt) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < P.ncell) fct_mult_body(P, fx, fy, fz, seed, mult, dt, idx);
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_update_kernel(Params P, const double *prim_in, const double *prim0,
+                                                          double *prim_out, const double *__restrict__ fx,
+                                                          const double *__restrict__ fy, const double *__restrict__ fz,
+                                                          const double *__restrict__ mult, double *__restrict__ seed,
+                                                          double dt_dyn) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < P.ncell) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, idx);
+}
+
+struct GcmPtrs { const double *p[5]; int use; };
+
+__global__ void __launch_bounds__(256) awfl_init_prim_kernel(Params P, const double *__restrict__ rho_d,
+                                                             const double *__restrict__ u, const double *__restrict__ v,
+                                                             const double *__restrict__ w, const double *__restrict__ temp,
+                                                             TracerPtrs trc, GcmPtrs gcm, double *__restrict__ prim,
+                                                             double *__restrict__ seed, int subtract_hy) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < P.ncell) init_prim_body(P, rho_d, u, v, w, temp, trc, gcm.use ? gcm.p : nullptr, prim, seed, subtract_hy != 0, idx);
+}
+
+__global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, const double *__restrict__ prim,
+                                                            const double *__restrict__ seed, double *__restrict__ rho_d,
+                                                            double *__restrict__ u, double *__restrict__ v,
+                                                            double *__restrict__ w, double *__restrict__ temp,
+                                                            TracerPtrs trc) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < P.ncell) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, idx);
+}
+
+// CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, one atomicMin per wavefront on the
+// bit pattern (positive doubles order like unsigned integers).
+__global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *__restrict__ rho_d,
+                                                       const double *__restrict__ u, const double *__restrict__ v,
+                                                       const double *__restrict__ w, const double *__restrict__ temp,
+                                                       const double *__restrict__ rho_v, double cfl,
+                                                       unsigned long long *result) {
+  double m = INFINITY;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < P.ncell;
+       idx += (long long)gridDim.x * blockDim.x)
+    m = fmin(m, cfl_body(P, rho_d, u, v, w, temp, rho_v, cfl, idx));
+  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    if (!(m > 0.0)) m = 0.0;   // NaN or non-positive: propagate as 0 (the host reports it)
+    atomicMin(result, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+template <bool VZ_PER_ENS>
+__global__ void __launch_bounds__(64) awfl_hydro_kernel(Params P, const double *__restrict__ prim, double *grav_var,
+                                                        double *hy_dens, double *hy_pres) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long long)P.nz * P.nens)
+    hydro_mean_body<VZ_PER_ENS>(P, prim, grav_var, hy_dens, hy_pres, (int)(idx / P.nens), (int)(idx % P.nens));
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                    \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess)                                                                                \
+      return fail(_e == hipErrorOutOfMemory ? PAM_AMD_ENOMEM : PAM_AMD_ENOGPU,                           \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                                    \
+  } while (0)
+
+struct KernelTimer {
+  double total_ms = 0;
+  long long launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct pam_amd_awfl {
+  pam_amd_awfl_config_t cfg;
+  Params P;
+  hipStream_t stream = nullptr;
+  // options (Dycore.h:871-891)
+  double R_d, cp_d, R_v, cp_v, p0, grav, cv_d, gamma_d, kappa_d, cv_v, C0;
+  // device buffers
+  double *prim0 = nullptr, *prim1 = nullptr, *flux_x = nullptr, *flux_y = nullptr, *flux_z = nullptr;
+  double *seed = nullptr, *mult = nullptr, *dz = nullptr, *grav_var = nullptr, *hy_dens = nullptr, *hy_pres = nullptr;
+  double *vz = nullptr, *vert_s2c = nullptr, *vert_wrl = nullptr;
+  unsigned long long *dt_bits = nullptr;
+  size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
+  bool timing = false;
+  bool hydro_declared = false;
+  std::map<std::string, KernelTimer> timers;
+};
+
+namespace {
+
+struct ScopedTimer {
+  pam_amd_awfl *h;
+  KernelTimer *t = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(pam_amd_awfl *h_, const char *name) : h(h_) {
+    if (!h->timing) return;
+    t = &h->timers[name];
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipEventRecord(a, h->stream);
+  }
+  ~ScopedTimer() {
+    if (!t) return;
+    hipEventRecord(b, h->stream);
+    t->pending.emplace_back(a, b);
+    t->launches++;
+  }
+};
+
+void drain(KernelTimer &t) {
+  for (auto &p : t.pending) {
+    hipEventSynchronize(p.second);
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.first, p.second);
+    t.total_ms += ms;
+    hipEventDestroy(p.first);
+    hipEventDestroy(p.second);
+  }
+  t.pending.clear();
+}
+
+inline int nblocks(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+int make_tracer_ptrs(const pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, TracerPtrs &tp) {
+  if (!f || !f->density_dry || !f->uvel || !f->vvel || !f->wvel || !f->temp || !f->tracers)
+    return fail(PAM_AMD_EINVAL, "fields: null pointer");
+  for (int t = 0; t < MAXT; t++) tp.p[t] = nullptr;
+  for (int t = 0; t < h->P.nt; t++) {
+    if (!f->tracers[t]) return fail(PAM_AMD_EINVAL, "fields: null tracer pointer");
+    tp.p[t] = f->tracers[t];
+  }
+  return PAM_AMD_OK;
+}
+
+int launch_init_prim(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, const pam_amd_awfl_gcm_columns_t *gcm,
+                     bool subtract_hy) {
+  TracerPtrs tp;
+  int rc = make_tracer_ptrs(h, f, tp);
+  if (rc) return rc;
+  GcmPtrs gp;
+  gp.use = gcm ? 1 : 0;
+  if (gcm) {
+    gp.p[0] = gcm->gcm_density_dry; gp.p[1] = gcm->gcm_temp; gp.p[2] = gcm->gcm_water_vapor;
+    gp.p[3] = gcm->gcm_cloud_water; gp.p[4] = gcm->gcm_cloud_ice;
+    for (int i = 0; i < 5; i++) if (!gp.p[i]) return fail(PAM_AMD_EINVAL, "gcm columns: null pointer");
+  } else {
+    for (int i = 0; i < 5; i++) gp.p[i] = nullptr;
+  }
+  ScopedTimer st(h, "init_prim");
+  hipLaunchKernelGGL(awfl_init_prim_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P,
+                     f->density_dry, f->uvel, f->vvel, f->wvel, f->temp, tp, gp, h->prim0, h->seed, subtract_hy ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int launch_flux(pam_amd_awfl *h, const double *prim) {
+  const Params &P = h->P;
+  FluxGrid G;
+  auto groups = [&](int nfaces) { return ((nfaces + P.seg - 1) / P.seg + 3) / 4; };
+  G.sgx = groups(P.nx); G.sgy = groups(P.ny); G.sgz = groups(P.nz + 1);
+  G.nbx = nblocks((long long)P.nz * P.ny * P.nens, 64) * G.sgx;
+  G.nby = P.sim2d ? 0 : nblocks((long long)P.nz * P.nx * P.nens, 64) * G.sgy;
+  G.nbz = nblocks((long long)P.ny * P.nx * P.nens, 64) * G.sgz;
+  const size_t lds_bytes = (size_t)2 * P.seg * FLUX_THREADS * sizeof(double);
+  ScopedTimer st(h, "flux");
+  if (P.vz_per_ens)
+    hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, h->stream, P, G,
+                       prim, h->flux_x, h->flux_y, h->flux_z);
+  else
+    hipLaunchKernelGGL(awfl_flux_kernel<false>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, h->stream, P,
+                       G, prim, h->flux_x, h->flux_y, h->flux_z);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int launch_fct(pam_amd_awfl *h, double dt) {
+  ScopedTimer st(h, "fct_mult");
+  hipLaunchKernelGGL(awfl_fct_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, h->flux_x, h->flux_y,
+                     h->flux_z, h->seed, h->mult, dt);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+template <int STAGE>
+int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn) {
+  ScopedTimer st(h, "update");
+  hipLaunchKernelGGL(awfl_update_kernel<STAGE>, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, prim_in,
+                     prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, double *dt) {
+  if (!f || !f->tracers) return fail(PAM_AMD_EINVAL, "fields: null pointer");
+  const unsigned long long init = 0x7FF0000000000000ull;   // +inf
+  HIP_TRY(hipMemcpyAsync(h->dt_bits, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  {
+    ScopedTimer st(h, "cfl");
+    int nb = nblocks(h->P.ncell, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(awfl_cfl_kernel, dim3(nb), dim3(256), 0, h->stream, h->P, f->density_dry, f->uvel, f->vvel, f->wvel,
+                       f->temp, f->tracers[h->P.idWV], cfl, h->dt_bits);
+    HIP_TRY(hipGetLastError());
+  }
+  unsigned long long bits = 0;
+  HIP_TRY(hipMemcpyAsync(&bits, h->dt_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double v;
+  std::memcpy(&v, &bits, sizeof(v));
+  *dt = v;
+  return PAM_AMD_OK;
+}
+
+void free_all(pam_amd_awfl *h) {
+  double **bufs[] = {&h->prim0, &h->prim1, &h->flux_x, &h->flux_y, &h->flux_z, &h->seed, &h->mult, &h->dz,
+                     &h->grav_var, &h->hy_dens, &h->hy_pres, &h->vz, &h->vert_s2c, &h->vert_wrl};
+  for (auto b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (h->dt_bits) (void)hipFree(h->dt_bits);
+  h->dt_bits = nullptr;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int pam_amd_awfl_abi_version(void) { return PAM_AMD_AWFL_ABI_VERSION; }
+const char *pam_amd_awfl_last_error(void) { return g_last_error.c_str(); }
+
+int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
+  if (!cfg || !out) return fail(PAM_AMD_EINVAL, "init: null argument");
+  *out = nullptr;
+  if (cfg->nens < 1 || cfg->nx < 3 || cfg->nz < 3 || cfg->ny < 1 || (cfg->ny > 1 && cfg->ny < 3))
+    return fail(PAM_AMD_EINVAL, "init: need nens>=1, nx>=3, nz>=3 and ny==1 or ny>=3 (periodic stencils of half-width 3)");
+  if (cfg->num_tracers < 1 || cfg->num_tracers > MAXT)
+    return fail(PAM_AMD_EINVAL, "init: num_tracers must be in [1,50] (pam_const.h max_fields)");
+  if (cfg->idWV < 0 || cfg->idWV >= cfg->num_tracers) return fail(PAM_AMD_EINVAL, "init: idWV out of range (tracer water_vapor missing?)");
+  if (!(cfg->xlen > 0) || !(cfg->ylen > 0)) return fail(PAM_AMD_EINVAL, "init: xlen/ylen must be positive (set_grid not called?)");
+  if (!cfg->tracer_positive || !cfg->tracer_adds_mass || !cfg->vertical_cell_dz)
+    return fail(PAM_AMD_EINVAL, "init: null tracer flags or vertical_cell_dz");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(PAM_AMD_ENOGPU, "init: no HIP device available (this library has no CPU path)");
+
+  pam_amd_awfl *h = new pam_amd_awfl();
+  h->cfg = *cfg;
+  h->stream = (hipStream_t)cfg->stream;
+  auto opt = [](double v, double dflt) { return std::isnan(v) ? dflt : v; };
+  h->R_d = opt(cfg->R_d, 287.);   h->cp_d = opt(cfg->cp_d, 1003.);
+  h->R_v = opt(cfg->R_v, 461.);   h->cp_v = opt(cfg->cp_v, 1859.);
+  h->p0 = opt(cfg->p0, 1.e5);     h->grav = opt(cfg->grav, 9.81);
+  h->cv_d = h->cp_d - h->R_d;
+  h->gamma_d = h->cp_d / h->cv_d;
+  h->kappa_d = h->R_d / h->cp_d;
+  h->cv_v = h->R_v - h->cp_v;
+  h->C0 = std::pow(h->R_d * std::pow(h->p0, -h->kappa_d), h->gamma_d);
+
+  Params &P = h->P;
+  std::memset(&P, 0, sizeof(P));
+  P.nens = cfg->nens; P.nx = cfg->nx; P.ny = cfg->ny; P.nz = cfg->nz; P.nt = cfg->num_tracers;
+  P.sim2d = (cfg->ny == 1);
+  P.grav_balance = 1;   // Dycore.h:866
+  P.seg = 8;
+  P.dx = cfg->xlen / cfg->nx; P.dy = cfg->ylen / cfg->ny; P.rdx = 1.0 / P.dx; P.rdy = 1.0 / P.dy;
+  P.C0 = h->C0; P.gamma = h->gamma_d; P.grav = h->grav; P.R_d = h->R_d; P.R_v = h->R_v;
+  P.sx = P.nens; P.sy = (long long)P.nx * P.nens; P.sz = (long long)P.ny * P.nx * P.nens;
+  P.prim_fs = (long long)(P.nz + 2 * HS) * P.sz;
+  P.ncell = (long long)P.nz * P.sz;
+  P.fz_fs = (long long)(P.nz + 1) * P.sz;
+  P.idWV = cfg->idWV;
+  for (int t = 0; t < P.nt; t++) {
+    if (cfg->tracer_positive[t]) P.pos_mask |= (1ull << t);
+    if (cfg->tracer_adds_mass[t]) P.mass_mask |= (1ull << t);
+  }
+
+  const size_t nzn = (size_t)P.nz * P.nens;
+  std::vector<double> dz_host(nzn);
+  auto bail = [&](int code, const std::string &m) { free_all(h); delete h; return fail(code, m); };
+#define INIT_TRY(expr)                                                                                    \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      return bail(_e == hipErrorOutOfMemory ? PAM_AMD_ENOMEM : PAM_AMD_ENOGPU, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+  INIT_TRY(hipMemcpy(dz_host.data(), cfg->vertical_cell_dz, nzn * sizeof(double), hipMemcpyDefault));
+  for (size_t i = 0; i < nzn; i++)
+    if (!(dz_host[i] > 0)) return bail(PAM_AMD_EINVAL, "init: vertical_cell_dz must be positive (set_grid not called?)");
+  VerticalTables vt = build_vertical_tables(dz_host.data(), P.nz, P.nens);
+  P.vz_per_ens = vt.per_ens ? 1 : 0;
+
+  h->n_prim = (size_t)(6 + P.nt) * P.prim_fs;
+  h->n_flux_xy = (size_t)(5 + P.nt) * P.ncell;
+  h->n_flux_z = (size_t)(5 + P.nt) * P.fz_fs;
+  h->n_seed = (size_t)P.nt * P.ncell;
+  INIT_TRY(hipMalloc(&h->prim0, h->n_prim * 8));
+  INIT_TRY(hipMalloc(&h->prim1, h->n_prim * 8));
+  INIT_TRY(hipMalloc(&h->flux_x, h->n_flux_xy * 8));
+  INIT_TRY(hipMalloc(&h->flux_y, (P.sim2d ? 8 : h->n_flux_xy) * 8));
+  INIT_TRY(hipMalloc(&h->flux_z, h->n_flux_z * 8));
+  INIT_TRY(hipMalloc(&h->seed, h->n_seed * 8));
+  INIT_TRY(hipMalloc(&h->mult, h->n_seed * 8));
+  INIT_TRY(hipMalloc(&h->dz, nzn * 8));
+  INIT_TRY(hipMalloc(&h->grav_var, nzn * 8));
+  INIT_TRY(hipMalloc(&h->hy_dens, nzn * 8));
+  INIT_TRY(hipMalloc(&h->hy_pres, nzn * 8));
+  INIT_TRY(hipMalloc(&h->vz, vt.table.size() * 8));
+  INIT_TRY(hipMalloc(&h->vert_s2c, vt.s2c.size() * 8));
+  INIT_TRY(hipMalloc(&h->vert_wrl, vt.wrl.size() * 8));
+  INIT_TRY(hipMalloc(&h->dt_bits, 8));
+  INIT_TRY(hipMemcpy(h->dz, dz_host.data(), nzn * 8, hipMemcpyHostToDevice));
+  INIT_TRY(hipMemcpy(h->vz, vt.table.data(), vt.table.size() * 8, hipMemcpyHostToDevice));
+  INIT_TRY(hipMemcpy(h->vert_s2c, vt.s2c.data(), vt.s2c.size() * 8, hipMemcpyHostToDevice));
+  INIT_TRY(hipMemcpy(h->vert_wrl, vt.wrl.data(), vt.wrl.size() * 8, hipMemcpyHostToDevice));
+  // the reference leaves variable_gravity / hy_* unset until declare_current_profile_as_hydrostatic;
+  // poison them so a missing call is loud (NaN state) instead of silently wrong.
+  INIT_TRY(hipMemset(h->grav_var, 0xFF, nzn * 8));
+  INIT_TRY(hipMemset(h->hy_dens, 0xFF, nzn * 8));
+  INIT_TRY(hipMemset(h->hy_pres, 0xFF, nzn * 8));
+  P.dz = h->dz; P.grav_var = h->grav_var; P.hy_dens = h->hy_dens; P.hy_pres = h->hy_pres; P.vz = h->vz;
+#undef INIT_TRY
+  *out = h;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_finalize(pam_amd_awfl_t *h) {
+  if (!h) return PAM_AMD_OK;
+  (void)hipStreamSynchronize(h->stream);
+  for (auto &kv : h->timers) drain(kv.second);
+  free_all(h);
+  delete h;
+  return PAM_AMD_OK;
+}
+
+const char *pam_amd_awfl_dycore_name(const pam_amd_awfl_t *) { return "SSPRK3+WENO+FV A-grid (MI355X native)"; }
+
+int pam_amd_awfl_get_option(const pam_amd_awfl_t *h, const char *key, double *value) {
+  if (!h || !key || !value) return fail(PAM_AMD_EINVAL, "get_option: null argument");
+  const std::string k(key);
+  if (k == "R_d") *value = h->R_d;
+  else if (k == "R_v") *value = h->R_v;
+  else if (k == "cp_d") *value = h->cp_d;
+  else if (k == "cp_v") *value = h->cp_v;
+  else if (k == "p0") *value = h->p0;
+  else if (k == "grav") *value = h->grav;
+  else if (k == "cv_d") *value = h->cv_d;
+  else if (k == "cv_v") *value = h->cv_v;
+  else if (k == "gamma_d") *value = h->gamma_d;
+  else if (k == "kappa_d") *value = h->kappa_d;
+  else if (k == "C0") *value = h->C0;
+  else if (k == "balance_hydrostasis_with_gravity") *value = h->P.grav_balance;
+  else if (k == "idWV") *value = h->P.idWV;
+  else return fail(PAM_AMD_EINVAL, "ERROR: option " + k + " does not exist");   // Options.h get_option -> endrun
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_balance_hydrostasis_with_gravity(pam_amd_awfl_t *h, int value) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  h->P.grav_balance = value ? 1 : 0;
+  h->hydro_declared = false;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_ptr, int dims[5], int *ndims) {
+  if (!h || !name || !device_ptr || !dims || !ndims) return fail(PAM_AMD_EINVAL, "get_array: null argument");
+  const std::string k(name);
+  const Params &P = h->P;
+  if (k == "variable_gravity" || k == "hy_dens_cells" || k == "hy_pressure_cells") {
+    *device_ptr = (k == "variable_gravity") ? h->grav_var : (k == "hy_dens_cells" ? h->hy_dens : h->hy_pres);
+    dims[0] = P.nz; dims[1] = P.nens; *ndims = 2;
+  } else if (k == "vert_sten_to_coefs") {
+    *device_ptr = h->vert_s2c; dims[0] = P.nz + 2; dims[1] = 5; dims[2] = 5; dims[3] = P.nens; *ndims = 4;
+  } else if (k == "vert_weno_recon_lower") {
+    *device_ptr = h->vert_wrl; dims[0] = P.nz + 2; dims[1] = 3; dims[2] = 3; dims[3] = 3; dims[4] = P.nens; *ndims = 5;
+  } else {
+    return fail(PAM_AMD_EINVAL, "ERROR: array " + k + " is not owned by the dycore");
+  }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields,
+                                                        const pam_amd_awfl_gcm_columns_t *gcm) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  int rc = launch_init_prim(h, fields, gcm, /*subtract_hy=*/false);
+  if (rc) return rc;
+  {
+    ScopedTimer st(h, "hydro");
+    const long long n = (long long)h->P.nz * h->P.nens;
+    if (h->P.vz_per_ens)
+      hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->grav_var,
+                         h->hy_dens, h->hy_pres);
+    else
+      hipLaunchKernelGGL(awfl_hydro_kernel<false>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->grav_var,
+                         h->hy_dens, h->hy_pres);
+    HIP_TRY(hipGetLastError());
+  }
+  h->hydro_declared = true;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_compute_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double cfl, double *dt) {
+  if (!h || !dt) return fail(PAM_AMD_EINVAL, "compute_time_step: null argument");
+  return local_time_step(h, fields, cfl, dt);
+}
+
+int pam_amd_awfl_convert_coupler_to_dynamics(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  return launch_init_prim(h, fields, nullptr, !h->P.grav_balance);
+}
+
+int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  TracerPtrs tp;
+  int rc = make_tracer_ptrs(h, fields, tp);
+  if (rc) return rc;
+  ScopedTimer st(h, "finalize");
+  hipLaunchKernelGGL(awfl_finalize_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->seed,
+                     fields->density_dry, fields->uvel, fields->vvel, fields->wvel, fields->temp, tp);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double crm_dt, double dt_dyn_hint,
+                           int *ncycles_out, double *dt_dyn_out) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (!(crm_dt > 0)) return fail(PAM_AMD_EINVAL, "time_step: option crm_dt must be positive");
+  if (!h->hydro_declared)
+    return fail(PAM_AMD_ESTATE, "time_step: declare_current_profile_as_hydrostatic has not been called since init / "
+                                "since the balance option changed (variable_gravity / hy_* are undefined, SURVEY F4)");
+  // Dycore.h:128-134
+  int rc = pam_amd_awfl_convert_coupler_to_dynamics(h, fields);
+  if (rc) return rc;
+  // Dycore.h:141-145
+  double dt_dyn = dt_dyn_hint;
+  if (!(dt_dyn > 0)) {
+    rc = local_time_step(h, fields, 0.8, &dt_dyn);
+    if (rc) return rc;
+    if (!(dt_dyn > 0) || !std::isfinite(dt_dyn))
+      return fail(PAM_AMD_EINVAL, "time_step: CFL time step is not positive/finite (NaN or non-physical coupler state)");
+  }
+  const int ncycles = (int)std::ceil(crm_dt / dt_dyn);
+  dt_dyn = crm_dt / ncycles;
+  if (ncycles_out) *ncycles_out = ncycles;
+  if (dt_dyn_out) *dt_dyn_out = dt_dyn;
+  for (int ic = 0; ic < ncycles; ic++) {
+    // stage 1 (Dycore.h:156-176)
+    if ((rc = launch_flux(h, h->prim0))) return rc;
+    if ((rc = launch_fct(h, dt_dyn))) return rc;
+    if ((rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn))) return rc;
+    // stage 2 (Dycore.h:180-200)
+    if ((rc = launch_flux(h, h->prim1))) return rc;
+    if ((rc = launch_fct(h, (1.0 / 4.0) * dt_dyn))) return rc;
+    if ((rc = launch_update<2>(h, h->prim1, h->prim0, h->prim1, dt_dyn))) return rc;
+    // stage 3 (Dycore.h:204-221)
+    if ((rc = launch_flux(h, h->prim1))) return rc;
+    if ((rc = launch_fct(h, (2.0 / 3.0) * dt_dyn))) return rc;
+    if ((rc = launch_update<3>(h, h->prim1, h->prim0, h->prim0, dt_dyn))) return rc;
+  }
+  // Dycore.h:254
+  return pam_amd_awfl_convert_dynamics_to_coupler(h, fields);
+}
+
+int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  h->timing = enable != 0;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches) {
+  if (!h || !name || !total_ms || !launches) return fail(PAM_AMD_EINVAL, "get_kernel_timing: null argument");
+  auto it = h->timers.find(name);
+  if (it == h->timers.end()) { *total_ms = 0; *launches = 0; return PAM_AMD_OK; }
+  drain(it->second);
+  *total_ms = it->second.total_ms;
+  *launches = it->second.launches;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  for (auto &kv : h->timers) drain(kv.second);
+  h->timers.clear();
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (faces < 1 || faces > 32) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,32]");
+  h->P.seg = faces;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem) {
+  if (!h || !name || !device_ptr || !nelem) return fail(PAM_AMD_EINVAL, "debug_get_buffer: null argument");
+  const std::string k(name);
+  if (k == "prim0") { *device_ptr = h->prim0; *nelem = h->n_prim; }
+  else if (k == "prim1") { *device_ptr = h->prim1; *nelem = h->n_prim; }
+  else if (k == "flux_x") { *device_ptr = h->flux_x; *nelem = h->n_flux_xy; }
+  else if (k == "flux_y") { *device_ptr = h->flux_y; *nelem = h->P.sim2d ? 0 : h->n_flux_xy; }
+  else if (k == "flux_z") { *device_ptr = h->flux_z; *nelem = h->n_flux_z; }
+  else if (k == "seed") { *device_ptr = h->seed; *nelem = h->n_seed; }
+  else if (k == "mult") { *device_ptr = h->mult; *nelem = h->n_seed; }
+  else return fail(PAM_AMD_EINVAL, "debug_get_buffer: unknown buffer " + k);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  int rc;
+  if ((rc = launch_flux(h, h->prim0))) return rc;
+  return launch_fct(h, dt);
+}
+
+}  // extern "C"

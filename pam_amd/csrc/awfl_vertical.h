@@ -1,0 +1,126 @@
+// awfl_vertical.h -- host-side construction of the per-level vertical WENO matrices (init time only).
+//
+// Restates dynamics/awfl/Dycore.h:904-937 (normalised cell-edge locations per level, including the reference's
+// off-centre indexing: level k is built from cells k-1..k+3) and
+// dynamics/awfl/TransformMatrices_variable.h:11-69 (Vandermonde of cell-average monomials, inverted).
+// The reference inverts with yakl::intrinsics::matinv_ge, a third-party routine absent from the tree (YAKL
+// submodule, version unpinned); here it is Gauss-Jordan elimination without pivoting, (col,row) order.
+//
+// Output per level (and per ensemble member): 52 doubles
+//   [0..26]  vert_weno_recon_lower(k,i,s,ii)          -- as the reference stores it
+//   [27..51] bridged upper matrix B(s,ii) = (vert_sten_to_coefs(k,s,ii) - sum_i idl_i lower(i,s-i,ii)) / idl_3
+//            i.e. WenoLimiter.h:128-136 folded into the matrix (linear in the stencil, so exact up to rounding).
+// The un-bridged vert_sten_to_coefs is also returned for the DataManager entry of that name.
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "awfl_constants.h"
+
+namespace pama {
+
+inline void matinv_ge_host(int n, const double *a, double *inv) {
+  double scratch[25];
+  for (int icol = 0; icol < n; icol++)
+    for (int irow = 0; irow < n; irow++) {
+      scratch[icol * n + irow] = a[icol * n + irow];
+      inv[icol * n + irow] = (icol == irow) ? 1.0 : 0.0;
+    }
+  for (int d = 0; d < n; d++) {
+    double factor = 1.0 / scratch[d * n + d];
+    for (int icol = d; icol < n; icol++) scratch[icol * n + d] *= factor;
+    for (int icol = 0; icol < n; icol++) inv[icol * n + d] *= factor;
+    for (int irow = d + 1; irow < n; irow++) {
+      double f = scratch[d * n + irow];
+      for (int icol = d; icol < n; icol++) scratch[icol * n + irow] -= f * scratch[icol * n + d];
+      for (int icol = 0; icol < n; icol++) inv[icol * n + irow] -= f * inv[icol * n + d];
+    }
+  }
+  for (int d = n - 1; d >= 1; d--)
+    for (int irow = 0; irow < d; irow++) {
+      double f = scratch[d * n + irow];
+      for (int icol = irow + 1; icol < n; icol++) scratch[icol * n + irow] -= f * scratch[icol * n + d];
+      for (int icol = 0; icol < n; icol++) inv[icol * n + irow] -= f * inv[icol * n + d];
+    }
+}
+
+// TransformMatrices_variable.h:11-46
+inline void sten_to_coefs_variable_host(int n, const double *locs, double *rslt) {
+  double c2s[25], pwr[6];
+  for (int i = 0; i < n + 1; i++) pwr[i] = locs[i];
+  for (int i = 0; i < n; i++) c2s[i] = 1;
+  for (int i = 1; i < n; i++) {
+    for (int j = 0; j < n + 1; j++) pwr[j] *= locs[j];
+    for (int j = 0; j < n; j++) c2s[i * n + j] = 1. / (i + 1.) * (pwr[j] - pwr[j + 1]) / (locs[j] - locs[j + 1]);
+  }
+  matinv_ge_host(n, c2s, rslt);
+}
+
+struct VerticalTables {
+  bool per_ens;                 // false: all ensemble members share one dz column
+  std::vector<double> table;    // (nz+2,52) or (nz+2,52,nens)
+  std::vector<double> s2c;      // vert_sten_to_coefs    (nz+2,5,5,nens)
+  std::vector<double> wrl;      // vert_weno_recon_lower (nz+2,3,3,3,nens)
+};
+
+inline void level_matrices(const double *dzcol /* stride nens */, long long stride, int nz, int k, double s2c[25],
+                           double wrl[27], double bridged[25]) {
+  double dzloc[5], locs[6];
+  for (int kk = 0; kk < 5; kk++) {
+    int ind1 = std::min(nz - 1, std::max(0, -1 + k + kk));
+    int ind2 = std::min(nz - 1, std::max(0, -1 + k));
+    dzloc[kk] = dzcol[ind1 * stride] / dzcol[ind2 * stride];
+  }
+  locs[0] = 0;
+  for (int kk = 1; kk < 6; kk++) locs[kk] = locs[kk - 1] + dzloc[kk - 1];
+  double midloc = (locs[2] + locs[3]) / 2;
+  for (int kk = 0; kk < 6; kk++) locs[kk] = locs[kk] - midloc;
+  sten_to_coefs_variable_host(5, locs, s2c);
+  for (int i = 0; i < 3; i++) {
+    double lo[9];
+    sten_to_coefs_variable_host(3, locs + i, lo);
+    for (int jj = 0; jj < 3; jj++)
+      for (int ii = 0; ii < 3; ii++) wrl[(i * 3 + jj) * 3 + ii] = lo[jj * 3 + ii];
+  }
+  const double raw[4] = AWFL_WENO_IDL_INIT;
+  double sum = ((raw[0] + raw[1]) + raw[2]) + raw[3], idl[4];
+  for (int i = 0; i < 4; i++) idl[i] = raw[i] / (sum + 1.0e-20);
+  for (int s = 0; s < 5; s++)
+    for (int ii = 0; ii < 5; ii++) {
+      double b = s2c[s * 5 + ii];
+      if (ii < 3)
+        for (int i = 0; i < 3; i++)
+          if (s - i >= 0 && s - i < 3) b -= idl[i] * wrl[(i * 3 + (s - i)) * 3 + ii];
+      bridged[s * 5 + ii] = b / idl[3];
+    }
+}
+
+// dz: host copy of vertical_cell_dz (nz,nens)
+inline VerticalTables build_vertical_tables(const double *dz, int nz, int nens) {
+  VerticalTables vt;
+  vt.per_ens = false;
+  for (int k = 0; k < nz && !vt.per_ens; k++)
+    for (int e = 1; e < nens; e++)
+      if (dz[(long long)k * nens + e] != dz[(long long)k * nens]) { vt.per_ens = true; break; }
+  const int nl = nz + 2;
+  vt.s2c.assign((size_t)nl * 25 * nens, 0.0);
+  vt.wrl.assign((size_t)nl * 27 * nens, 0.0);
+  vt.table.assign((size_t)nl * 52 * (vt.per_ens ? nens : 1), 0.0);
+  for (int k = 0; k < nl; k++) {
+    double s2c[25], wrl[27], br[25];
+    for (int e = 0; e < nens; e++) {
+      if (e == 0 || vt.per_ens) level_matrices(dz + e, nens, nz, k, s2c, wrl, br);
+      for (int m = 0; m < 25; m++) vt.s2c[((size_t)k * 25 + m) * nens + e] = s2c[m];
+      for (int m = 0; m < 27; m++) vt.wrl[((size_t)k * 27 + m) * nens + e] = wrl[m];
+      if (vt.per_ens) {
+        for (int m = 0; m < 27; m++) vt.table[((size_t)k * 52 + m) * nens + e] = wrl[m];
+        for (int m = 0; m < 25; m++) vt.table[((size_t)k * 52 + 27 + m) * nens + e] = br[m];
+      } else if (e == 0) {
+        for (int m = 0; m < 27; m++) vt.table[(size_t)k * 52 + m] = wrl[m];
+        for (int m = 0; m < 25; m++) vt.table[(size_t)k * 52 + 27 + m] = br[m];
+      }
+    }
+  }
+  return vt;
+}
+
+}  // namespace pama

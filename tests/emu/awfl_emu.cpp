@@ -1,0 +1,184 @@
+// awfl_emu.cpp -- HOST EMULATION of the HIP kernel bodies.  TEST INFRASTRUCTURE ONLY (never shipped, never
+// linked into libpam_amd_awfl.so, never used by bench.py or the product package).
+//
+// It compiles pam_amd/csrc/awfl_device.h with g++ and runs every kernel body once per (block, thread) in plain
+// loops, with the launch geometry of pam_amd/csrc/awfl_kernels.hip, so that the index logic (segments, periodic
+// wrap, ghosts, FCT seam, RK aliasing) can be compared with the oracle on a machine without a GPU.
+// Differences to the device build: true division instead of v_rcp_f64+Newton, glibc pow, and whatever
+// contraction g++ applies -- i.e. rounding-level only.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../pam_amd/csrc/awfl_device.h"
+#include "../../pam_amd/csrc/awfl_vertical.h"
+
+using namespace pama;
+
+struct Emu {
+  Params P;
+  std::vector<double> prim0, prim1, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
+  VerticalTables vt;
+};
+
+static void flux_launch(Emu *h, const double *prim) {
+  const Params &P = h->P;
+  auto groups = [&](int nfaces) { return ((nfaces + P.seg - 1) / P.seg + 3) / 4; };
+  std::vector<double> lds((size_t)2 * P.seg * FLUX_THREADS);
+  for (int dir = 0; dir < 3; dir++) {
+    if (dir == 1 && P.sim2d) continue;
+    const int nfaces = dir == 0 ? P.nx : (dir == 1 ? P.ny : P.nz + 1);
+    const long long nitems = dir == 0 ? (long long)P.nz * P.ny * P.nens
+                                      : (dir == 1 ? (long long)P.nz * P.nx * P.nens : (long long)P.ny * P.nx * P.nens);
+    const int sg = groups(nfaces);
+    const long long nib = (nitems + 63) / 64;
+    for (long long b = 0; b < nib * sg; b++) {
+      const int grp = (int)(b % sg);
+      const long long ib = b / sg;
+      for (int tid = 0; tid < FLUX_THREADS; tid++) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int f0 = (grp * 4 + wave) * P.seg;
+        const long long item = ib * 64 + lane;
+        if (!(f0 < nfaces && item < nitems)) continue;
+        if (dir == 0) {
+          if (P.vz_per_ens) flux_line_body<0, true>(P, prim, h->fx.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<0, false>(P, prim, h->fx.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+        } else if (dir == 1) {
+          if (P.vz_per_ens) flux_line_body<1, true>(P, prim, h->fy.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<1, false>(P, prim, h->fy.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+        } else {
+          if (P.vz_per_ens) flux_line_body<2, true>(P, prim, h->fz.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<2, false>(P, prim, h->fz.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+        }
+      }
+    }
+  }
+}
+
+static void fct_launch(Emu *h, double dt) {
+  for (long long idx = 0; idx < h->P.ncell; idx++)
+    fct_mult_body(h->P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), dt, idx);
+}
+
+template <int STAGE>
+static void update_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
+  for (long long idx = 0; idx < h->P.ncell; idx++)
+    update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt, idx);
+}
+
+static TracerPtrs tptrs(const Emu *h, double *tracers) {
+  TracerPtrs tp;
+  for (int t = 0; t < MAXT; t++) tp.p[t] = nullptr;
+  for (int t = 0; t < h->P.nt; t++) tp.p[t] = tracers + (long long)t * h->P.ncell;
+  return tp;
+}
+
+extern "C" {
+
+Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen, const double *consts6, int idWV,
+              const unsigned char *pos, const unsigned char *mass, const double *dz, int seg) {
+  Emu *h = new Emu();
+  Params &P = h->P;
+  std::memset(&P, 0, sizeof(P));
+  double R_d = consts6 ? consts6[0] : 287., cp_d = consts6 ? consts6[1] : 1003., R_v = consts6 ? consts6[2] : 461.;
+  double p0 = consts6 ? consts6[4] : 1.e5, grav = consts6 ? consts6[5] : 9.81;
+  double cv_d = cp_d - R_d, gamma = cp_d / cv_d, kappa = R_d / cp_d;
+  P.nens = nens; P.nx = nx; P.ny = ny; P.nz = nz; P.nt = nt; P.sim2d = ny == 1; P.grav_balance = 1; P.seg = seg;
+  P.dx = xlen / nx; P.dy = ylen / ny; P.rdx = 1 / P.dx; P.rdy = 1 / P.dy;
+  P.C0 = std::pow(R_d * std::pow(p0, -kappa), gamma); P.gamma = gamma; P.grav = grav; P.R_d = R_d; P.R_v = R_v;
+  P.sx = nens; P.sy = (long long)nx * nens; P.sz = (long long)ny * nx * nens;
+  P.prim_fs = (long long)(nz + 6) * P.sz; P.ncell = (long long)nz * P.sz; P.fz_fs = (long long)(nz + 1) * P.sz;
+  P.idWV = idWV;
+  for (int t = 0; t < nt; t++) {
+    if (pos[t]) P.pos_mask |= 1ull << t;
+    if (mass[t]) P.mass_mask |= 1ull << t;
+  }
+  h->dz.assign(dz, dz + (size_t)nz * nens);
+  h->vt = build_vertical_tables(h->dz.data(), nz, nens);
+  P.vz_per_ens = h->vt.per_ens;
+  h->vz = h->vt.table;
+  const double nan = NAN;
+  h->prim0.assign((size_t)(6 + nt) * P.prim_fs, nan); h->prim1.assign((size_t)(6 + nt) * P.prim_fs, nan);
+  h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
+  h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
+  h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
+  h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
+  P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
+  P.vz = h->vz.data();
+  return h;
+}
+
+void emu_destroy(Emu *h) { delete h; }
+void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
+void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
+int emu_vz_per_ens(Emu *h) { return h->P.vz_per_ens; }
+double *emu_buffer(Emu *h, const char *name) {
+  std::string k(name);
+  if (k == "prim0") return h->prim0.data();
+  if (k == "prim1") return h->prim1.data();
+  if (k == "flux_x") return h->fx.data();
+  if (k == "flux_y") return h->fy.data();
+  if (k == "flux_z") return h->fz.data();
+  if (k == "seed") return h->seed.data();
+  if (k == "mult") return h->mult.data();
+  if (k == "variable_gravity") return h->grav_var.data();
+  if (k == "hy_dens_cells") return h->hy_dens.data();
+  if (k == "hy_pressure_cells") return h->hy_pres.data();
+  if (k == "vert_sten_to_coefs") return h->vt.s2c.data();
+  if (k == "vert_weno_recon_lower") return h->vt.wrl.data();
+  return nullptr;
+}
+
+static void init_prim(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers,
+                      const double *const *gcm, bool subtract_hy) {
+  TracerPtrs tp = tptrs(h, tracers);
+  for (long long idx = 0; idx < h->P.ncell; idx++)
+    init_prim_body(h->P, rho_d, u, v, w, T, tp, gcm, h->prim0.data(), h->seed.data(), subtract_hy, idx);
+}
+
+void emu_declare_hydrostatic(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers,
+                             const double *const *gcm) {
+  init_prim(h, rho_d, u, v, w, T, tracers, gcm, false);
+  for (int k = 0; k < h->P.nz; k++)
+    for (int e = 0; e < h->P.nens; e++) {
+      if (h->P.vz_per_ens) hydro_mean_body<true>(h->P, h->prim0.data(), h->grav_var.data(), h->hy_dens.data(), h->hy_pres.data(), k, e);
+      else hydro_mean_body<false>(h->P, h->prim0.data(), h->grav_var.data(), h->hy_dens.data(), h->hy_pres.data(), k, e);
+    }
+}
+
+double emu_compute_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers, double cfl) {
+  double m = INFINITY;
+  for (long long idx = 0; idx < h->P.ncell; idx++)
+    m = std::fmin(m, cfl_body(h->P, rho_d, u, v, w, T, tracers + (long long)h->P.idWV * h->P.ncell, cfl, idx));
+  return m;
+}
+
+void emu_convert_coupler_to_dynamics(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers) {
+  init_prim(h, rho_d, u, v, w, T, tracers, nullptr, !h->P.grav_balance);
+}
+
+void emu_flux_stage(Emu *h, double dt) {
+  flux_launch(h, h->prim0.data());
+  fct_launch(h, dt);
+}
+
+int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers, double crm_dt,
+                  double dt_hint, double *dt_out) {
+  emu_convert_coupler_to_dynamics(h, rho_d, u, v, w, T, tracers);
+  double dt = dt_hint > 0 ? dt_hint : emu_compute_time_step(h, rho_d, u, v, w, T, tracers, 0.8);
+  int ncycles = (int)std::ceil(crm_dt / dt);
+  dt = crm_dt / ncycles;
+  if (dt_out) *dt_out = dt;
+  double *p0 = h->prim0.data(), *p1 = h->prim1.data();
+  for (int ic = 0; ic < ncycles; ic++) {
+    flux_launch(h, p0); fct_launch(h, dt); update_launch<1>(h, p0, p0, p1, dt);
+    flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt); update_launch<2>(h, p1, p0, p1, dt);
+    flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
+  }
+  TracerPtrs tp = tptrs(h, tracers);
+  for (long long idx = 0; idx < h->P.ncell; idx++) finalize_body(h->P, p0, h->seed.data(), rho_d, u, v, w, T, tp, idx);
+  return ncycles;
+}
+
+}  // extern "C"

