@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/pam_amd_awfl.h (libpam_amd_awfl.so, built by __graft_entry__.build()).
+
+There is no fallback: if the shared library is missing this module raises at load(), and if no HIP device
+is present `pam_amd_awfl_init` fails with PAM_AMD_ENOGPU -- the product never routes through a CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpam_amd_awfl.so")
+_DP = C.POINTER(C.c_double)
+_LIB = None
+
+
+class Config(C.Structure):
+    _fields_ = [("nens", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("num_tracers", C.c_int),
+                ("xlen", C.c_double), ("ylen", C.c_double),
+                ("R_d", C.c_double), ("cp_d", C.c_double), ("R_v", C.c_double), ("cp_v", C.c_double),
+                ("p0", C.c_double), ("grav", C.c_double),
+                ("idWV", C.c_int),
+                ("tracer_positive", C.c_char_p), ("tracer_adds_mass", C.c_char_p),
+                ("vertical_cell_dz", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class Fields(C.Structure):
+    _fields_ = [("density_dry", C.c_void_p), ("uvel", C.c_void_p), ("vvel", C.c_void_p), ("wvel", C.c_void_p),
+                ("temp", C.c_void_p), ("tracers", C.POINTER(C.c_void_p))]
+
+
+class GcmColumns(C.Structure):
+    _fields_ = [("gcm_density_dry", C.c_void_p), ("gcm_temp", C.c_void_p), ("gcm_water_vapor", C.c_void_p),
+                ("gcm_cloud_water", C.c_void_p), ("gcm_cloud_ice", C.c_void_p)]
+
+
+# every symbol include/pam_amd_awfl.h declares (tests/test_capi_symbols.py checks the header against this list)
+SYMBOLS = {
+    "pam_amd_awfl_abi_version": (C.c_int, []),
+    "pam_amd_awfl_last_error": (C.c_char_p, []),
+    "pam_amd_awfl_init": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "pam_amd_awfl_finalize": (C.c_int, [C.c_void_p]),
+    "pam_amd_awfl_dycore_name": (C.c_char_p, [C.c_void_p]),
+    "pam_amd_awfl_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _DP]),
+    "pam_amd_awfl_set_balance_hydrostasis_with_gravity": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_get_array": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
+    "pam_amd_awfl_declare_current_profile_as_hydrostatic": (C.c_int, [C.c_void_p, C.POINTER(Fields),
+                                                                     C.POINTER(GcmColumns)]),
+    "pam_amd_awfl_compute_time_step": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_double, _DP]),
+    "pam_amd_awfl_time_step": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_double, C.c_double, C.POINTER(C.c_int), _DP]),
+    "pam_amd_awfl_convert_coupler_to_dynamics": (C.c_int, [C.c_void_p, C.POINTER(Fields)]),
+    "pam_amd_awfl_convert_dynamics_to_coupler": (C.c_int, [C.c_void_p, C.POINTER(Fields)]),
+    "pam_amd_awfl_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, _DP, C.POINTER(C.c_longlong)]),
+    "pam_amd_awfl_reset_kernel_timing": (C.c_int, [C.c_void_p]),
+    "pam_amd_awfl_set_flux_segment": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_debug_get_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "pam_amd_awfl_debug_flux_stage": (C.c_int, [C.c_void_p, C.c_double]),
+}
+
+
+class PamAmdError(RuntimeError):
+    """Raised where the reference would call endrun() (pam_core/pam_const.h:249-252)."""
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PamAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  pam_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().pam_amd_awfl_last_error()
+        raise PamAmdError((msg or b"").decode() + f" [code {rc}]")

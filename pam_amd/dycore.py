@@ -1,0 +1,218 @@
+"""`Dycore`: host-side mirror of the reference plug-in class (dynamics/awfl/Dycore.h) over the C ABI.
+
+Member names, call order and error behaviour follow the reference:
+
+    init(coupler)                                    Dycore.h:835
+    declare_current_profile_as_hydrostatic(coupler)  Dycore.h:1392  (the host model calls it once per GCM step)
+    compute_time_step(coupler, cfl)                  Dycore.h:65
+    timeStep(coupler)                                Dycore.h:107
+    convert_coupler_to_dynamics / convert_dynamics_to_coupler   Dycore.h:1336 / :1281
+    dycore_name(), finalize(coupler)                 Dycore.h:1544, :1548
+
+All arithmetic happens in libpam_amd_awfl.so (hand-written HIP, gfx950); this file only marshals pointers.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import capi
+from .capi import PamAmdError, check
+from .coupler import endrun
+
+
+class Dycore:
+    def __init__(self):
+        self._h = None
+        self._lib = None
+        self._fields = None
+        self._keep = None
+
+    # -------------------------------------------------------------------------------------------- init
+    def init(self, coupler, verbose=False):
+        lib = capi.load()
+        self._lib = lib
+        nens, nx, ny, nz = coupler.get_nens(), coupler.get_nx(), coupler.get_ny(), coupler.get_nz()
+        if min(nens, nx, ny, nz) < 1:
+            endrun("ERROR: coupler state not allocated (allocate_coupler_state) before dycore.init")
+        names = coupler.get_tracer_names()
+        if "water_vapor" not in names:
+            endrun("ERROR: tracer water_vapor must be registered before dycore.init (micro.init runs first)")
+        pos = bytes(bytearray(int(coupler.get_tracer_info(n)[2]) for n in names))
+        mass = bytes(bytearray(int(coupler.get_tracer_info(n)[3]) for n in names))
+        cfg = capi.Config()
+        cfg.nens, cfg.nx, cfg.ny, cfg.nz, cfg.num_tracers = nens, nx, ny, nz, len(names)
+        cfg.xlen, cfg.ylen = coupler.get_xlen(), coupler.get_ylen()
+        for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav"):       # Dycore.h:871-876: defaults if absent
+            setattr(cfg, k, float(coupler.get_option(k)) if coupler.option_exists(k) else math.nan)
+        cfg.idWV = names.index("water_vapor")
+        cfg.tracer_positive, cfg.tracer_adds_mass = pos, mass
+        dz = coupler.get_data_manager_device_readonly().get("vertical_cell_dz", readonly=True)
+        cfg.vertical_cell_dz = dz.data_ptr()
+        cfg.stream = torch.cuda.current_stream(coupler.device).cuda_stream
+        h = C.c_void_p()
+        with torch.cuda.device(coupler.device):
+            check(lib.pam_amd_awfl_init(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._device = coupler.device
+        # options the reference writes back into the coupler (Dycore.h:866-891,974)
+        coupler.set_option("balance_hydrostasis_with_gravity", True)
+        for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav", "cv_d", "gamma_d", "kappa_d", "cv_v", "C0"):
+            if not coupler.option_exists(k):
+                coupler.set_option(k, self.get_option(k))
+        coupler.set_option("idWV", cfg.idWV)
+        # dycore-owned DataManager entries (Dycore.h:868,897-898,975-984)
+        dm = coupler.get_data_manager_device_readwrite()
+        for name in ("variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs", "vert_weno_recon_lower"):
+            dm.register_existing(name, "", self._owned_array(name))
+        dm.register_existing("tracer_adds_mass", "", torch.tensor(list(mass), dtype=torch.bool, device=coupler.device))
+        dm.register_existing("tracer_positive", "", torch.tensor(list(pos), dtype=torch.bool, device=coupler.device))
+
+    def _owned_array(self, name):
+        ptr, dims, nd = C.c_void_p(), (C.c_int * 5)(), C.c_int()
+        check(self._lib.pam_amd_awfl_get_array(self._h, name.encode(), C.byref(ptr), dims, C.byref(nd)))
+        shape = tuple(dims[i] for i in range(nd.value))
+        n = 1
+        for d in shape:
+            n *= d
+        return _device_view(ptr.value, shape, self._device)
+
+    def get_option(self, key):
+        v = C.c_double()
+        check(self._lib.pam_amd_awfl_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    # -------------------------------------------------------------------------------------------- helpers
+    def _need(self):
+        if self._h is None:
+            endrun("ERROR: dycore.init(coupler) must be called first")
+
+    def _mk_fields(self, coupler, readonly=False):
+        dm = coupler.get_data_manager_device_readonly() if readonly else coupler.get_data_manager_device_readwrite()
+        names = coupler.get_tracer_names()
+        tens = [dm.get(k, readonly=readonly) for k in ("density_dry", "uvel", "vvel", "wvel", "temp")]
+        trc = [dm.get(n, readonly=readonly) for n in names]
+        shape = (coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens())
+        for t in tens + trc:
+            if tuple(t.shape) != shape or t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda:
+                endrun("ERROR: coupler field has wrong shape/type (expected contiguous fp64 (nz,ny,nx,nens) on the GPU)")
+        f = capi.Fields()
+        f.density_dry, f.uvel, f.vvel, f.wvel, f.temp = [t.data_ptr() for t in tens]
+        arr = (C.c_void_p * len(trc))(*[t.data_ptr() for t in trc])
+        f.tracers = arr
+        self._keep = (tens, trc, arr)
+        return f
+
+    def _sync_balance_option(self, coupler):
+        # the reference re-reads the option on every call (Dycore.h:284,624,1410)
+        want = bool(coupler.get_option("balance_hydrostasis_with_gravity"))
+        if want != bool(self.get_option("balance_hydrostasis_with_gravity")):
+            check(self._lib.pam_amd_awfl_set_balance_hydrostasis_with_gravity(self._h, int(want)))
+
+    # -------------------------------------------------------------------------------------------- reference surface
+    def declare_current_profile_as_hydrostatic(self, coupler, use_gcm_data=False):
+        self._need()
+        self._sync_balance_option(coupler)
+        f = self._mk_fields(coupler, readonly=True)
+        g = None
+        if use_gcm_data:
+            dm = coupler.get_data_manager_device_readonly()
+            g = capi.GcmColumns()
+            cols = [dm.get(k, readonly=True) for k in ("gcm_density_dry", "gcm_temp", "gcm_water_vapor",
+                                                        "gcm_cloud_water", "gcm_cloud_ice")]
+            (g.gcm_density_dry, g.gcm_temp, g.gcm_water_vapor, g.gcm_cloud_water, g.gcm_cloud_ice) = \
+                [c.data_ptr() for c in cols]
+            self._keep_g = cols
+        check(self._lib.pam_amd_awfl_declare_current_profile_as_hydrostatic(self._h, C.byref(f),
+                                                                            C.byref(g) if g is not None else None))
+
+    def compute_time_step(self, coupler, cfl=0.8):
+        self._need()
+        f = self._mk_fields(coupler, readonly=True)
+        dt = C.c_double()
+        check(self._lib.pam_amd_awfl_compute_time_step(self._h, C.byref(f), float(cfl), C.byref(dt)))
+        return dt.value
+
+    def timeStep(self, coupler, dt_dyn_hint=0.0):
+        """dt_dyn_hint > 0: ensemble-global CFL step agreed between nens shards (see parallel.py); the reference
+        has a single process and always derives it locally (Dycore.h:141)."""
+        self._need()
+        self._sync_balance_option(coupler)
+        f = self._mk_fields(coupler)
+        n, dt = C.c_int(), C.c_double()
+        check(self._lib.pam_amd_awfl_time_step(self._h, C.byref(f), float(coupler.get_option("crm_dt")),
+                                               float(dt_dyn_hint), C.byref(n), C.byref(dt)))
+        self.last_ncycles, self.last_dt_dyn = n.value, dt.value
+        return n.value
+
+    def convert_coupler_to_dynamics(self, coupler):
+        self._need()
+        self._sync_balance_option(coupler)
+        f = self._mk_fields(coupler, readonly=True)
+        check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics(self._h, C.byref(f)))
+
+    def convert_dynamics_to_coupler(self, coupler):
+        self._need()
+        f = self._mk_fields(coupler)
+        check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler(self._h, C.byref(f)))
+
+    def dycore_name(self):
+        lib = self._lib or capi.load()
+        return lib.pam_amd_awfl_dycore_name(self._h).decode()
+
+    def finalize(self, coupler=None):
+        if self._h is not None:
+            if coupler is not None:
+                dm = coupler.get_data_manager_device_readwrite()
+                for name in ("variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs",
+                             "vert_weno_recon_lower", "tracer_adds_mass", "tracer_positive"):
+                    dm.unregister(name)
+            check(self._lib.pam_amd_awfl_finalize(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.finalize()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------------------------------------- measurement / tests
+    def set_kernel_timing(self, enable):
+        check(self._lib.pam_amd_awfl_set_kernel_timing(self._h, int(bool(enable))))
+
+    def reset_kernel_timing(self):
+        check(self._lib.pam_amd_awfl_reset_kernel_timing(self._h))
+
+    def get_kernel_timing(self, name):
+        ms, n = C.c_double(), C.c_longlong()
+        check(self._lib.pam_amd_awfl_get_kernel_timing(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_flux_segment(self, faces):
+        check(self._lib.pam_amd_awfl_set_flux_segment(self._h, int(faces)))
+
+    def debug_buffer(self, name):
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(self._lib.pam_amd_awfl_debug_get_buffer(self._h, name.encode(), C.byref(ptr), C.byref(n)))
+        return _device_view(ptr.value, (n.value,), self._device)
+
+    def debug_flux_stage(self, dt):
+        check(self._lib.pam_amd_awfl_debug_flux_stage(self._h, float(dt)))
+
+
+class _CudaArrayView:
+    """__cuda_array_interface__ wrapper so torch can view a raw device pointer owned by the dycore (no copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def _device_view(ptr, shape, device):
+    n = 1
+    for d in shape:
+        n *= d
+    if n == 0 or not ptr:
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        return torch.as_tensor(_CudaArrayView(ptr, shape), device=device)
