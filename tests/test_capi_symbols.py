@@ -1,0 +1,81 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/pam_amd_awfl.h
+declares; argument validation happens before any GPU work; without a GPU the product fails loudly (no fallback)."""
+import ctypes as C
+import math
+import os
+import re
+
+import pytest
+
+from pam_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "pam_amd_awfl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(pam_amd_awfl_\w+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = _header_symbols()
+    assert declared, "no prototypes parsed from the header"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/pam_amd_awfl.h but not exported"
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    assert lib.pam_amd_awfl_abi_version() == 1
+
+
+def _cfg(**kw):
+    cfg = capi.Config()
+    cfg.nens, cfg.nx, cfg.ny, cfg.nz, cfg.num_tracers = 2, 8, 1, 8, 1
+    cfg.xlen, cfg.ylen = 8000.0, 8000.0
+    for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav"):
+        setattr(cfg, k, math.nan)
+    cfg.idWV = 0
+    cfg.tracer_positive = b"\x01"
+    cfg.tracer_adds_mass = b"\x01"
+    cfg.vertical_cell_dz = 1   # never dereferenced: validation / device check fail first
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("bad", [dict(nx=2), dict(ny=2), dict(nz=1), dict(nens=0), dict(num_tracers=0),
+                                 dict(num_tracers=51), dict(idWV=3), dict(xlen=-1.0), dict(vertical_cell_dz=None)])
+def test_init_rejects_bad_arguments(bad):
+    lib = capi.load()
+    h = C.c_void_p()
+    rc = lib.pam_amd_awfl_init(C.byref(_cfg(**bad)), C.byref(h))
+    assert rc == -1 and not h.value            # PAM_AMD_EINVAL, like the reference's endrun()
+    assert len(lib.pam_amd_awfl_last_error()) > 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = capi.load()
+    h = C.c_void_p()
+    rc = lib.pam_amd_awfl_init(C.byref(_cfg()), C.byref(h))
+    assert rc == -2 and not h.value            # PAM_AMD_ENOGPU
+    assert b"no HIP device" in lib.pam_amd_awfl_last_error()
+
+
+def test_null_handle_calls_fail_cleanly():
+    lib = capi.load()
+    v = C.c_double()
+    assert lib.pam_amd_awfl_get_option(None, b"C0", C.byref(v)) == -1
+    assert lib.pam_amd_awfl_time_step(None, None, 1.0, 0.0, None, None) == -1
+    assert lib.pam_amd_awfl_finalize(None) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under pam_amd/ may import, load or link it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pam_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "awfl_oracle" not in text and "libawfl_emu" not in text, os.path.join(dirpath, f)
