@@ -42,7 +42,7 @@ namespace pama {
 constexpr int HS = 3;          // ghost levels (Dycore.h:23)
 constexpr int MAXT = 50;       // pam_const.h:24 max_fields
 constexpr int FLUX_THREADS = 256;
-constexpr int VZ_STRIDE = 52;  // per-level vertical table: 27 (lower) + 25 (bridged upper)
+constexpr int VZ_STRIDE = 38;  // per-level vertical table in difference form (struct DTable)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
 
@@ -64,7 +64,7 @@ struct Params {
   const double *grav_var; // (nz,nens)
   const double *hy_dens;  // (nz,nens)
   const double *hy_pres;  // (nz,nens)
-  const double *vz;       // vertical matrices: (nz+2,52) or (nz+2,52,nens)
+  const double *vz;       // vertical difference-form tables: (nz+2,38) or (nz+2,38,nens)
   unsigned long long pos_mask, mass_mask;  // tracer_positive / tracer_adds_mass bit sets
   int idWV;
 };
@@ -105,16 +105,31 @@ PAMA_D WenoConsts weno_consts() {
   return w;
 }
 
-// Non-linear part shared by the constant- and table-matrix variants: candidate polynomials in, blended
-// polynomial evaluated at the left (x=-1/2) and right (x=+1/2) edge out.
-// (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum;
-//  Dycore.h:601-603 edge evaluation with coefs_to_gll_lower = (+-1/2)^p.)
-PAMA_D void weno5_blend(const double alo[3][3], const double ah[5], const WenoConsts &wc, double &left, double &right) {
+// ------------------------------------------------------------------------------------------------
+// WENO5 polynomial of one cell, evaluated at the left (x=-1/2) and right (x=+1/2) edge of the cell.
+//
+// Same algorithm as WenoLimiter.h:98-181 + Dycore.h:591-604, re-expressed in DIFFERENCE FORM: with
+// d_m = u_m - u_{m-1} (m = 1..4), every non-constant coefficient of every candidate polynomial is a linear form in
+// the d_m only (a constant field has a constant polynomial), and the constant coefficient is the centre value plus a
+// linear form in the d_m (the polynomial reproduces the centre cell average).  The candidates therefore need
+// 12 + 16 multiply-adds instead of 27 + 25, the constant coefficients are never formed, and
+//      even = u2 + sum_i w_i E_i ,  odd = sum_i w_i O_i ,  left = even - odd ,  right = even + odd
+// with E_i = (a0_i - u2) + a2_i/4 (+ a4/16), O_i = a1_i/2 (+ a3/8).  The bridge polynomial (WenoLimiter.h:128-136) is
+// linear in the stencil and is folded into the upper-polynomial coefficients.
+struct WenoLin {
+  double a1[3], a2[3];   // lower candidates: x and x^2 coefficients
+  double h1, h2, h3, h4; // bridged upper polynomial: x .. x^4 coefficients
+  double E[3], Eh;       // even-part edge contributions minus u2
+};
+
+// Non-linear part (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum).
+PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, double &left, double &right) {
   double tv[4];
 #pragma unroll
-  for (int i = 0; i < 3; i++) tv[i] = alo[i][1] * alo[i][1] + AWFL_TV3_A2A2 * (alo[i][2] * alo[i][2]);
-  tv[3] = ah[1] * ah[1] + AWFL_TV5_A2A2 * (ah[2] * ah[2]) + AWFL_TV5_A1A3 * ah[1] * ah[3] +
-          AWFL_TV5_A3A3 * (ah[3] * ah[3]) + AWFL_TV5_A2A4 * ah[2] * ah[4] + AWFL_TV5_A4A4 * (ah[4] * ah[4]);
+  for (int i = 0; i < 3; i++) tv[i] = p.a1[i] * p.a1[i] + AWFL_TV3_A2A2 * (p.a2[i] * p.a2[i]);
+  // coefs_to_tv<5> (TransformMatrices.h:871-876) grouped as h1 (h1 + .5 h3) + h2 (c2 h2 + 4.2 h4) + c3 h3^2 + c4 h4^2
+  tv[3] = p.h1 * (p.h1 + AWFL_TV5_A1A3 * p.h3) + p.h2 * (AWFL_TV5_A2A2 * p.h2 + AWFL_TV5_A2A4 * p.h4) +
+          (AWFL_TV5_A3A3 * p.h3) * p.h3 + (AWFL_TV5_A4A4 * p.h4) * p.h4;
   double lo_avg = (tv[0] + tv[1] + tv[2]) * (1.0 / 3.0);
   tv[3] = lo_avg + (tv[3] - lo_avg) * wc.sigma;
   // w_i = idl_i/(tv_i^2+eps), then convexify: w_i /= (sum_k w_k + eps) (WenoLimiter.h:163-166).  One reciprocal,
@@ -139,90 +154,107 @@ PAMA_D void weno5_blend(const double alo[3][3], const double ah[5], const WenoCo
   double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
   double rm = fast_rcp(((m0 + m1) + m2) + m3);
   m0 *= rm; m1 *= rm; m2 *= rm; m3 *= rm;
-  // blended coefficients
-  double a0 = m3 * ah[0] + (m0 * alo[0][0] + (m1 * alo[1][0] + m2 * alo[2][0]));
-  double a1 = m3 * ah[1] + (m0 * alo[0][1] + (m1 * alo[1][1] + m2 * alo[2][1]));
-  double a2 = m3 * ah[2] + (m0 * alo[0][2] + (m1 * alo[1][2] + m2 * alo[2][2]));
-  double a3 = m3 * ah[3];
-  double a4 = m3 * ah[4];
-  double even = a0 + (0.25 * a2 + 0.0625 * a4);
-  double odd = 0.5 * a1 + 0.125 * a3;
+  double even = u2 + (m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2])));
+  double odd = 0.5 * (m3 * p.h1 + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]))) + 0.125 * (m3 * p.h3);
   left = even - odd;
   right = even + odd;
 }
 
-// Horizontal directions: constant matrices (TransformMatrices.h:970, :1218), zero entries skipped at
-// compile time, bridge polynomial (WenoLimiter.h:128-136) folded into a constant 5x5 matrix.
-PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
-  constexpr double S5[5][5] = AWFL_STEN_TO_COEFS_INIT;
-  constexpr double W3[3][3][3] = AWFL_WENO_LOWER_INIT;
-  double alo[3][3], ah[5];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-#pragma unroll
-    for (int ii = 0; ii < 3; ii++) {
-      double t = 0.0;
-      bool first = true;
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        if (W3[i][s][ii] != 0.0) {
-          t = first ? W3[i][s][ii] * u[i + s] : t + W3[i][s][ii] * u[i + s];
-          first = false;
-        }
-      }
-      alo[i][ii] = t;
-    }
-  }
-#pragma unroll
-  for (int ii = 0; ii < 5; ii++) {
-    double t = 0.0;
-    bool first = true;
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-      // bridged coefficient: (S5[s][ii] - sum_i idl_i * W3[i][s-i][ii]) / idl_3
-      double b = S5[s][ii];
-      if (ii < 3) {
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-          if (s - i >= 0 && s - i < 3) b -= wc.idl[i] * W3[i][s - i][ii];
-      }
-      b *= wc.ridl3;
-      if (!(ii >= 3 && S5[s][ii] == 0.0)) {
-        t = first ? b * u[s] : t + b * u[s];
-        first = false;
-      }
-    }
-    ah[ii] = t;
-  }
-  weno5_blend(alo, ah, wc, left, right);
+// Difference-form coefficient tables.  Lower candidate i uses (d_{i+1}, d_{i+2}); the upper polynomial uses d_1..d_4.
+//   lo1[i][2], lo2[i][2]      x and x^2 coefficients of candidate i
+//   loE[i][2]                 (a0_i - u2) + a2_i/4
+//   hi[p-1][4]   p=1..4       bridged upper coefficients
+//   hiE[4]                    (a0_h - u2) + a2_h/4 + a4_h/16
+// VZ_STRIDE = 38 doubles per level in this order.
+struct DTable { double lo1[3][2], lo2[3][2], loE[3][2], hi[4][4], hiE[4]; };
+
+// conversion of a stencil-form linear functional  sum_s c_s u_{s0+s}  (cells s0..s0+n-1 of the 5-stencil, centre = 2)
+// to difference form: coefficient of d_m (m = 1..4), dropping (sum c_s) u2 (=0 or u2, handled by the caller).
+//   u0-u2 = -d1-d2, u1-u2 = -d2, u3-u2 = d3, u4-u2 = d3+d4
+constexpr double dcoef(const double c[5], int m) {
+  return m == 1 ? -c[0] : m == 2 ? -c[0] - c[1] : m == 3 ? c[3] + c[4] : c[4];
 }
 
-// Vertical direction: per-level matrices built at init from the cell-edge locations
-// (Dycore.h:904-937 + TransformMatrices_variable.h), used as Dycore.h:454-469.
-// tab points at 52 doubles with element stride `ts` (1 for the ensemble-uniform table, nens otherwise):
-//   [0..26]  lower matrices  [i][s][ii]
-//   [27..51] bridged upper matrix [s][ii]
-PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, const WenoConsts &wc, double &left,
-                        double &right) {
-  double alo[3][3], ah[5];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-#pragma unroll
+// Build the difference-form table from the stencil-form matrices recon_lo[i][s][ii] (vert_weno_recon_lower /
+// TransformMatrices.h:1218) and recon_hi[s][ii] (vert_sten_to_coefs / TransformMatrices.h:970) and the ideal weights.
+constexpr DTable make_dtable(const double lo[3][3][3], const double hi[5][5], const double idl[4]) {
+  DTable t{};
+  double lod[3][3][4] = {};   // [i][ii][m-1] full-width difference form of the lower candidates
+  for (int i = 0; i < 3; i++)
     for (int ii = 0; ii < 3; ii++) {
-      double t = tab[((i * 3 + 0) * 3 + ii) * ts] * u[i];
-      t += tab[((i * 3 + 1) * 3 + ii) * ts] * u[i + 1];
-      t += tab[((i * 3 + 2) * 3 + ii) * ts] * u[i + 2];
-      alo[i][ii] = t;
+      double c[5] = {0, 0, 0, 0, 0};
+      for (int s = 0; s < 3; s++) c[i + s] = lo[i][s][ii];
+      for (int m = 1; m <= 4; m++) lod[i][ii][m - 1] = dcoef(c, m);
+    }
+  double hid[5][4] = {};      // [ii][m-1]
+  for (int ii = 0; ii < 5; ii++) {
+    double c[5] = {hi[0][ii], hi[1][ii], hi[2][ii], hi[3][ii], hi[4][ii]};
+    for (int m = 1; m <= 4; m++) {
+      double v = dcoef(c, m);
+      if (ii < 3)
+        for (int i = 0; i < 3; i++) v -= idl[i] * lod[i][ii][m - 1];   // bridge, WenoLimiter.h:129-133
+      hid[ii][m - 1] = v / idl[3];                                    // WenoLimiter.h:134-136
     }
   }
+  for (int i = 0; i < 3; i++)
+    for (int q = 0; q < 2; q++) {
+      t.lo1[i][q] = lod[i][1][i + q];
+      t.lo2[i][q] = lod[i][2][i + q];
+      t.loE[i][q] = lod[i][0][i + q] + 0.25 * lod[i][2][i + q];
+    }
+  for (int pp = 1; pp <= 4; pp++)
+    for (int m = 0; m < 4; m++) t.hi[pp - 1][m] = hid[pp][m];
+  for (int m = 0; m < 4; m++) t.hiE[m] = hid[0][m] + 0.25 * hid[2][m] + 0.0625 * hid[4][m];
+  return t;
+}
+
+constexpr DTable make_const_dtable() {
+  constexpr double S5[5][5] = AWFL_STEN_TO_COEFS_INIT;
+  constexpr double W3[3][3][3] = AWFL_WENO_LOWER_INIT;
+  constexpr double raw[4] = AWFL_WENO_IDL_INIT;
+  double sum = ((raw[0] + raw[1]) + raw[2]) + raw[3];
+  double idl[4] = {raw[0] / (sum + 1.0e-20), raw[1] / (sum + 1.0e-20), raw[2] / (sum + 1.0e-20), raw[3] / (sum + 1.0e-20)};
+  return make_dtable(W3, S5, idl);
+}
+
+// Horizontal directions: constant matrices (uniform grid).  All coefficients are compile-time literals.
+PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
+  constexpr DTable T = make_const_dtable();
+  const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
+  WenoLin p;
 #pragma unroll
-  for (int ii = 0; ii < 5; ii++) {
-    double t = tab[(27 + 0 * 5 + ii) * ts] * u[0];
-#pragma unroll
-    for (int s = 1; s < 5; s++) t += tab[(27 + s * 5 + ii) * ts] * u[s];
-    ah[ii] = t;
+  for (int i = 0; i < 3; i++) {
+    p.a1[i] = T.lo1[i][0] * d[i] + T.lo1[i][1] * d[i + 1];
+    p.a2[i] = T.lo2[i][0] * d[i] + T.lo2[i][1] * d[i + 1];
+    p.E[i] = T.loE[i][0] * d[i] + T.loE[i][1] * d[i + 1];
   }
-  weno5_blend(alo, ah, wc, left, right);
+  p.h1 = T.hi[0][0] * d[0] + (T.hi[0][1] * d[1] + (T.hi[0][2] * d[2] + T.hi[0][3] * d[3]));
+  p.h2 = T.hi[1][0] * d[0] + (T.hi[1][1] * d[1] + (T.hi[1][2] * d[2] + T.hi[1][3] * d[3]));
+  p.h3 = T.hi[2][0] * d[0] + (T.hi[2][1] * d[1] + (T.hi[2][2] * d[2] + T.hi[2][3] * d[3]));
+  p.h4 = T.hi[3][0] * d[0] + (T.hi[3][1] * d[1] + (T.hi[3][2] * d[2] + T.hi[3][3] * d[3]));
+  p.Eh = T.hiE[0] * d[0] + (T.hiE[1] * d[1] + (T.hiE[2] * d[2] + T.hiE[3] * d[3]));
+  weno5_blend(u[2], p, wc, left, right);
+}
+
+// Vertical direction: per-level difference-form table built at init from the cell-edge locations
+// (Dycore.h:904-937 + TransformMatrices_variable.h -> awfl_vertical.h), used as Dycore.h:454-469.
+// tab points at VZ_STRIDE doubles with element stride `ts` (1 for the ensemble-uniform table, nens otherwise).
+PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, const WenoConsts &wc, double &left,
+                        double &right) {
+  const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
+  WenoLin p;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    p.a1[i] = tab[(0 + 2 * i) * ts] * d[i] + tab[(1 + 2 * i) * ts] * d[i + 1];
+    p.a2[i] = tab[(6 + 2 * i) * ts] * d[i] + tab[(7 + 2 * i) * ts] * d[i + 1];
+    p.E[i] = tab[(12 + 2 * i) * ts] * d[i] + tab[(13 + 2 * i) * ts] * d[i + 1];
+  }
+  p.h1 = tab[18 * ts] * d[0] + (tab[19 * ts] * d[1] + (tab[20 * ts] * d[2] + tab[21 * ts] * d[3]));
+  p.h2 = tab[22 * ts] * d[0] + (tab[23 * ts] * d[1] + (tab[24 * ts] * d[2] + tab[25 * ts] * d[3]));
+  p.h3 = tab[26 * ts] * d[0] + (tab[27 * ts] * d[1] + (tab[28 * ts] * d[2] + tab[29 * ts] * d[3]));
+  p.h4 = tab[30 * ts] * d[0] + (tab[31 * ts] * d[1] + (tab[32 * ts] * d[2] + tab[33 * ts] * d[3]));
+  p.Eh = tab[34 * ts] * d[0] + (tab[35 * ts] * d[1] + (tab[36 * ts] * d[2] + tab[37 * ts] * d[3]));
+  weno5_blend(u[2], p, wc, left, right);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,15 +6,17 @@
 // The reference inverts with yakl::intrinsics::matinv_ge, a third-party routine absent from the tree (YAKL
 // submodule, version unpinned); here it is Gauss-Jordan elimination without pivoting, (col,row) order.
 //
-// Output per level (and per ensemble member): 52 doubles
-//   [0..26]  vert_weno_recon_lower(k,i,s,ii)          -- as the reference stores it
-//   [27..51] bridged upper matrix B(s,ii) = (vert_sten_to_coefs(k,s,ii) - sum_i idl_i lower(i,s-i,ii)) / idl_3
-//            i.e. WenoLimiter.h:128-136 folded into the matrix (linear in the stencil, so exact up to rounding).
-// The un-bridged vert_sten_to_coefs is also returned for the DataManager entry of that name.
+// Output per level (and per ensemble member): VZ_STRIDE = 38 doubles, the difference-form table `DTable` of
+// awfl_device.h (make_dtable): lower-candidate x / x^2 / even-edge coefficients and the bridged upper polynomial
+// (WenoLimiter.h:128-136 folded in; linear in the stencil, so exact up to rounding).
+// The stencil-form vert_sten_to_coefs / vert_weno_recon_lower are also returned for the DataManager entries of
+// those names.
 #pragma once
 #include <algorithm>
+#include <cstring>
 #include <vector>
 #include "awfl_constants.h"
+#include "awfl_device.h"
 
 namespace pama {
 
@@ -63,7 +65,7 @@ struct VerticalTables {
 };
 
 inline void level_matrices(const double *dzcol /* stride nens */, long long stride, int nz, int k, double s2c[25],
-                           double wrl[27], double bridged[25]) {
+                           double wrl[27], double dform[VZ_STRIDE]) {
   double dzloc[5], locs[6];
   for (int kk = 0; kk < 5; kk++) {
     int ind1 = std::min(nz - 1, std::max(0, -1 + k + kk));
@@ -84,14 +86,15 @@ inline void level_matrices(const double *dzcol /* stride nens */, long long stri
   const double raw[4] = AWFL_WENO_IDL_INIT;
   double sum = ((raw[0] + raw[1]) + raw[2]) + raw[3], idl[4];
   for (int i = 0; i < 4; i++) idl[i] = raw[i] / (sum + 1.0e-20);
+  double lo[3][3][3], hi[5][5];
+  for (int i = 0; i < 3; i++)
+    for (int s = 0; s < 3; s++)
+      for (int ii = 0; ii < 3; ii++) lo[i][s][ii] = wrl[(i * 3 + s) * 3 + ii];
   for (int s = 0; s < 5; s++)
-    for (int ii = 0; ii < 5; ii++) {
-      double b = s2c[s * 5 + ii];
-      if (ii < 3)
-        for (int i = 0; i < 3; i++)
-          if (s - i >= 0 && s - i < 3) b -= idl[i] * wrl[(i * 3 + (s - i)) * 3 + ii];
-      bridged[s * 5 + ii] = b / idl[3];
-    }
+    for (int ii = 0; ii < 5; ii++) hi[s][ii] = s2c[s * 5 + ii];
+  const DTable t = make_dtable(lo, hi, idl);
+  static_assert(sizeof(DTable) == VZ_STRIDE * sizeof(double), "DTable layout");
+  std::memcpy(dform, &t, sizeof(t));
 }
 
 // dz: host copy of vertical_cell_dz (nz,nens)
@@ -104,19 +107,17 @@ inline VerticalTables build_vertical_tables(const double *dz, int nz, int nens) 
   const int nl = nz + 2;
   vt.s2c.assign((size_t)nl * 25 * nens, 0.0);
   vt.wrl.assign((size_t)nl * 27 * nens, 0.0);
-  vt.table.assign((size_t)nl * 52 * (vt.per_ens ? nens : 1), 0.0);
+  vt.table.assign((size_t)nl * VZ_STRIDE * (vt.per_ens ? nens : 1), 0.0);
   for (int k = 0; k < nl; k++) {
-    double s2c[25], wrl[27], br[25];
+    double s2c[25], wrl[27], br[VZ_STRIDE];
     for (int e = 0; e < nens; e++) {
       if (e == 0 || vt.per_ens) level_matrices(dz + e, nens, nz, k, s2c, wrl, br);
       for (int m = 0; m < 25; m++) vt.s2c[((size_t)k * 25 + m) * nens + e] = s2c[m];
       for (int m = 0; m < 27; m++) vt.wrl[((size_t)k * 27 + m) * nens + e] = wrl[m];
       if (vt.per_ens) {
-        for (int m = 0; m < 27; m++) vt.table[((size_t)k * 52 + m) * nens + e] = wrl[m];
-        for (int m = 0; m < 25; m++) vt.table[((size_t)k * 52 + 27 + m) * nens + e] = br[m];
+        for (int m = 0; m < VZ_STRIDE; m++) vt.table[((size_t)k * VZ_STRIDE + m) * nens + e] = br[m];
       } else if (e == 0) {
-        for (int m = 0; m < 27; m++) vt.table[(size_t)k * 52 + m] = wrl[m];
-        for (int m = 0; m < 25; m++) vt.table[(size_t)k * 52 + 27 + m] = br[m];
+        for (int m = 0; m < VZ_STRIDE; m++) vt.table[(size_t)k * VZ_STRIDE + m] = br[m];
       }
     }
   }
