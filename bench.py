@@ -95,7 +95,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--nens", type=int, default=0, help="members per GPU (default: the config's)")
-    ap.add_argument("--seg", type=int, default=0, help="flux-kernel segment length (default: library default)")
+    ap.add_argument("--seg", type=int, default=0, help="flux-kernel chunk length (default: library default)")
+    ap.add_argument("--span", type=int, default=-1, help="flux-kernel faces per thread (default: automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -141,6 +142,8 @@ def main():
     dycore.init(coupler)
     if args.seg > 0:
         dycore.set_flux_segment(args.seg)
+    if args.span >= 0:
+        dycore.set_flux_span(args.span)
     nens_gen = min(16, nens_pg)
     f = make_inputs(idz, nens_pg, nx, ny, nz, zint, tracers, consts, xlen, ylen, nens_gen=nens_gen, id0=rank * 1000)
     reps = (nens_pg + nens_gen - 1) // nens_gen

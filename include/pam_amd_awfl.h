@@ -114,8 +114,11 @@ int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
  * "finalize","cfl","hydro") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
-/* faces per flux-kernel segment (tuning knob, default 8; 1..32) */
+/* flux-kernel tuning knobs; results do not depend on them.
+ *   segment: faces per chunk = LDS face slots per thread (default 8; 1..16)
+ *   span:    faces swept by one thread (0 = automatic: the whole line/column when the ensemble fills the chip) */
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
+int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
 
 /* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
 /* name: "prim0","prim1","flux_x","flux_y","flux_z","seed","mult". */

@@ -53,7 +53,7 @@ struct Params {
   int sim2d;          // ny == 1 (Dycore.h:279)
   int grav_balance;   // option balance_hydrostasis_with_gravity (Dycore.h:284)
   int vz_per_ens;     // 0: vertical matrices identical for every ensemble member (wave-uniform table)
-  int seg;            // faces per flux-kernel segment
+  int seg;            // faces per flux-kernel chunk (LDS face slots per thread)
   double dx, dy, rdx, rdy;
   double C0, gamma, grav, R_d, R_v;
   long long sx, sy, sz;   // cell strides in doubles: nens, nx*nens, ny*nx*nens
@@ -260,9 +260,9 @@ PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, cons
 // ------------------------------------------------------------------------------------------------
 // Flux kernel geometry.  One "line" = the cells along the sweep direction for fixed other indices and
 // ensemble member; an "item" = (line, iens) flattened with iens fastest so that a wavefront's 64 lanes read
-// 64 consecutive doubles (512 B, fully coalesced) for nens >= 64.  A thread sweeps one segment of `seg` faces
-// of its line; the 4 wavefronts of a workgroup take 4 consecutive segments of the same 64 items, so the
-// 5 overlap cells between neighbouring segments are L1/L2 hits.
+// 64 consecutive doubles (512 B, fully coalesced) for nens >= 64.  A thread sweeps a span of faces of its line
+// (the whole line when there are enough lines x members to fill the chip); consecutive wavefronts take consecutive
+// spans of the same 64 items, so the overlap cells between neighbouring spans are L1/L2 hits.
 struct LineGeom {
   int dir;             // 0 x, 1 y, 2 z
   int n;               // cells along the line
@@ -286,13 +286,23 @@ PAMA_D int wrap(int c, int n) {
 }
 
 // Body of the reconstruction + flux kernel for one thread.
-//   dir      sweep direction; item = flattened (line, iens); f0 = first face of this thread's segment
-//   lds      per-thread private slots: lds[(2*s+0)*lstride + tid] = mass flux of face f0+s, (2*s+1) = pressure
+//   DIR      sweep direction; item = flattened (line, iens)
+//   f0,span  this thread sweeps the faces f0 .. min(f0+span, nfaces)-1 of its line (a whole 32-cell line or a whole
+//            60-level column when the ensemble is large enough to fill the chip with such threads)
+//   lds      per-thread private slots (stride nthr doubles, conflict-free ds_read/write_b64):
+//              lds[(2*s+0)*nthr + tid] = mass flux of face cf0+s, lds[(2*s+1)*nthr + tid] = face pressure   (s < seg)
+//              lds[(2*seg + v)*nthr + tid] = right-edge value of the last cell of the previous chunk, per swept
+//                                            quantity v (0 rho*u_n, 1 p, 2.. advected fields)
+// The span is processed in chunks of P.seg faces: per chunk first the acoustic pair, then one advected field at a
+// time, each with a 5-cell sliding window in registers.  Every cell polynomial is computed once and evaluated at both
+// edges; the right-edge value of a chunk's last cell is carried to the next chunk through the thread's LDS slot, so
+// the only redundant polynomial is the one of cell f0-1 at the start of the span ((span+1)/span work: 33/32 for a
+// whole line, against 9/8 when every 8-face segment starts from scratch).
 // Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
 // with vertical ghosts already filled (Dycore.h:662-710).
 template <int DIR, bool VZ_PER_ENS>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux,
-                           long long item, int f0, double *lds, int lstride, int tid) {
+                           long long item, int f0, int span, double *lds, int nthr, int tid) {
   const LineGeom g = line_geom(P, DIR);
   const WenoConsts wc = weno_consts();
   const int e = (int)(item % P.nens);
@@ -311,92 +321,101 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     pbase = (long long)HS * P.sz + line * P.sx + e;
     fbase = line * P.sx + e;
   }
-  const int flast = (f0 + P.seg < g.nfaces) ? f0 + P.seg : g.nfaces;  // exclusive
+  const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive
   const double cs = 350.0, rcs = 1.0 / 350.0;                        // Dycore.h:335
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
+  double *carry = lds + (long long)2 * P.seg * nthr;
 
   auto cell_off = [&](int c) -> long long {
     if (DIR == 2) return pbase + (long long)(c > P.nz + 2 ? P.nz + 2 : c) * g.cs;   // ghosts exist for c in [-3, nz+2]
     return pbase + (long long)wrap(c, g.n) * g.cs;                     // periodic (Dycore.h:629-657)
   };
-  auto vtab = [&](int c) -> const double * {                           // matrices of cell c: level index c+1
+  auto vtab = [&](int c) -> const double * {                           // table of cell c: level index c+1
     return VZ_PER_ENS ? P.vz + ((long long)(c + 1) * VZ_STRIDE) * P.nens + e : P.vz + (long long)(c + 1) * VZ_STRIDE;
   };
   const long long vts = VZ_PER_ENS ? (long long)P.nens : 1;
-
-  // ---------------- acoustic part: mass flux and pressure at the faces (Dycore.h:341-366) -------------
-  {
-    const double *pr = prim + (long long)P_RHO * P.prim_fs;
-    const double *pn = prim + (long long)ncomp * P.prim_fs;
-    const double *pp = prim + (long long)P_PRES * P.prim_fs;
-    double wm[5], wp[5];   // windows: rho*u_n product and pressure, cells c-2..c+2
-    int c = f0 - 1;
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-      long long o = cell_off(c - 2 + s);
-      wm[s] = pr[o] * pn[o];
-      wp[s] = pp[o];
-    }
-    double prevR_m = 0.0, prevR_p = 0.0;
-    for (; c < flast; c++) {
-      // prefetch the next cell entering the window
-      long long on = cell_off(c + 3);
-      double nm = pr[on] * pn[on], np_ = pp[on];
-      double Lm, Rm, Lp, Rp;
-      if (DIR == 2) {
-        weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
-        weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
-      } else {
-        weno5_const(wm, wc, Lm, Rm);
-        weno5_const(wp, wc, Lp, Rp);
-      }
-      if (c >= f0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
-        double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
-        bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
-        if (wall) { ru_L = 0.0; ru_R = 0.0; }
-        double w1 = 0.5 * (pp_R - cs * ru_R);
-        double w2 = 0.5 * (pp_L + cs * ru_L);
-        double ppf = w1 + w2;
-        double ruf = (w2 - w1) * rcs;
-        if (wall) ruf = 0.0;
-        flux[fbase + (long long)c * g.cs] = ruf;            // flux field 0
-        lds[(2 * (c - f0) + 0) * lstride + tid] = ruf;
-        lds[(2 * (c - f0) + 1) * lstride + tid] = ppf;
-      }
-      prevR_m = Rm; prevR_p = Rp;
-#pragma unroll
-      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; }
-      wm[4] = nm; wp[4] = np_;
-    }
-  }
-  // ---------------- advected quantities, one field at a time (Dycore.h:367-385) -----------------------
   const int nadv = 4 + P.nt;
-  for (int a = 0; a < nadv; a++) {
-    const int pf = P_U + a;                 // prim field
-    const double *q = prim + (long long)pf * P.prim_fs;
-    double *fl = flux + (long long)(1 + a) * g.fs_flux;
-    const bool addp = (pf == ncomp);
-    double w[5];
-    int c = f0 - 1;
+
+  for (int cf0 = f0; cf0 < fend; cf0 += P.seg) {
+    const int flast = (cf0 + P.seg < fend) ? cf0 + P.seg : fend;       // exclusive
+    const bool first = (cf0 == f0);
+    const int cstart = first ? cf0 - 1 : cf0;                          // the first chunk also builds cell f0-1
+    // ---------------- acoustic part: mass flux and pressure at the faces (Dycore.h:341-366) -------------
+    {
+      const double *pr = prim + (long long)P_RHO * P.prim_fs;
+      const double *pn = prim + (long long)ncomp * P.prim_fs;
+      const double *pp = prim + (long long)P_PRES * P.prim_fs;
+      double wm[5], wp[5];   // windows: rho*u_n product and pressure, cells c-2..c+2
+      int c = cstart;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
-    double prevR = 0.0;
-    for (; c < flast; c++) {
-      double nq = q[cell_off(c + 3)];
-      double L, R;
-      if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
-      else weno5_const(w, wc, L, R);
-      if (c >= f0) {
-        double ruf = lds[(2 * (c - f0) + 0) * lstride + tid];
-        double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
-        double f = ruf * val;
-        if (addp) f += lds[(2 * (c - f0) + 1) * lstride + tid];
-        fl[fbase + (long long)c * g.cs] = f;
+      for (int s = 0; s < 5; s++) {
+        long long o = cell_off(c - 2 + s);
+        wm[s] = pr[o] * pn[o];
+        wp[s] = pp[o];
       }
-      prevR = R;
+      double prevR_m = first ? 0.0 : carry[0 * nthr + tid];
+      double prevR_p = first ? 0.0 : carry[1 * nthr + tid];
+      for (; c < flast; c++) {
+        long long on = cell_off(c + 3);                    // prefetch the next cell entering the window
+        double nm = pr[on] * pn[on], np_ = pp[on];
+        double Lm, Rm, Lp, Rp;
+        if (DIR == 2) {
+          weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
+          weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
+        } else {
+          weno5_const(wm, wc, Lm, Rm);
+          weno5_const(wp, wc, Lp, Rp);
+        }
+        if (c >= cf0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
+          double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
+          bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
+          if (wall) { ru_L = 0.0; ru_R = 0.0; }
+          double w1 = 0.5 * (pp_R - cs * ru_R);
+          double w2 = 0.5 * (pp_L + cs * ru_L);
+          double ppf = w1 + w2;
+          double ruf = (w2 - w1) * rcs;
+          if (wall) ruf = 0.0;
+          flux[fbase + (long long)c * g.cs] = ruf;            // flux field 0
+          lds[(2 * (c - cf0) + 0) * nthr + tid] = ruf;
+          lds[(2 * (c - cf0) + 1) * nthr + tid] = ppf;
+        }
+        prevR_m = Rm; prevR_p = Rp;
 #pragma unroll
-      for (int s = 0; s < 4; s++) w[s] = w[s + 1];
-      w[4] = nq;
+        for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; }
+        wm[4] = nm; wp[4] = np_;
+      }
+      carry[0 * nthr + tid] = prevR_m;
+      carry[1 * nthr + tid] = prevR_p;
+    }
+    // ---------------- advected quantities, one field at a time (Dycore.h:367-385) -----------------------
+    for (int a = 0; a < nadv; a++) {
+      const int pf = P_U + a;                 // prim field
+      const double *q = prim + (long long)pf * P.prim_fs;
+      double *fl = flux + (long long)(1 + a) * g.fs_flux;
+      const bool addp = (pf == ncomp);
+      double w[5];
+      int c = cstart;
+#pragma unroll
+      for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
+      double prevR = first ? 0.0 : carry[(2 + a) * nthr + tid];
+      for (; c < flast; c++) {
+        double nq = q[cell_off(c + 3)];
+        double L, R;
+        if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
+        else weno5_const(w, wc, L, R);
+        if (c >= cf0) {
+          double ruf = lds[(2 * (c - cf0) + 0) * nthr + tid];
+          double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
+          double f = ruf * val;
+          if (addp) f += lds[(2 * (c - cf0) + 1) * nthr + tid];
+          fl[fbase + (long long)c * g.cs] = f;
+        }
+        prevR = R;
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[s] = w[s + 1];
+        w[4] = nq;
+      }
+      carry[(2 + a) * nthr + tid] = prevR;
     }
   }
 }

@@ -27,9 +27,15 @@
 using namespace pama;
 
 // ------------------------------------------------------------------------------------------------ kernels
-// grid: [0,nbx) x-sweep blocks, [nbx,nbx+nby) y-sweep, rest z-sweep.  Within a sweep: block -> (item block of 64
-// items, group of 4 segments); wavefront w of the block takes segment 4*group+w.
-struct FluxGrid { int nbx, nby, nbz; int sgx, sgy, sgz; /* segment groups (of 4) per line */ };
+// grid: [0,nbx) x-sweep blocks, [nbx,nbx+nby) y-sweep, rest z-sweep.  Within a sweep every WAVEFRONT is one work
+// unit: unit u -> (item block of 64 items = u / nspan, span index = u % nspan), i.e. consecutive wavefronts take
+// consecutive spans of the same items.
+struct FluxGrid {
+  int nbx, nby, nbz;        // workgroups per sweep
+  int spx, spy, spz;        // faces per thread (span) per sweep
+  int nsx, nsy, nsz;        // spans per line
+  long long nux, nuy, nuz;  // work units (wavefronts) per sweep
+};
 
 template <bool VZ_PER_ENS>
 __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxGrid G, const double *__restrict__ prim,
@@ -41,25 +47,20 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
   if (b < G.nbx) {
-    const int grp = b % G.sgx, ib = b / G.sgx;
-    const int f0 = (grp * 4 + wave) * P.seg;
-    const long long item = (long long)ib * 64 + lane;
-    if (f0 < P.nx && item < (long long)P.nz * P.ny * P.nens)
-      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, item, f0, lds, FLUX_THREADS, tid);
+    const long long u = (long long)b * 4 + wave;
+    const long long item = (u / G.nsx) * 64 + lane;
+    if (u < G.nux && item < (long long)P.nz * P.ny * P.nens)
+      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, item, (int)(u % G.nsx) * G.spx, G.spx, lds, FLUX_THREADS, tid);
   } else if (b < G.nbx + G.nby) {
-    b -= G.nbx;
-    const int grp = b % G.sgy, ib = b / G.sgy;
-    const int f0 = (grp * 4 + wave) * P.seg;
-    const long long item = (long long)ib * 64 + lane;
-    if (f0 < P.ny && item < (long long)P.nz * P.nx * P.nens)
-      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, item, f0, lds, FLUX_THREADS, tid);
+    const long long u = (long long)(b - G.nbx) * 4 + wave;
+    const long long item = (u / G.nsy) * 64 + lane;
+    if (u < G.nuy && item < (long long)P.nz * P.nx * P.nens)
+      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, item, (int)(u % G.nsy) * G.spy, G.spy, lds, FLUX_THREADS, tid);
   } else {
-    b -= G.nbx + G.nby;
-    const int grp = b % G.sgz, ib = b / G.sgz;
-    const int f0 = (grp * 4 + wave) * P.seg;
-    const long long item = (long long)ib * 64 + lane;
-    if (f0 < P.nz + 1 && item < (long long)P.ny * P.nx * P.nens)
-      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, item, f0, lds, FLUX_THREADS, tid);
+    const long long u = (long long)(b - G.nbx - G.nby) * 4 + wave;
+    const long long item = (u / G.nsz) * 64 + lane;
+    if (u < G.nuz && item < (long long)P.ny * P.nx * P.nens)
+      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, item, (int)(u % G.nsz) * G.spz, G.spz, lds, FLUX_THREADS, tid);
   }
 }
 
@@ -160,6 +161,7 @@ struct pam_amd_awfl {
   unsigned long long *dt_bits = nullptr;
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
+  int span_override = 0;   // 0: automatic flux-kernel span
   bool hydro_declared = false;
   std::map<std::string, KernelTimer> timers;
 };
@@ -231,15 +233,34 @@ int launch_init_prim(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, const pam_
   return PAM_AMD_OK;
 }
 
+// Span (faces per thread) of one sweep: the whole line if that still leaves enough wavefronts to fill the chip
+// (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail), otherwise the line is cut into equal spans, rounded
+// up to whole chunks, down to one chunk per thread.  `span_override` > 0 forces a value (tests / tuning).
+static void choose_span(int nfaces, long long nitems, int seg, int span_override, int &span, int &nspan, long long &nunits) {
+  const long long nib = (nitems + 63) / 64;
+  const long long want_units = 6144;
+  int pieces = 1;
+  if (span_override > 0) {
+    span = ((span_override + seg - 1) / seg) * seg;
+  } else {
+    while (nib * pieces < want_units && ((nfaces + pieces - 1) / pieces) > seg) pieces *= 2;
+    span = (((nfaces + pieces - 1) / pieces + seg - 1) / seg) * seg;
+  }
+  if (span < seg) span = seg;
+  nspan = (nfaces + span - 1) / span;
+  nunits = nib * nspan;
+}
+
 int launch_flux(pam_amd_awfl *h, const double *prim) {
   const Params &P = h->P;
   FluxGrid G;
-  auto groups = [&](int nfaces) { return ((nfaces + P.seg - 1) / P.seg + 3) / 4; };
-  G.sgx = groups(P.nx); G.sgy = groups(P.ny); G.sgz = groups(P.nz + 1);
-  G.nbx = nblocks((long long)P.nz * P.ny * P.nens, 64) * G.sgx;
-  G.nby = P.sim2d ? 0 : nblocks((long long)P.nz * P.nx * P.nens, 64) * G.sgy;
-  G.nbz = nblocks((long long)P.ny * P.nx * P.nens, 64) * G.sgz;
-  const size_t lds_bytes = (size_t)2 * P.seg * FLUX_THREADS * sizeof(double);
+  choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, G.spx, G.nsx, G.nux);
+  choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, G.spy, G.nsy, G.nuy);
+  choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, G.spz, G.nsz, G.nuz);
+  if (P.sim2d) G.nuy = 0;
+  G.nbx = (int)((G.nux + 3) / 4); G.nby = (int)((G.nuy + 3) / 4); G.nbz = (int)((G.nuz + 3) / 4);
+  // per-thread LDS: 2*seg face slots + one carried edge value per swept quantity (2 acoustic + 4+NT advected)
+  const size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
   ScopedTimer st(h, "flux");
   if (P.vz_per_ens)
     hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, h->stream, P, G,
@@ -565,8 +586,15 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h) {
 
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (faces < 1 || faces > 32) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,32]");
+  if (faces < 1 || faces > 16) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,16] (LDS slots per thread)");
   h->P.seg = faces;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (faces < 0) return fail(PAM_AMD_EINVAL, "set_flux_span: faces must be >= 0 (0 = automatic)");
+  h->span_override = faces;
   return PAM_AMD_OK;
 }
 

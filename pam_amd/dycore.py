@@ -191,6 +191,9 @@ class Dycore:
     def set_flux_segment(self, faces):
         check(self._lib.pam_amd_awfl_set_flux_segment(self._h, int(faces)))
 
+    def set_flux_span(self, faces):
+        check(self._lib.pam_amd_awfl_set_flux_span(self._h, int(faces)))
+
     def debug_buffer(self, name):
         ptr, n = C.c_void_p(), C.c_size_t()
         check(self._lib.pam_amd_awfl_debug_get_buffer(self._h, name.encode(), C.byref(ptr), C.byref(n)))

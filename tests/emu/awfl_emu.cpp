@@ -20,36 +20,38 @@ struct Emu {
   Params P;
   std::vector<double> prim0, prim1, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
   VerticalTables vt;
+  int span = 0;   // faces per thread in the flux sweep (0 = whole line)
 };
 
 static void flux_launch(Emu *h, const double *prim) {
   const Params &P = h->P;
-  auto groups = [&](int nfaces) { return ((nfaces + P.seg - 1) / P.seg + 3) / 4; };
-  std::vector<double> lds((size_t)2 * P.seg * FLUX_THREADS);
+  std::vector<double> lds(((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS);
   for (int dir = 0; dir < 3; dir++) {
     if (dir == 1 && P.sim2d) continue;
     const int nfaces = dir == 0 ? P.nx : (dir == 1 ? P.ny : P.nz + 1);
     const long long nitems = dir == 0 ? (long long)P.nz * P.ny * P.nens
                                       : (dir == 1 ? (long long)P.nz * P.nx * P.nens : (long long)P.ny * P.nx * P.nens);
-    const int sg = groups(nfaces);
-    const long long nib = (nitems + 63) / 64;
-    for (long long b = 0; b < nib * sg; b++) {
-      const int grp = (int)(b % sg);
-      const long long ib = b / sg;
-      for (int tid = 0; tid < FLUX_THREADS; tid++) {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int f0 = (grp * 4 + wave) * P.seg;
-        const long long item = ib * 64 + lane;
-        if (!(f0 < nfaces && item < nitems)) continue;
+    // span as in awfl_kernels.hip::choose_span with an override (h->span; 0 = whole line)
+    int span = h->span > 0 ? ((h->span + P.seg - 1) / P.seg) * P.seg : ((nfaces + P.seg - 1) / P.seg) * P.seg;
+    const int nspan = (nfaces + span - 1) / span;
+    const long long nunits = ((nitems + 63) / 64) * nspan;
+    double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());
+    for (long long u = 0; u < nunits; u++) {
+      const int wave = (int)(u % 4);
+      for (int lane = 0; lane < 64; lane++) {
+        const int tid = wave * 64 + lane;
+        const long long item = (u / nspan) * 64 + lane;
+        const int f0 = (int)(u % nspan) * span;
+        if (item >= nitems) continue;
         if (dir == 0) {
-          if (P.vz_per_ens) flux_line_body<0, true>(P, prim, h->fx.data(), item, f0, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<0, false>(P, prim, h->fx.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          if (P.vz_per_ens) flux_line_body<0, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<0, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
         } else if (dir == 1) {
-          if (P.vz_per_ens) flux_line_body<1, true>(P, prim, h->fy.data(), item, f0, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<1, false>(P, prim, h->fy.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          if (P.vz_per_ens) flux_line_body<1, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<1, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
         } else {
-          if (P.vz_per_ens) flux_line_body<2, true>(P, prim, h->fz.data(), item, f0, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<2, false>(P, prim, h->fz.data(), item, f0, lds.data(), FLUX_THREADS, tid);
+          if (P.vz_per_ens) flux_line_body<2, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
+          else flux_line_body<2, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
         }
       }
     }
@@ -112,6 +114,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
 void emu_destroy(Emu *h) { delete h; }
 void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
 void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
+void emu_set_span(Emu *h, int span) { h->span = span; }
 int emu_vz_per_ens(Emu *h) { return h->P.vz_per_ens; }
 double *emu_buffer(Emu *h, const char *name) {
   std::string k(name);

@@ -106,16 +106,18 @@ def test_time_step_matches_oracle(case):
     dycore.finalize(coupler)
 
 
-@pytest.mark.parametrize("seg", [1, 3, 8, 16])
-def test_flux_segment_length_does_not_change_results(seg):
-    """The flux kernel's segment length is a pure scheduling knob."""
+@pytest.mark.parametrize("seg,span", [(1, 1), (3, 0), (3, 6), (8, 8), (16, 0), (8, 16)])
+def test_flux_sweep_geometry_does_not_change_results(seg, span):
+    """Chunk length (LDS face slots) and span (faces per thread) of the flux kernel are pure scheduling knobs: every
+    cell polynomial and every face flux is the same arithmetic whatever the decomposition -> bit-identical results."""
     import torch
     nens, nx, ny, nz = 4, 9, 4, 9
     tr = idz.TRACERS_KESSLER_SHOC
     res = []
-    for s in (8, seg):
+    for s, sp in ((8, 0), (seg, span)):
         coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, idz.stretched_interfaces(nz, 12000.0))
         dycore.set_flux_segment(s)
+        dycore.set_flux_span(sp)
         dycore.declare_current_profile_as_hydrostatic(coupler)
         dycore.timeStep(coupler)
         torch.cuda.synchronize()
