@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--nens", type=int, default=0, help="members per GPU (default: the config's)")
     ap.add_argument("--seg", type=int, default=0, help="flux-kernel chunk length (default: library default)")
     ap.add_argument("--span", type=int, default=-1, help="flux-kernel faces per thread (default: automatic)")
+    ap.add_argument("--chunks", type=int, default=-1, help="internal ensemble chunks / HIP streams (default: automatic)")
+    ap.add_argument("--lds-floor", type=int, default=64 * 1024, help="flux-kernel LDS floor in bytes when chunks > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -144,6 +146,8 @@ def main():
         dycore.set_flux_segment(args.seg)
     if args.span >= 0:
         dycore.set_flux_span(args.span)
+    if args.chunks >= 0:
+        dycore.set_ensemble_chunks(args.chunks, args.lds_floor)
     nens_gen = min(16, nens_pg)
     f = make_inputs(idz, nens_pg, nx, ny, nz, zint, tracers, consts, xlen, ylen, nens_gen=nens_gen, id0=rank * 1000)
     reps = (nens_pg + nens_gen - 1) // nens_gen

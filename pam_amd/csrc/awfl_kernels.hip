@@ -30,6 +30,14 @@ using namespace pama;
 // grid: [0,nbx) x-sweep blocks, [nbx,nbx+nby) y-sweep, rest z-sweep.  Within a sweep every WAVEFRONT is one work
 // unit: unit u -> (item block of 64 items = u / nspan, span index = u % nspan), i.e. consecutive wavefronts take
 // consecutive spans of the same items.
+// Ensemble sub-range [e0, e0+ne) processed by one launch (the arrays keep their full-nens strides).  Local thread
+// indices are flattened over (cell or line, local member) with the member fastest, then mapped to global indices.
+struct EnsRange { int e0, ne; };
+__device__ __forceinline__ long long to_global(long long t, int nens, EnsRange R) {
+  const long long r = t / R.ne;
+  return r * nens + R.e0 + (t - r * R.ne);
+}
+
 struct FluxGrid {
   int nbx, nby, nbz;        // workgroups per sweep
   int spx, spy, spz;        // faces per thread (span) per sweep
@@ -38,7 +46,8 @@ struct FluxGrid {
 };
 
 template <bool VZ_PER_ENS>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxGrid G, const double *__restrict__ prim,
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
+                                                                  const double *__restrict__ prim,
                                                                   double *__restrict__ fx, double *__restrict__ fy,
                                                                   double *__restrict__ fz) {
   extern __shared__ double lds[];
@@ -49,57 +58,62 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
   if (b < G.nbx) {
     const long long u = (long long)b * 4 + wave;
     const long long item = (u / G.nsx) * 64 + lane;
-    if (u < G.nux && item < (long long)P.nz * P.ny * P.nens)
-      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, item, (int)(u % G.nsx) * G.spx, G.spx, lds, FLUX_THREADS, tid);
+    if (u < G.nux && item < (long long)P.nz * P.ny * R.ne)
+      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, to_global(item, P.nens, R), (int)(u % G.nsx) * G.spx, G.spx, lds,
+                                    FLUX_THREADS, tid);
   } else if (b < G.nbx + G.nby) {
     const long long u = (long long)(b - G.nbx) * 4 + wave;
     const long long item = (u / G.nsy) * 64 + lane;
-    if (u < G.nuy && item < (long long)P.nz * P.nx * P.nens)
-      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, item, (int)(u % G.nsy) * G.spy, G.spy, lds, FLUX_THREADS, tid);
+    if (u < G.nuy && item < (long long)P.nz * P.nx * R.ne)
+      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, to_global(item, P.nens, R), (int)(u % G.nsy) * G.spy, G.spy, lds,
+                                    FLUX_THREADS, tid);
   } else {
     const long long u = (long long)(b - G.nbx - G.nby) * 4 + wave;
     const long long item = (u / G.nsz) * 64 + lane;
-    if (u < G.nuz && item < (long long)P.ny * P.nx * P.nens)
-      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, item, (int)(u % G.nsz) * G.spz, G.spz, lds, FLUX_THREADS, tid);
+    if (u < G.nuz && item < (long long)P.ny * P.nx * R.ne)
+      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, to_global(item, P.nens, R), (int)(u % G.nsz) * G.spz, G.spz, lds,
+                                    FLUX_THREADS, tid);
   }
 }
 
-__global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, const double *__restrict__ fx,
+__global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
                                                        double dt) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < P.ncell) fct_mult_body(P, fx, fy, fz, seed, mult, dt, idx);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)P.nz * P.ny * P.nx * R.ne) fct_mult_body(P, fx, fy, fz, seed, mult, dt, to_global(t, P.nens, R));
 }
 
 template <int STAGE>
-__global__ void __launch_bounds__(256) awfl_update_kernel(Params P, const double *prim_in, const double *prim0,
-                                                          double *prim_out, const double *__restrict__ fx,
-                                                          const double *__restrict__ fy, const double *__restrict__ fz,
-                                                          const double *__restrict__ mult, double *__restrict__ seed,
-                                                          double dt_dyn) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < P.ncell) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, idx);
+__global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, const double *prim_in,
+                                                          const double *prim0, double *prim_out,
+                                                          const double *__restrict__ fx, const double *__restrict__ fy,
+                                                          const double *__restrict__ fz, const double *__restrict__ mult,
+                                                          double *__restrict__ seed, double dt_dyn) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)P.nz * P.ny * P.nx * R.ne)
+    update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, to_global(t, P.nens, R));
 }
 
 struct GcmPtrs { const double *p[5]; int use; };
 
-__global__ void __launch_bounds__(256) awfl_init_prim_kernel(Params P, const double *__restrict__ rho_d,
+__global__ void __launch_bounds__(256) awfl_init_prim_kernel(Params P, EnsRange R, const double *__restrict__ rho_d,
                                                              const double *__restrict__ u, const double *__restrict__ v,
                                                              const double *__restrict__ w, const double *__restrict__ temp,
                                                              TracerPtrs trc, GcmPtrs gcm, double *__restrict__ prim,
                                                              double *__restrict__ seed, int subtract_hy) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < P.ncell) init_prim_body(P, rho_d, u, v, w, temp, trc, gcm.use ? gcm.p : nullptr, prim, seed, subtract_hy != 0, idx);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)P.nz * P.ny * P.nx * R.ne)
+    init_prim_body(P, rho_d, u, v, w, temp, trc, gcm.use ? gcm.p : nullptr, prim, seed, subtract_hy != 0, to_global(t, P.nens, R));
 }
 
-__global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, const double *__restrict__ prim,
+__global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, EnsRange R, const double *__restrict__ prim,
                                                             const double *__restrict__ seed, double *__restrict__ rho_d,
                                                             double *__restrict__ u, double *__restrict__ v,
                                                             double *__restrict__ w, double *__restrict__ temp,
                                                             TracerPtrs trc) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < P.ncell) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, idx);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)P.nz * P.ny * P.nx * R.ne) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, to_global(t, P.nens, R));
 }
 
 // CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, one atomicMin per wavefront on the
@@ -148,6 +162,15 @@ struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// One ensemble chunk = a contiguous range of members advanced on its own HIP stream, so that the HBM-bound update /
+// FCT kernels of one chunk overlap the FP64-VALU-bound flux kernel of another (members are independent; Dycore.h:629-657).
+struct Chunk {
+  EnsRange r;
+  hipStream_t stream = nullptr;   // == the caller's stream when there is a single chunk
+  hipEvent_t done = nullptr;      // end of this chunk's work in a timeStep (join)
+  hipEvent_t flux_done = nullptr; // end of this chunk's most recent flux kernel (anti-phase chain)
+};
+
 struct pam_amd_awfl {
   pam_amd_awfl_config_t cfg;
   Params P;
@@ -161,7 +184,11 @@ struct pam_amd_awfl {
   unsigned long long *dt_bits = nullptr;
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
-  int span_override = 0;   // 0: automatic flux-kernel span
+  int span_override = 0;       // 0: automatic flux-kernel span
+  int chunks_requested = 0;    // 0: automatic
+  size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
+  std::vector<Chunk> chunks;
+  hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
   std::map<std::string, KernelTimer> timers;
 };
@@ -170,18 +197,19 @@ namespace {
 
 struct ScopedTimer {
   pam_amd_awfl *h;
+  hipStream_t s;
   KernelTimer *t = nullptr;
   hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(pam_amd_awfl *h_, const char *name) : h(h_) {
+  ScopedTimer(pam_amd_awfl *h_, const char *name, hipStream_t s_) : h(h_), s(s_) {
     if (!h->timing) return;
     t = &h->timers[name];
     hipEventCreate(&a);
     hipEventCreate(&b);
-    hipEventRecord(a, h->stream);
+    hipEventRecord(a, s);
   }
   ~ScopedTimer() {
     if (!t) return;
-    hipEventRecord(b, h->stream);
+    hipEventRecord(b, s);
     t->pending.emplace_back(a, b);
     t->launches++;
   }
@@ -200,6 +228,8 @@ void drain(KernelTimer &t) {
 }
 
 inline int nblocks(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+inline long long ncell_of(const Params &P, EnsRange r) { return (long long)P.nz * P.ny * P.nx * r.ne; }
+inline EnsRange full_range(const Params &P) { return EnsRange{0, P.nens}; }
 
 int make_tracer_ptrs(const pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, TracerPtrs &tp) {
   if (!f || !f->density_dry || !f->uvel || !f->vvel || !f->wvel || !f->temp || !f->tracers)
@@ -213,7 +243,7 @@ int make_tracer_ptrs(const pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, Trac
 }
 
 int launch_init_prim(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, const pam_amd_awfl_gcm_columns_t *gcm,
-                     bool subtract_hy) {
+                     bool subtract_hy, EnsRange r, hipStream_t s) {
   TracerPtrs tp;
   int rc = make_tracer_ptrs(h, f, tp);
   if (rc) return rc;
@@ -226,9 +256,20 @@ int launch_init_prim(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, const pam_
   } else {
     for (int i = 0; i < 5; i++) gp.p[i] = nullptr;
   }
-  ScopedTimer st(h, "init_prim");
-  hipLaunchKernelGGL(awfl_init_prim_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P,
+  ScopedTimer st(h, "init_prim", s);
+  hipLaunchKernelGGL(awfl_init_prim_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r,
                      f->density_dry, f->uvel, f->vvel, f->wvel, f->temp, tp, gp, h->prim0, h->seed, subtract_hy ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r, hipStream_t s) {
+  TracerPtrs tp;
+  int rc = make_tracer_ptrs(h, f, tp);
+  if (rc) return rc;
+  ScopedTimer st(h, "finalize", s);
+  hipLaunchKernelGGL(awfl_finalize_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, h->prim0,
+                     h->seed, f->density_dry, f->uvel, f->vvel, f->wvel, f->temp, tp);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -251,39 +292,44 @@ static void choose_span(int nfaces, long long nitems, int seg, int span_override
   nunits = nib * nspan;
 }
 
-int launch_flux(pam_amd_awfl *h, const double *prim) {
+int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) {
   const Params &P = h->P;
   FluxGrid G;
+  // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
   choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, G.spx, G.nsx, G.nux);
   choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, G.spy, G.nsy, G.nuy);
   choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, G.spz, G.nsz, G.nuz);
-  if (P.sim2d) G.nuy = 0;
+  G.nux = (((long long)P.nz * P.ny * r.ne + 63) / 64) * G.nsx;
+  G.nuy = P.sim2d ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
+  G.nuz = (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz;
   G.nbx = (int)((G.nux + 3) / 4); G.nby = (int)((G.nuy + 3) / 4); G.nbz = (int)((G.nuz + 3) / 4);
   // per-thread LDS: 2*seg face slots + one carried edge value per swept quantity (2 acoustic + 4+NT advected)
-  const size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
-  ScopedTimer st(h, "flux");
+  size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
+  if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
+  ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
-    hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, h->stream, P, G,
-                       prim, h->flux_x, h->flux_y, h->flux_z);
+    hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
+                       h->flux_x, h->flux_y, h->flux_z);
   else
-    hipLaunchKernelGGL(awfl_flux_kernel<false>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, h->stream, P,
-                       G, prim, h->flux_x, h->flux_y, h->flux_z);
+    hipLaunchKernelGGL(awfl_flux_kernel<false>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
+                       h->flux_x, h->flux_y, h->flux_z);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
 
-int launch_fct(pam_amd_awfl *h, double dt) {
-  ScopedTimer st(h, "fct_mult");
-  hipLaunchKernelGGL(awfl_fct_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, h->flux_x, h->flux_y,
+int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s) {
+  ScopedTimer st(h, "fct_mult", s);
+  hipLaunchKernelGGL(awfl_fct_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
                      h->flux_z, h->seed, h->mult, dt);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
 
 template <int STAGE>
-int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn) {
-  ScopedTimer st(h, "update");
-  hipLaunchKernelGGL(awfl_update_kernel<STAGE>, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, prim_in,
+int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
+                  hipStream_t s) {
+  ScopedTimer st(h, "update", s);
+  hipLaunchKernelGGL(awfl_update_kernel<STAGE>, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, prim_in,
                      prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
@@ -294,7 +340,7 @@ int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl,
   const unsigned long long init = 0x7FF0000000000000ull;   // +inf
   HIP_TRY(hipMemcpyAsync(h->dt_bits, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   {
-    ScopedTimer st(h, "cfl");
+    ScopedTimer st(h, "cfl", h->stream);
     int nb = nblocks(h->P.ncell, 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(awfl_cfl_kernel, dim3(nb), dim3(256), 0, h->stream, h->P, f->density_dry, f->uvel, f->vvel, f->wvel,
@@ -310,7 +356,46 @@ int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl,
   return PAM_AMD_OK;
 }
 
+void destroy_chunks(pam_amd_awfl *h) {
+  for (auto &c : h->chunks) {
+    if (c.done) (void)hipEventDestroy(c.done);
+    if (c.flux_done) (void)hipEventDestroy(c.flux_done);
+    if (c.stream && c.stream != h->stream) (void)hipStreamDestroy(c.stream);
+  }
+  h->chunks.clear();
+}
+
+// (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
+int build_chunks(pam_amd_awfl *h) {
+  (void)hipStreamSynchronize(h->stream);
+  for (auto &c : h->chunks) if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
+  destroy_chunks(h);
+  const int nens = h->P.nens;
+  int n = h->chunks_requested;
+  if (n <= 0) n = (nens >= 512) ? 3 : (nens >= 256 ? 2 : 1);   // automatic (measured on C2: 1 -> 1.52, 2 -> 1.65, 3 -> 1.66 G/s)
+  const int per = (((nens + n - 1) / n + 63) / 64) * 64;
+  for (int e0 = 0; e0 < nens; e0 += per) {
+    Chunk c;
+    c.r.e0 = e0;
+    c.r.ne = (e0 + per <= nens) ? per : nens - e0;
+    h->chunks.push_back(c);
+  }
+  if (h->chunks.size() == 1) {
+    h->chunks[0].stream = h->stream;
+  } else {
+    for (auto &c : h->chunks) {
+      HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c.flux_done, hipEventDisableTiming));
+    }
+  }
+  return PAM_AMD_OK;
+}
+
 void free_all(pam_amd_awfl *h) {
+  destroy_chunks(h);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  h->ev_fork = nullptr;
   double **bufs[] = {&h->prim0, &h->prim1, &h->flux_x, &h->flux_y, &h->flux_z, &h->seed, &h->mult, &h->dz,
                      &h->grav_var, &h->hy_dens, &h->hy_pres, &h->vz, &h->vert_s2c, &h->vert_wrl};
   for (auto b : bufs) {
@@ -419,7 +504,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMemset(h->hy_dens, 0xFF, nzn * 8));
   INIT_TRY(hipMemset(h->hy_pres, 0xFF, nzn * 8));
   P.dz = h->dz; P.grav_var = h->grav_var; P.hy_dens = h->hy_dens; P.hy_pres = h->hy_pres; P.vz = h->vz;
+  INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
 #undef INIT_TRY
+  h->flux_lds_floor = 64 * 1024;   // with >1 chunk: at most 2 flux workgroups per CU, leaving wave slots for update blocks
+  if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }
   *out = h;
   return PAM_AMD_OK;
 }
@@ -427,6 +515,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
 int pam_amd_awfl_finalize(pam_amd_awfl_t *h) {
   if (!h) return PAM_AMD_OK;
   (void)hipStreamSynchronize(h->stream);
+  for (auto &c : h->chunks) if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
   for (auto &kv : h->timers) drain(kv.second);
   free_all(h);
   delete h;
@@ -482,10 +571,10 @@ int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_
 int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields,
                                                         const pam_amd_awfl_gcm_columns_t *gcm) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  int rc = launch_init_prim(h, fields, gcm, /*subtract_hy=*/false);
+  int rc = launch_init_prim(h, fields, gcm, /*subtract_hy=*/false, full_range(h->P), h->stream);
   if (rc) return rc;
   {
-    ScopedTimer st(h, "hydro");
+    ScopedTimer st(h, "hydro", h->stream);
     const long long n = (long long)h->P.nz * h->P.nens;
     if (h->P.vz_per_ens)
       hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->grav_var,
@@ -506,19 +595,12 @@ int pam_amd_awfl_compute_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_
 
 int pam_amd_awfl_convert_coupler_to_dynamics(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  return launch_init_prim(h, fields, nullptr, !h->P.grav_balance);
+  return launch_init_prim(h, fields, nullptr, !h->P.grav_balance, full_range(h->P), h->stream);
 }
 
 int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  TracerPtrs tp;
-  int rc = make_tracer_ptrs(h, fields, tp);
-  if (rc) return rc;
-  ScopedTimer st(h, "finalize");
-  hipLaunchKernelGGL(awfl_finalize_kernel, dim3(nblocks(h->P.ncell, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->seed,
-                     fields->density_dry, fields->uvel, fields->vvel, fields->wvel, fields->temp, tp);
-  HIP_TRY(hipGetLastError());
-  return PAM_AMD_OK;
+  return launch_finalize(h, fields, full_range(h->P), h->stream);
 }
 
 int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double crm_dt, double dt_dyn_hint,
@@ -528,10 +610,10 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   if (!h->hydro_declared)
     return fail(PAM_AMD_ESTATE, "time_step: declare_current_profile_as_hydrostatic has not been called since init / "
                                 "since the balance option changed (variable_gravity / hy_* are undefined, SURVEY F4)");
-  // Dycore.h:128-134
-  int rc = pam_amd_awfl_convert_coupler_to_dynamics(h, fields);
+  TracerPtrs tp_check;
+  int rc = make_tracer_ptrs(h, fields, tp_check);
   if (rc) return rc;
-  // Dycore.h:141-145
+  // Dycore.h:141-145: the dynamics step comes from the COUPLER fields of every member (before any conversion)
   double dt_dyn = dt_dyn_hint;
   if (!(dt_dyn > 0)) {
     rc = local_time_step(h, fields, 0.8, &dt_dyn);
@@ -543,22 +625,46 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   dt_dyn = crm_dt / ncycles;
   if (ncycles_out) *ncycles_out = ncycles;
   if (dt_dyn_out) *dt_dyn_out = dt_dyn;
-  for (int ic = 0; ic < ncycles; ic++) {
-    // stage 1 (Dycore.h:156-176)
-    if ((rc = launch_flux(h, h->prim0))) return rc;
-    if ((rc = launch_fct(h, dt_dyn))) return rc;
-    if ((rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn))) return rc;
-    // stage 2 (Dycore.h:180-200)
-    if ((rc = launch_flux(h, h->prim1))) return rc;
-    if ((rc = launch_fct(h, (1.0 / 4.0) * dt_dyn))) return rc;
-    if ((rc = launch_update<2>(h, h->prim1, h->prim0, h->prim1, dt_dyn))) return rc;
-    // stage 3 (Dycore.h:204-221)
-    if ((rc = launch_flux(h, h->prim1))) return rc;
-    if ((rc = launch_fct(h, (2.0 / 3.0) * dt_dyn))) return rc;
-    if ((rc = launch_update<3>(h, h->prim1, h->prim0, h->prim0, dt_dyn))) return rc;
+  const bool forked = h->chunks.size() > 1;
+  if (forked) {   // chunk streams start after everything already queued on the caller's stream
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    for (auto &c : h->chunks) HIP_TRY(hipStreamWaitEvent(c.stream, h->ev_fork, 0));
   }
-  // Dycore.h:254
-  return pam_amd_awfl_convert_dynamics_to_coupler(h, fields);
+  // Dycore.h:128-134 (per chunk)
+  for (auto &c : h->chunks)
+    if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
+  // Launches are issued stage by stage, round-robin over the chunks.  With several chunks the flux kernels are chained
+  // across chunks by events (A1 -> B1 -> A2 -> B2 ...): two VALU-bound flux kernels never share the chip, and a chunk's
+  // HBM-bound FCT/update kernels run beside the NEXT chunk's flux kernel instead of beside their own kind.
+  hipEvent_t prev_flux = nullptr;
+  auto stage = [&](Chunk &c, int st, const double *pin, double *pout, double dt_stage) -> int {
+    int r2;
+    if (forked && prev_flux) HIP_TRY(hipStreamWaitEvent(c.stream, prev_flux, 0));
+    if ((r2 = launch_flux(h, pin, c.r, c.stream))) return r2;
+    if (forked) { HIP_TRY(hipEventRecord(c.flux_done, c.stream)); prev_flux = c.flux_done; }
+    if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
+    if (st == 1) return launch_update<1>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    if (st == 2) return launch_update<2>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    return launch_update<3>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+  };
+  for (int ic = 0; ic < ncycles; ic++) {
+    for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
+      if ((rc = stage(c, 1, h->prim0, h->prim1, dt_dyn))) return rc;
+    for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
+      if ((rc = stage(c, 2, h->prim1, h->prim1, (1.0 / 4.0) * dt_dyn))) return rc;
+    for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
+      if ((rc = stage(c, 3, h->prim1, h->prim0, (2.0 / 3.0) * dt_dyn))) return rc;
+  }
+  // Dycore.h:254 (per chunk), then join: the caller's stream continues after every chunk has finished
+  for (auto &c : h->chunks)
+    if ((rc = launch_finalize(h, fields, c.r, c.stream))) return rc;
+  if (forked) {
+    for (auto &c : h->chunks) {
+      HIP_TRY(hipEventRecord(c.done, c.stream));
+      HIP_TRY(hipStreamWaitEvent(h->stream, c.done, 0));
+    }
+  }
+  return PAM_AMD_OK;
 }
 
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable) {
@@ -598,6 +704,16 @@ int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces) {
   return PAM_AMD_OK;
 }
 
+int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (chunks < 0 || chunks > 16) return fail(PAM_AMD_EINVAL, "set_ensemble_chunks: chunks must be in [0,16] (0 = automatic)");
+  if (flux_lds_floor_bytes < 0 || flux_lds_floor_bytes > 160 * 1024)
+    return fail(PAM_AMD_EINVAL, "set_ensemble_chunks: flux_lds_floor_bytes must be in [0, 163840]");
+  h->chunks_requested = chunks;
+  h->flux_lds_floor = (size_t)flux_lds_floor_bytes;
+  return build_chunks(h);
+}
+
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem) {
   if (!h || !name || !device_ptr || !nelem) return fail(PAM_AMD_EINVAL, "debug_get_buffer: null argument");
   const std::string k(name);
@@ -615,8 +731,8 @@ int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **
 int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   int rc;
-  if ((rc = launch_flux(h, h->prim0))) return rc;
-  return launch_fct(h, dt);
+  if ((rc = launch_flux(h, h->prim0, full_range(h->P), h->stream))) return rc;
+  return launch_fct(h, dt, full_range(h->P), h->stream);
 }
 
 }  // extern "C"

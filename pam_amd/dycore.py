@@ -194,6 +194,9 @@ class Dycore:
     def set_flux_span(self, faces):
         check(self._lib.pam_amd_awfl_set_flux_span(self._h, int(faces)))
 
+    def set_ensemble_chunks(self, chunks, flux_lds_floor_bytes=64 * 1024):
+        check(self._lib.pam_amd_awfl_set_ensemble_chunks(self._h, int(chunks), int(flux_lds_floor_bytes)))
+
     def debug_buffer(self, name):
         ptr, n = C.c_void_p(), C.c_size_t()
         check(self._lib.pam_amd_awfl_debug_get_buffer(self._h, name.encode(), C.byref(ptr), C.byref(n)))

@@ -127,6 +127,27 @@ def test_flux_sweep_geometry_does_not_change_results(seg, span):
         assert np.array_equal(res[0][k], res[1][k]), k
 
 
+@pytest.mark.parametrize("chunks", [1, 2, 3])
+def test_ensemble_chunking_does_not_change_results(chunks):
+    """Internal ensemble chunks (member ranges on separate HIP streams) are a scheduling device: members are
+    independent, so any chunking gives bit-identical results, including ragged last chunks (nens=150 -> 128+22)."""
+    import torch
+    nens, nx, ny, nz = 150, 6, 3, 7
+    tr = idz.TRACERS_KESSLER_SHOC
+    res = []
+    for n in (1, chunks):
+        coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, idz.stretched_interfaces(nz, 9000.0))
+        dycore.set_ensemble_chunks(n)
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+        dycore.timeStep(coupler)
+        dycore.timeStep(coupler)
+        torch.cuda.synchronize()
+        res.append(coupler.dump_fields())
+        dycore.finalize(coupler)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_raw_fluxes_match_oracle():
     """Kernel-level check of the reconstruction/flux kernel (Dycore.h:334-519) on its own."""
     import torch
