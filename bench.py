@@ -193,31 +193,49 @@ def main():
     total_updates = cells * substeps * world
     value = total_updates / elapsed
 
-    # ---- per-kernel durations (HIP events on the launch stream), separate un-timed pass
+    # ---- per-kernel durations (HIP events on the stream each kernel is launched on), separate un-timed passes
     roofline = None
     kernels = {}
     if not args.no_kernel_timing:
+        def timed_pass():
+            dycore.reset_kernel_timing()
+            one_step()
+            torch.cuda.synchronize()
+            out = {}
+            for name in ("flux", "fct_mult", "update", "init_prim", "finalize", "cfl"):
+                ms, n = dycore.get_kernel_timing(name)
+                if n:
+                    out[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+            return out
         dycore.set_kernel_timing(True)
-        dycore.reset_kernel_timing()
-        one_step()
-        torch.cuda.synchronize()
-        for name in ("flux", "fct_mult", "update", "init_prim", "finalize", "cfl"):
-            ms, n = dycore.get_kernel_timing(name)
-            if n:
-                kernels[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+        kernels = timed_pass()                         # shipped configuration (chunks overlap: durations include contention)
+        # kernel-level roofline: the dominant kernel on its own (one chunk = whole ensemble per launch, nothing co-running)
+        dycore.set_ensemble_chunks(1)
+        alone = timed_pass()
+        dycore.set_ensemble_chunks(args.chunks if args.chunks >= 0 else 0, args.lds_floor)
         dycore.set_kernel_timing(False)
-        if "flux" in kernels:
-            avg_s = kernels["flux"]["avg_ms"] * 1e-3
+        if "flux" in alone:
+            avg_s = alone["flux"]["avg_ms"] * 1e-3
             alg_bytes = cells / 3.0 * 64.0 * (5 + nt)            # 64*(5+NT) B per cell-update, 1/3 per stage
             achieved = alg_bytes / avg_s / 1e9
             ndir = 2 if ny == 1 else 3
-            flops = cells * ndir * (6 + nt) * 330.0                # (6+NT) polynomials/cell/dir x ~330 flop
+            # polynomials per cell-stage: ndir x (2 acoustic + 4+NT advected), x(span+1)/span (whole-line spans: ~1.03);
+            # 148 FP64 instructions per polynomial of which 49% FMAs (ISA count) -> 220 flop
+            flops = cells * ndir * (6 + nt) * 1.03 * 220.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_c2_flux_traffic.json")
+            if args.config == "c2" and args.nens == 0 and os.path.exists(tpath):
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]   # rocprofv3 PMC passes of this same command
             roofline = {"bound": "hbm", "kernel": "awfl_flux_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_ms": kernels["flux"]["avg_ms"], "alg_bytes_per_launch": alg_bytes,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "avg_launch_ms": alone["flux"]["avg_ms"], "alg_bytes_per_launch": alg_bytes,
+                        "note": "one launch = one tendency stage of the whole ensemble, measured with --chunks 1 "
+                                "(nothing co-running); in the shipped chunked configuration launches are per chunk and "
+                                "overlap the update kernels (see kernels)",
                         "valu": {"bound": "fp64-valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                 "note": "the kernel is FP64-VALU-bound (SURVEY F5): this is the roofline that binds"}}
+                                 "note": "the kernel is FP64-VALU-bound (SURVEY F5; SQ counters: VALU issuing ~85% of "
+                                         "cycles at the ~2.0 GHz clock held): this is the roofline that binds"}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -139,7 +139,10 @@ def _sc_pressure_dry(z, z_0, z_trop, z_top, T_0, T_trop, T_top, p_0, R_d, grav):
 
 
 def _sc_relhum(z, z_0, z_trop):
-    return 1.0 - 0.75 * (z / z_trop) ** 1.25 if z <= z_trop else 0.25
+    # a quadrature point can sit at z = -1e-13: the reference's pow() then gives NaN, which its std::min() turns into
+    # qv = 0.014 (supercell_init.h:62-63); Python's min() does the same, so only the warning is silenced here.
+    with np.errstate(invalid="ignore"):
+        return 1.0 - 0.75 * np.float64(z / z_trop) ** 1.25 if z <= z_trop else 0.25
 
 
 def _sc_sat_mix_dry(press, T):

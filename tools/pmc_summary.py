@@ -23,7 +23,7 @@ def short(name):
 
 def main():
     acc = defaultdict(lambda: defaultdict(list))
-    for path in sys.argv[1:]:
+    for path in [a for a in sys.argv[1:] if not a.startswith('--')]:
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
@@ -39,6 +39,13 @@ def main():
                 if c == "FETCH_SIZE":
                     extra += "  (x2 gfx950 correction: %.3f GB)" % (2 * mean * 1024 / 1e9)
             print("%-26s %-22s n=%4d mean=%.6g%s" % (k, c, len(v), mean, extra))
+    if "--flux-json" in sys.argv and "awfl_flux_kernel" in acc:
+        import json
+        f = acc["awfl_flux_kernel"]
+        fetch = sum(f["FETCH_SIZE"]) / len(f["FETCH_SIZE"]) * 1024 * 2      # gfx950: x2 (calibrated)
+        write = sum(f["WRITE_SIZE"]) / len(f["WRITE_SIZE"]) * 1024
+        print(json.dumps({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write,
+                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --chunks 1, config c2"}))
 
 
 if __name__ == "__main__":
