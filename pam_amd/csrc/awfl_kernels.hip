@@ -166,9 +166,12 @@ struct KernelTimer {
 // FCT kernels of one chunk overlap the FP64-VALU-bound flux kernel of another (members are independent; Dycore.h:629-657).
 struct Chunk {
   EnsRange r;
-  hipStream_t stream = nullptr;   // == the caller's stream when there is a single chunk
+  hipStream_t stream = nullptr;   // FCT/update/convert kernels (== the caller's stream when there is a single chunk)
+  hipStream_t fstream = nullptr;  // flux kernels: a separate LOWER-priority stream, so that HBM-bound update blocks are
+                                  // dispatched ahead of queued flux blocks whenever both are ready
   hipEvent_t done = nullptr;      // end of this chunk's work in a timeStep (join)
-  hipEvent_t flux_done = nullptr; // end of this chunk's most recent flux kernel (anti-phase chain)
+  hipEvent_t flux_done = nullptr; // end of this chunk's most recent flux kernel
+  hipEvent_t upd_done = nullptr;  // end of this chunk's most recent update (or init) kernel
 };
 
 struct pam_amd_awfl {
@@ -186,6 +189,7 @@ struct pam_amd_awfl {
   bool timing = false;
   int span_override = 0;       // 0: automatic flux-kernel span
   int chunks_requested = 0;    // 0: automatic
+  bool use_priorities = true;
   size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
@@ -360,6 +364,8 @@ void destroy_chunks(pam_amd_awfl *h) {
   for (auto &c : h->chunks) {
     if (c.done) (void)hipEventDestroy(c.done);
     if (c.flux_done) (void)hipEventDestroy(c.flux_done);
+    if (c.upd_done) (void)hipEventDestroy(c.upd_done);
+    if (c.fstream && c.fstream != h->stream) (void)hipStreamDestroy(c.fstream);
     if (c.stream && c.stream != h->stream) (void)hipStreamDestroy(c.stream);
   }
   h->chunks.clear();
@@ -368,7 +374,10 @@ void destroy_chunks(pam_amd_awfl *h) {
 // (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
 int build_chunks(pam_amd_awfl *h) {
   (void)hipStreamSynchronize(h->stream);
-  for (auto &c : h->chunks) if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
+  for (auto &c : h->chunks) {
+    if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
+    if (c.fstream && c.fstream != h->stream) (void)hipStreamSynchronize(c.fstream);
+  }
   destroy_chunks(h);
   const int nens = h->P.nens;
   int n = h->chunks_requested;
@@ -382,11 +391,16 @@ int build_chunks(pam_amd_awfl *h) {
   }
   if (h->chunks.size() == 1) {
     h->chunks[0].stream = h->stream;
+    h->chunks[0].fstream = h->stream;
   } else {
+    int prio_low = 0, prio_high = 0;   // numerically lower = higher priority
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     for (auto &c : h->chunks) {
-      HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, h->use_priorities ? prio_high : prio_low));
+      HIP_TRY(hipStreamCreateWithPriority(&c.fstream, hipStreamNonBlocking, prio_low));
       HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c.flux_done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c.upd_done, hipEventDisableTiming));
     }
   }
   return PAM_AMD_OK;
@@ -515,7 +529,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
 int pam_amd_awfl_finalize(pam_amd_awfl_t *h) {
   if (!h) return PAM_AMD_OK;
   (void)hipStreamSynchronize(h->stream);
-  for (auto &c : h->chunks) if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
+  for (auto &c : h->chunks) {
+    if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
+    if (c.fstream && c.fstream != h->stream) (void)hipStreamSynchronize(c.fstream);
+  }
   for (auto &kv : h->timers) drain(kv.second);
   free_all(h);
   delete h;
@@ -631,21 +648,34 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     for (auto &c : h->chunks) HIP_TRY(hipStreamWaitEvent(c.stream, h->ev_fork, 0));
   }
   // Dycore.h:128-134 (per chunk)
-  for (auto &c : h->chunks)
+  for (auto &c : h->chunks) {
     if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
-  // Launches are issued stage by stage, round-robin over the chunks.  With several chunks the flux kernels are chained
-  // across chunks by events (A1 -> B1 -> A2 -> B2 ...): two VALU-bound flux kernels never share the chip, and a chunk's
-  // HBM-bound FCT/update kernels run beside the NEXT chunk's flux kernel instead of beside their own kind.
+    if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+  }
+  // Launches are issued stage by stage, round-robin over the chunks.  With several chunks:
+  //  * flux kernels run on each chunk's low-priority flux stream and are chained ACROSS chunks by events
+  //    (A1 -> B1 -> C1 -> A2 ...): two VALU-bound flux kernels never share the chip;
+  //  * a chunk's HBM-bound FCT/update kernels run on its high-priority stream beside the NEXT chunk's flux kernel.
   hipEvent_t prev_flux = nullptr;
   auto stage = [&](Chunk &c, int st, const double *pin, double *pout, double dt_stage) -> int {
     int r2;
-    if (forked && prev_flux) HIP_TRY(hipStreamWaitEvent(c.stream, prev_flux, 0));
-    if ((r2 = launch_flux(h, pin, c.r, c.stream))) return r2;
-    if (forked) { HIP_TRY(hipEventRecord(c.flux_done, c.stream)); prev_flux = c.flux_done; }
+    if (forked) {
+      HIP_TRY(hipStreamWaitEvent(c.fstream, c.upd_done, 0));               // this chunk's previous update / init
+      if (prev_flux) HIP_TRY(hipStreamWaitEvent(c.fstream, prev_flux, 0));  // the flux kernel launched just before
+    }
+    if ((r2 = launch_flux(h, pin, c.r, c.fstream))) return r2;
+    if (forked) {
+      HIP_TRY(hipEventRecord(c.flux_done, c.fstream));
+      prev_flux = c.flux_done;
+      HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
+    }
     if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
-    if (st == 1) return launch_update<1>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
-    if (st == 2) return launch_update<2>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
-    return launch_update<3>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    if (st == 1) r2 = launch_update<1>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    else if (st == 2) r2 = launch_update<2>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    else r2 = launch_update<3>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    if (r2) return r2;
+    if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+    return PAM_AMD_OK;
   };
   for (int ic = 0; ic < ncycles; ic++) {
     for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
@@ -711,6 +741,7 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
     return fail(PAM_AMD_EINVAL, "set_ensemble_chunks: flux_lds_floor_bytes must be in [0, 163840]");
   h->chunks_requested = chunks;
   h->flux_lds_floor = (size_t)flux_lds_floor_bytes;
+  if (const char *e = getenv("PAMA_NO_PRIO")) h->use_priorities = (atoi(e) == 0);   // experiment switch
   return build_chunks(h);
 }
 
