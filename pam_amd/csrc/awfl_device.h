@@ -355,7 +355,6 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       }
       double prevR_m = first ? 0.0 : carry[0 * nthr + tid];
       double prevR_p = first ? 0.0 : carry[1 * nthr + tid];
-#pragma unroll 2
       for (; c < flast; c++) {
         long long on = cell_off(c + 3);                    // prefetch the next cell entering the window
         double nm = pr[on] * pn[on], np_ = pp[on];
@@ -399,7 +398,6 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 #pragma unroll
       for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
       double prevR = first ? 0.0 : carry[(2 + a) * nthr + tid];
-#pragma unroll 2
       for (; c < flast; c++) {
         double nq = q[cell_off(c + 3)];
         double L, R;
