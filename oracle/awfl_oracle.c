@@ -535,6 +535,7 @@ void awfl_oracle_compute_tendencies(const awfl_oracle_t *o, double *state, doubl
 
   double *pressure = alloc_nan(awfl_oracle_halo_elems(o));
   /* Dycore.h:310-321 */
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
     for (int e = 0; e < nens; e++) {
       if (grav_balance) {
@@ -561,7 +562,7 @@ void awfl_oracle_compute_tendencies(const awfl_oracle_t *o, double *state, doubl
   double *tfz = alloc_nan((size_t)nt * (nz + 1) * ny * nx * nens);
 
   /* Dycore.h:334-519 */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
   for (int k = 0; k < nz + 1; k++) for (int j = 0; j < ny + 1; j++) for (int i = 0; i < nx + 1; i++)
     for (int e = 0; e < nens; e++) {
       const double cs = 350;
@@ -713,6 +714,7 @@ void awfl_oracle_compute_tendencies(const awfl_oracle_t *o, double *state, doubl
     }
 
   /* Dycore.h:553-584 */
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
     for (int e = 0; e < nens; e++) {
       for (int l = 0; l < NUM_STATE; l++) {
