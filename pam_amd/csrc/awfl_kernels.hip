@@ -43,6 +43,7 @@ struct FluxGrid {
   int spx, spy, spz;        // faces per thread (span) per sweep
   int nsx, nsy, nsz;        // spans per line
   long long nux, nuy, nuz;  // work units (wavefronts) per sweep
+  int nbx_l, nby_l;         // x / y workgroups per vertical level when the two sweeps are interleaved level by level (else 0)
 };
 
 template <bool VZ_PER_ENS>
@@ -55,6 +56,13 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
+  // x- and y-sweeps read the same horizontal slab of the state: when their workgroups tile the levels evenly they are
+  // interleaved level by level, so that the second sweep of a level finds the slab in the Infinity Cache.
+  if (G.nbx_l > 0 && b < G.nbx + G.nby) {
+    const int per = G.nbx_l + G.nby_l;
+    const int lev = b / per, r = b % per;
+    b = (r < G.nbx_l) ? lev * G.nbx_l + r : G.nbx + lev * G.nby_l + (r - G.nbx_l);
+  }
   if (b < G.nbx) {
     const long long u = (long long)b * 4 + wave;
     const long long item = (u / G.nsx) * 64 + lane;
@@ -190,6 +198,7 @@ struct pam_amd_awfl {
   int span_override = 0;       // 0: automatic flux-kernel span
   int chunks_requested = 0;    // 0: automatic
   bool use_priorities = true;
+  bool interleave_xy = true;
   size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
@@ -307,6 +316,11 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) 
   G.nuy = P.sim2d ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
   G.nuz = (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz;
   G.nbx = (int)((G.nux + 3) / 4); G.nby = (int)((G.nuy + 3) / 4); G.nbz = (int)((G.nuz + 3) / 4);
+  G.nbx_l = G.nby_l = 0;
+  if (h->interleave_xy && !P.sim2d && G.nux % (4LL * P.nz) == 0 && G.nuy % (4LL * P.nz) == 0) {
+    G.nbx_l = G.nbx / P.nz;
+    G.nby_l = G.nby / P.nz;
+  }
   // per-thread LDS: 2*seg face slots + one carried edge value per swept quantity (2 acoustic + 4+NT advected)
   size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
   if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
