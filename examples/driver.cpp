@@ -1,0 +1,77 @@
+// examples/driver.cpp -- a small C++ host driver over the plug-in surface, mirroring the call sequence of the
+// reference's standalone/mmf_simplified/driver.cpp (:120-191 set-up, :237-272 time loop) for the dycore alone:
+//
+//   coupler.allocate_coupler_state -> set_grid -> [micro.init: tracer registration + constants] -> dycore.init
+//   -> (host model fills the coupler fields) -> dycore.declare_current_profile_as_hydrostatic
+//   -> N x coupler.run_module("dycore", dycore.timeStep) -> output
+//
+// Input/output are raw little-endian fp64 files written/read by tests/test_cpp_driver.py (the reference reads YAML and
+// writes netCDF; neither library exists in this image and I/O is out of scope):
+//   header (8 x int64): nens nx ny nz num_tracers nsteps mode_a has_consts ; then xlen ylen crm_dt (3 x f64),
+//   6 constants (R_d cp_d R_v cp_v p0 grav), zint (nz+1), tracer flags (num_tracers x 2 bytes positive/adds_mass,
+//   then idWV int64), then density_dry,uvel,vvel,wvel,temp,(tracers...) each nz*ny*nx*nens f64.
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+
+#include "dynamics/awfl_amd/Dycore.h"
+
+static void die(const char *m) { std::fprintf(stderr, "driver: %s\n", m); std::exit(2); }
+
+int main(int argc, char **argv) {
+  if (argc != 3) die("usage: driver <input.bin> <output.bin>");
+  std::ifstream in(argv[1], std::ios::binary);
+  if (!in) die("cannot open input");
+  int64_t hdr[8];
+  in.read((char *)hdr, sizeof(hdr));
+  const int nens = hdr[0], nx = hdr[1], ny = hdr[2], nz = hdr[3], nt = hdr[4], nsteps = hdr[5];
+  const bool mode_a = hdr[6] != 0;
+  double geo[3], consts[6];
+  in.read((char *)geo, sizeof(geo));
+  in.read((char *)consts, sizeof(consts));
+  std::vector<real> zint(nz + 1);
+  in.read((char *)zint.data(), zint.size() * sizeof(real));
+  std::vector<unsigned char> flags(2 * nt);
+  in.read((char *)flags.data(), flags.size());
+  int64_t idWV;
+  in.read((char *)&idWV, sizeof(idWV));
+  const size_t ncell = (size_t)nz * ny * nx * nens;
+  try {
+    pam::PamCoupler coupler;
+    coupler.set_option<real>("crm_dt", geo[2]);
+    coupler.allocate_coupler_state(nz, ny, nx, nens);                       // driver.cpp:177
+    coupler.set_grid(geo[0], geo[1], zint);                                 // driver.cpp:180
+    // what micro.init()/sgs.init() do for the dycore: constants + tracer registration, BEFORE dycore.init (driver.cpp:189-191)
+    const char *cn[6] = {"R_d", "cp_d", "R_v", "cp_v", "p0", "grav"};
+    if (hdr[7]) for (int i = 0; i < 6; i++) coupler.set_option<real>(cn[i], consts[i]);
+    for (int t = 0; t < nt; t++)
+      coupler.add_tracer(t == idWV ? "water_vapor" : "tracer_" + std::to_string(t), "", flags[2 * t] != 0, flags[2 * t + 1] != 0);
+    Dycore dycore;
+    dycore.init(coupler);                                                    // driver.cpp:191
+    std::printf("Dycore: %s\n", dycore.dycore_name());                       // driver.cpp:203
+    auto &dm = coupler.get_data_manager_device_readwrite();
+    std::vector<real> buf(ncell);
+    std::vector<std::string> names = {"density_dry", "uvel", "vvel", "wvel", "temp"};
+    for (auto &n : coupler.get_tracer_names()) names.push_back(n);
+    for (auto &n : names) {
+      in.read((char *)buf.data(), ncell * sizeof(real));
+      if (!in) die("short input file");
+      if (hipMemcpy(dm.get<real, 4>(n).data(), buf.data(), ncell * sizeof(real), hipMemcpyHostToDevice) != hipSuccess) die("memcpy");
+    }
+    if (!mode_a) coupler.set_option<bool>("balance_hydrostasis_with_gravity", false);   // after init(), SURVEY 8c
+    dycore.declare_current_profile_as_hydrostatic(coupler);                  // the host model does this once per GCM step
+    for (int s = 0; s < nsteps; s++)
+      coupler.run_module("dycore", [&](pam::PamCoupler &c) { dycore.timeStep(c); });    // driver.cpp:248
+    if (hipDeviceSynchronize() != hipSuccess) die("device error");
+    std::ofstream out(argv[2], std::ios::binary);
+    for (auto &n : names) {
+      if (hipMemcpy(buf.data(), dm.get<real, 4>(n).data(), ncell * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) die("memcpy");
+      out.write((char *)buf.data(), ncell * sizeof(real));
+    }
+    dycore.finalize(coupler);                                                // driver.cpp:285
+  } catch (std::string &msg) {
+    std::fprintf(stderr, "driver: endrun: %s\n", msg.c_str());
+    return 1;
+  }
+  return 0;
+}

@@ -186,6 +186,7 @@ struct pam_amd_awfl {
   pam_amd_awfl_config_t cfg;
   Params P;
   hipStream_t stream = nullptr;
+  int device = 0;               // HIP device the handle was created on (every entry point re-selects it)
   // options (Dycore.h:871-891)
   double R_d, cp_d, R_v, cp_v, p0, grav, cv_d, gamma_d, kappa_d, cv_v, C0;
   // device buffers
@@ -437,6 +438,13 @@ void free_all(pam_amd_awfl *h) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// every entry point that touches the GPU runs on the handle's device, whatever the caller's current device is
+#define USE_DEVICE(h)                                                                  \
+  do {                                                                                 \
+    int _cur = -1;                                                                     \
+    if (hipGetDevice(&_cur) != hipSuccess || _cur != (h)->device) HIP_TRY(hipSetDevice((h)->device)); \
+  } while (0)
+
 extern "C" {
 
 int pam_amd_awfl_abi_version(void) { return PAM_AMD_AWFL_ABI_VERSION; }
@@ -459,6 +467,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
 
   pam_amd_awfl *h = new pam_amd_awfl();
   h->cfg = *cfg;
+  if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(PAM_AMD_ENOGPU, "init: hipGetDevice failed"); }
   h->stream = (hipStream_t)cfg->stream;
   auto opt = [](double v, double dflt) { return std::isnan(v) ? dflt : v; };
   h->R_d = opt(cfg->R_d, 287.);   h->cp_d = opt(cfg->cp_d, 1003.);
@@ -542,6 +551,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
 
 int pam_amd_awfl_finalize(pam_amd_awfl_t *h) {
   if (!h) return PAM_AMD_OK;
+  USE_DEVICE(h);
   (void)hipStreamSynchronize(h->stream);
   for (auto &c : h->chunks) {
     if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
@@ -602,6 +612,7 @@ int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_
 int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields,
                                                         const pam_amd_awfl_gcm_columns_t *gcm) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
   int rc = launch_init_prim(h, fields, gcm, /*subtract_hy=*/false, full_range(h->P), h->stream);
   if (rc) return rc;
   {
@@ -621,16 +632,19 @@ int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const
 
 int pam_amd_awfl_compute_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double cfl, double *dt) {
   if (!h || !dt) return fail(PAM_AMD_EINVAL, "compute_time_step: null argument");
+  USE_DEVICE(h);
   return local_time_step(h, fields, cfl, dt);
 }
 
 int pam_amd_awfl_convert_coupler_to_dynamics(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
   return launch_init_prim(h, fields, nullptr, !h->P.grav_balance, full_range(h->P), h->stream);
 }
 
 int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
   return launch_finalize(h, fields, full_range(h->P), h->stream);
 }
 
@@ -638,6 +652,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
                            int *ncycles_out, double *dt_dyn_out) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (!(crm_dt > 0)) return fail(PAM_AMD_EINVAL, "time_step: option crm_dt must be positive");
+  USE_DEVICE(h);
   if (!h->hydro_declared)
     return fail(PAM_AMD_ESTATE, "time_step: declare_current_profile_as_hydrostatic has not been called since init / "
                                 "since the balance option changed (variable_gravity / hy_* are undefined, SURVEY F4)");
@@ -753,6 +768,7 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
   if (chunks < 0 || chunks > 16) return fail(PAM_AMD_EINVAL, "set_ensemble_chunks: chunks must be in [0,16] (0 = automatic)");
   if (flux_lds_floor_bytes < 0 || flux_lds_floor_bytes > 160 * 1024)
     return fail(PAM_AMD_EINVAL, "set_ensemble_chunks: flux_lds_floor_bytes must be in [0, 163840]");
+  USE_DEVICE(h);
   h->chunks_requested = chunks;
   h->flux_lds_floor = (size_t)flux_lds_floor_bytes;
   if (const char *e = getenv("PAMA_NO_PRIO")) h->use_priorities = (atoi(e) == 0);   // experiment switch
@@ -775,6 +791,7 @@ int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **
 
 int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
   int rc;
   if ((rc = launch_flux(h, h->prim0, full_range(h->P), h->stream))) return rc;
   return launch_fct(h, dt, full_range(h->P), h->stream);

@@ -1,0 +1,66 @@
+"""The C++ host side above the C ABI (pam_amd/csrc/host: minimal pam::PamCoupler work-alike + the plug-in class
+dynamics/awfl_amd/Dycore.h) driven by examples/driver.cpp, which mirrors the reference driver's call sequence
+(standalone/mmf_simplified/driver.cpp:120-191,237-272).  The binary is built by __graft_entry__.build()."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from pam_amd import idealized as idz
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "examples", "driver")
+
+
+def test_driver_sources_use_only_reference_member_names():
+    """CPU-side sanity: the adaptor header calls nothing on the coupler that the reference's coupler lacks."""
+    text = open(os.path.join(ROOT, "pam_amd", "csrc", "host", "dynamics", "awfl_amd", "Dycore.h")).read()
+    for member in ("get_tracer_names", "get_tracer_info", "get_data_manager_device_readwrite", "option_exists",
+                   "get_option<real>", "set_option<bool>", "register_existing<real>", "get<real, 4>", "get<real const, 2>"):
+        assert member in text
+    for method in ("void init(", "void timeStep(", "real compute_time_step(", "void declare_current_profile_as_hydrostatic(",
+                   "void convert_coupler_to_dynamics(", "void convert_dynamics_to_coupler(", "char const *dycore_name(",
+                   "void finalize("):
+        assert method in text, method
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode_a", [True, False])
+def test_cpp_driver_matches_oracle(tmp_path, mode_a):
+    from oracle import awfl_oracle as ao
+    assert os.path.exists(DRIVER), "examples/driver missing: run __graft_entry__.build()"
+    nens, nx, ny, nz, nsteps, crm_dt = 5, 7, 4, 9, 2, 2.0
+    tr = idz.TRACERS_KESSLER_SHOC
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    xlen, ylen = nx * 500.0, ny * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    c = idz.CONSTS_DEFAULT
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as fh:
+        fh.write(struct.pack("<8q", nens, nx, ny, nz, len(tr), nsteps, int(mode_a), 1))
+        fh.write(struct.pack("<3d", xlen, ylen, crm_dt))
+        fh.write(struct.pack("<6d", c["R_d"], c["cp_d"], c["R_v"], c["cp_v"], c["p0"], c["grav"]))
+        fh.write(np.asarray(zint, dtype="<f8").tobytes())
+        fh.write(bytes(bytearray(v for t in range(len(tr)) for v in (int(pos[t]), int(mass[t])))))
+        fh.write(struct.pack("<q", idwv))
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            fh.write(f[k].astype("<f8").tobytes())
+        for t in range(len(tr)):
+            fh.write(f["tracers"][t].astype("<f8").tobytes())
+    r = subprocess.run([DRIVER, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "SSPRK3+WENO+FV A-grid" in r.stdout
+    raw = np.fromfile(outp, dtype="<f8").reshape(5 + len(tr), nz, ny, nx, nens)
+    o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), pos, mass, idwv)
+    o.set_grav_balance(mode_a)
+    o.declare_current_profile_as_hydrostatic(f)
+    for _ in range(nsteps):
+        o.time_step(f, crm_dt)
+    exp = [f["density_dry"], f["uvel"], f["vvel"], f["wvel"], f["temp"]] + [f["tracers"][t] for t in range(len(tr))]
+    for i, e in enumerate(exp):
+        tol = 1e-12 if i in (0, 4, 5 + idwv) else 1e-9
+        assert np.abs(raw[i] - e).max() <= tol * max(np.abs(e).max(), 1e-300), i
