@@ -325,6 +325,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) 
   // per-thread LDS: 2*seg face slots + one carried edge value per swept quantity (2 acoustic + 4+NT advected)
   size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
   if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
+  if (lds_bytes > 160 * 1024) return fail(PAM_AMD_EINVAL, "flux kernel: chunk length x tracer count exceeds the 160 KiB LDS of a CU");
   ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
     hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
@@ -542,6 +543,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMemset(h->hy_pres, 0xFF, nzn * 8));
   P.dz = h->dz; P.grav_var = h->grav_var; P.hy_dens = h->hy_dens; P.hy_pres = h->hy_pres; P.vz = h->vz;
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap, or many tracers: one carry
+  // slot per tracer per thread -> 144 KiB at the reference's maximum of 50 tracers)
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 64 * 1024;   // with >1 chunk: at most 2 flux workgroups per CU, leaving wave slots for update blocks
   if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }

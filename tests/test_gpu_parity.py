@@ -79,6 +79,12 @@ CASES = {
                     dict(supercell=False, crm_dt=1.0), True, 3),
     # ragged sizes: nens not a multiple of 64 but > 64, line lengths not multiples of the segment
     "3d_ragged_nens70": (70, 5, 3, 7, idz.TRACERS_NONE, idz.stretched_interfaces(7, 9000.0), {}, True, 1),
+    # smallest legal grid: one member, 3 cells per direction (the periodic stencil wraps the whole line twice)
+    "3d_minimal_1x3x3x3": (1, 3, 3, 3, idz.TRACERS_NONE, idz.uniform_interfaces(3, 3000.0), {}, True, 2),
+    # the reference's maximum tracer count (pam_const.h:24 max_fields = 50): water_vapor + 49 more, mixed flags
+    "2d_nt50_max_tracers": (2, 6, 1, 6, [("t%02d" % i, i % 3 != 0, i % 4 == 0) for i in range(20)] +
+                            [("water_vapor", True, True)] + [("u%02d" % i, i % 2 == 0, False) for i in range(29)],
+                            idz.stretched_interfaces(6, 9000.0), {}, True, 1),
 }
 
 
