@@ -397,7 +397,19 @@ int build_chunks(pam_amd_awfl *h) {
   destroy_chunks(h);
   const int nens = h->P.nens;
   int n = h->chunks_requested;
-  if (n <= 0) n = (nens >= 512) ? 3 : (nens >= 256 ? 2 : 1);   // automatic (measured on C2: 1 -> 1.52, 2 -> 1.65, 3 -> 1.66 G/s)
+  if (n <= 0) {
+    // automatic: chunking only pays when every chunk's flux launch still fills the chip.  W = wavefronts of one whole-
+    // ensemble flux launch.  Measured: C2 (W=87k) 1/2/3 chunks -> 1.52/1.65/1.66 G/s; C3 (W=14k) 1.27/1.29/1.16;
+    // C4 (W=4k) 0.60/0.57/0.45.
+    const Params &P = h->P;
+    int sp, ns;
+    long long ux, uy, uz;
+    choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, sp, ns, ux);
+    choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, sp, ns, uy);
+    choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, sp, ns, uz);
+    const long long W = ux + (P.sim2d ? 0 : uy) + uz;
+    n = (W >= 48000) ? 3 : (W >= 12000 ? 2 : 1);
+  }
   const int per = (((nens + n - 1) / n + 63) / 64) * 64;
   for (int e0 = 0; e0 < nens; e0 += per) {
     Chunk c;
