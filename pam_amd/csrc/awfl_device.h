@@ -620,6 +620,7 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   const long long o = (long long)(k + HS) * P.sz + c2;
   const long long ke = (long long)k * P.nens + e;
   const double dzk = P.dz[ke];
+  const double rdzk = fast_rcp(dzk);
   const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
   const long long im1 = idx + ((i == 0) ? (long long)(P.nx - 1) * P.sx : -P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
@@ -631,9 +632,11 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 #pragma unroll
   for (int l = 0; l < 5; l++) {
     const double *sx_ = fx + (long long)l * P.ncell, *sy_ = fy + (long long)l * P.ncell, *sz_ = fz + (long long)l * P.fz_fs;
-    double tend = -(sx_[ip1] - sx_[idx]) / P.dx;
-    if (!P.sim2d) tend = tend - (sy_[jp1] - sy_[idx]) / P.dy;
-    tend = tend - (sz_[idx + P.sz] - sz_[idx]) / dzk;
+    // reciprocal multiplies instead of the reference's divisions (<= 1 ulp per term): the kernel co-runs with the
+    // FP64-bound flux kernel of another ensemble chunk, so its VALU work is not free
+    double tend = -(sx_[ip1] - sx_[idx]) * P.rdx;
+    if (!P.sim2d) tend = tend - (sy_[jp1] - sy_[idx]) * P.rdy;
+    tend = tend - (sz_[idx + P.sz] - sz_[idx]) * rdzk;
     if (l == 3) {
       if (P.grav_balance) tend += -P.grav_var[ke] * rho_in;
       else tend += -P.grav * (rho_in - P.hy_dens[ke]);
@@ -659,16 +662,16 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
     const double m_c = mt[idx];
     double f_x = limited_flux(tx[idx], mt[im1], m_c, i == 0);
     double f_xp1 = limited_flux(tx[ip1], m_c, mt[ip1], i == P.nx - 1);
-    double tend = -(f_xp1 - f_x) / P.dx;
+    double tend = -(f_xp1 - f_x) * P.rdx;
     if (!P.sim2d) {
       double f_y = limited_flux(ty[idx], mt[jm1], m_c, j == 0);
       double f_yp1 = limited_flux(ty[jp1], m_c, mt[jp1], j == P.ny - 1);
-      tend = tend - (f_yp1 - f_y) / P.dy;
+      tend = tend - (f_yp1 - f_y) * P.rdy;
     }
     // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
     double f_z = limited_flux(tz[idx], (k > 0) ? mt[idx - P.sz] : 1.0, m_c, false);
     double f_zp1 = limited_flux(tz[idx + P.sz], m_c, (k < P.nz - 1) ? mt[idx + P.sz] : 1.0, false);
-    tend = tend - (f_zp1 - f_z) / dzk;
+    tend = tend - (f_zp1 - f_z) * rdzk;
     const int pf = P_TR0 + t;
     const double m_in = prim_in[pf * P.prim_fs + o] * rho_in;
     double m_0 = 0.0;
