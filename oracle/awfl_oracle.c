@@ -893,3 +893,34 @@ int awfl_oracle_time_step(awfl_oracle_t *o, double *rho_d_c, double *u_c, double
   free(state); free(tracers);
   return ncycles;
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* modules::sponge_layer (pam_core/modules/sponge_layer.h:8-95), "next row" N2 of SURVEY.md section 8f.
+ * fields: num_fields pointers to (nz,ny,nx,nens) arrays in the reference's order density_dry, uvel, vvel, wvel, temp,
+ * tracers...; zint (nz+1,nens), zmid (nz,nens).  The horizontal means are accumulated in the reference's serial
+ * atomicAdd order (j outer, i inner); field index 3 (wvel) relaxes towards zero (:34, :76). */
+void awfl_oracle_sponge_layer(int nens, int nx, int ny, int nz, int num_fields, double *const *fields, const double *zint,
+                              const double *zmid, double dt, int num_layers, double time_scale) {
+  const int WFLD = 3;
+  const double r_nx_ny = 1.0 / (nx * ny);
+  double *havg = (double *)calloc((size_t)num_fields * nz * nens, sizeof(double));
+  for (int ifld = 0; ifld < num_fields; ifld++)
+    for (int kloc = 0; kloc < num_layers; kloc++)
+      for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+        int k = nz - 1 - kloc;
+        if (ifld != WFLD) havg[((size_t)ifld * nz + k) * nens + e] += fields[ifld][C4(k, j, i, e)] * r_nx_ny;
+      }
+  const double time_factor = dt / time_scale;
+  for (int ifld = 0; ifld < num_fields; ifld++)
+    for (int kloc = 0; kloc < num_layers; kloc++)
+      for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+        int k = nz - 1 - kloc;
+        double rel_dist = (zint[(size_t)nz * nens + e] - zmid[(size_t)k * nens + e]) /
+                          (zint[(size_t)nz * nens + e] - zmid[(size_t)(nz - 1 - (num_layers - 1)) * nens + e]);
+        double space_factor = (cos(M_PI * rel_dist) + 1) / 2;
+        double factor = space_factor * time_factor;
+        double *f = fields[ifld];
+        f[C4(k, j, i, e)] += (havg[((size_t)ifld * nz + k) * nens + e] - f[C4(k, j, i, e)]) * factor;
+      }
+  free(havg);
+}

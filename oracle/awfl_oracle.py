@@ -61,6 +61,7 @@ def load(path=None):
     lib.awfl_oracle_convert_dynamics_to_coupler.argtypes = [C.c_void_p] + [_DP] * 8
     lib.awfl_oracle_compute_tendencies.argtypes = [C.c_void_p] + [_DP] * 4 + [C.c_double]
     lib.awfl_oracle_set_flux_taps.argtypes = [C.c_void_p, _DP, _DP, _DP]
+    lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
     if path is None:
         _LIB = lib
     return lib
@@ -208,3 +209,18 @@ class OracleDycore:
             self.lib.awfl_oracle_set_flux_taps(self.h, None, None, None)
             return st, tt, fl
         return st, tt
+
+
+def sponge_layer(fields, zint, zmid, dt, num_layers=5, time_scale=60.0, lib=None):
+    """modules::sponge_layer on numpy coupler fields (dict as for OracleDycore), updated in place.
+    zint (nz+1,nens), zmid (nz,nens)."""
+    lib = lib or load()
+    nz, ny, nx, nens = fields["density_dry"].shape
+    arrs = [fields[k] for k in ("density_dry", "uvel", "vvel", "wvel", "temp")] + \
+           [fields["tracers"][t] for t in range(fields["tracers"].shape[0])]
+    for a in arrs:
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == np.float64
+    ptrs = (_DP * len(arrs))(*[_p(a) for a in arrs])
+    zi = np.ascontiguousarray(zint, dtype=np.float64)
+    zm = np.ascontiguousarray(zmid, dtype=np.float64)
+    lib.awfl_oracle_sponge_layer(nens, nx, ny, nz, len(arrs), ptrs, _p(zi), _p(zm), float(dt), int(num_layers), float(time_scale))

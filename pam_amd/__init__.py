@@ -7,3 +7,4 @@ from .capi import PamAmdError, LIB_PATH  # noqa: F401
 from .coupler import PamCoupler, DataManager, Options  # noqa: F401
 from .dycore import Dycore  # noqa: F401
 from . import parallel  # noqa: F401
+from . import modules  # noqa: F401

@@ -59,6 +59,12 @@ SYMBOLS = {
     "pam_amd_awfl_debug_flux_stage": (C.c_int, [C.c_void_p, C.c_double]),
 }
 
+# include/pam_amd_modules.h
+MODULE_SYMBOLS = {
+    "pam_amd_sponge_layer": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                       C.c_double, C.c_void_p, C.c_void_p]),
+}
+
 
 class PamAmdError(RuntimeError):
     """Raised where the reference would call endrun() (pam_core/pam_const.h:249-252)."""
@@ -72,7 +78,7 @@ def load():
         raise PamAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  pam_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(MODULE_SYMBOLS.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args

@@ -458,6 +458,9 @@ void free_all(pam_amd_awfl *h) {
     if (hipGetDevice(&_cur) != hipSuccess || _cur != (h)->device) HIP_TRY(hipSetDevice((h)->device)); \
   } while (0)
 
+// shared with the other translation units of the library (modules_kernels.hip)
+extern "C" int pam_amd_set_last_error_(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
 extern "C" {
 
 int pam_amd_awfl_abi_version(void) { return PAM_AMD_AWFL_ABI_VERSION; }

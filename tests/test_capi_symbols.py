@@ -12,10 +12,10 @@ from pam_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "pam_amd_awfl.h")).read()
+def _header_symbols(header="pam_amd_awfl.h", prefix="pam_amd_awfl_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b(pam_amd_awfl_\w+)\s*\(", text))
+    return set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text))
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/pam_amd_awfl.h but not exported"
     assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
     assert lib.pam_amd_awfl_abi_version() == 1
+    mods = _header_symbols("pam_amd_modules.h", "pam_amd_")
+    assert mods == set(capi.MODULE_SYMBOLS) and all(hasattr(lib, n) for n in mods)
+
+
+def test_sponge_layer_rejects_bad_arguments():
+    lib = capi.load()
+    assert lib.pam_amd_sponge_layer(2, 4, 1, 8, 6, None, None, None, 1.0, 5, 60.0, None, None) == -1
+    assert b"sponge_layer" in lib.pam_amd_awfl_last_error()
 
 
 def _cfg(**kw):
