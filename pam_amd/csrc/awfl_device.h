@@ -462,6 +462,11 @@ PAMA_D void store_rho_pres(const Params &P, double *prim, int k, long long c2, i
   }
 }
 
+// A cell and its flattened index (nens fastest).  The pointwise kernels get k and j from the launch grid and split only
+// (i, member) per thread with one 32-bit division: a 64-bit div/mod decomposition of the flat index costs several
+// hundred VALU instructions per thread, which matters because these kernels co-run with the FP64-bound flux kernel.
+struct CellId { int k, j, i, e; long long idx; };
+
 // decompose a flattened cell index (nens fastest) -> k, j, i, e
 PAMA_D void cell_coords(const Params &P, long long idx, int &k, int &j, int &i, int &e) {
   e = (int)(idx % P.nens);
@@ -470,6 +475,12 @@ PAMA_D void cell_coords(const Params &P, long long idx, int &k, int &j, int &i, 
   j = (int)(r % P.ny);
   k = (int)(r / P.ny);
 }
+PAMA_D CellId cell_of(const Params &P, long long idx) {
+  CellId c;
+  cell_coords(P, idx, c.k, c.j, c.i, c.e);
+  c.idx = idx;
+  return c;
+}
 
 // Coupler fields -> prim (+ghosts) and seed.  Dycore.h:1370-1387, :130-134.
 // gcm != nullptr selects the use_gcm_data branch of declare_current_profile_as_hydrostatic (Dycore.h:1415-1434):
@@ -477,9 +488,9 @@ PAMA_D void cell_coords(const Params &P, long long idx, int &k, int &j, int &i, 
 PAMA_D void init_prim_body(const Params &P, const double *__restrict__ rho_d_c, const double *__restrict__ u_c,
                            const double *__restrict__ v_c, const double *__restrict__ w_c,
                            const double *__restrict__ temp_c, const TracerPtrs &trc, const double *const *gcm,
-                           double *__restrict__ prim, double *__restrict__ seed, bool subtract_hy, long long idx) {
-  int k, j, i, e;
-  cell_coords(P, idx, k, j, i, e);
+                           double *__restrict__ prim, double *__restrict__ seed, bool subtract_hy, const CellId &c) {
+  const int k = c.k, j = c.j, i = c.i, e = c.e;
+  const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
   double rho, ru, rv, rw, rt;
   if (gcm) {
@@ -520,9 +531,9 @@ PAMA_D void init_prim_body(const Params &P, const double *__restrict__ rho_d_c, 
 // prim + seed -> coupler fields.  Dycore.h:1313-1330.
 PAMA_D void finalize_body(const Params &P, const double *__restrict__ prim, const double *__restrict__ seed,
                           double *__restrict__ rho_d_c, double *__restrict__ u_c, double *__restrict__ v_c,
-                          double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc, long long idx) {
-  int k, j, i, e;
-  cell_coords(P, idx, k, j, i, e);
+                          double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc, const CellId &c) {
+  const int k = c.k, j = c.j, i = c.i, e = c.e;
+  const long long idx = c.idx;
   const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
   double rho = prim[P_RHO * P.prim_fs + o];
   double theta = prim[P_THETA * P.prim_fs + o];
@@ -561,9 +572,9 @@ PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, cons
 // FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
 PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const double *__restrict__ fy,
                           const double *__restrict__ fz, const double *__restrict__ seed, double *__restrict__ mult,
-                          double dt, long long idx) {
-  int k, j, i, e;
-  cell_coords(P, idx, k, j, i, e);
+                          double dt, const CellId &c) {
+  const int k = c.k, j = c.j, i = c.i, e = c.e;
+  const long long idx = c.idx;
   const double dzk = P.dz[(long long)k * P.nens + e];
   const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
@@ -613,9 +624,9 @@ template <int STAGE>
 PAMA_D void update_body(const Params &P, const double *prim_in, const double *prim0,
                         double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
                         const double *__restrict__ fz, const double *__restrict__ mult, double *__restrict__ seed,
-                        double dt_dyn, long long idx) {
-  int k, j, i, e;
-  cell_coords(P, idx, k, j, i, e);
+                        double dt_dyn, const CellId &c) {
+  const int k = c.k, j = c.j, i = c.i, e = c.e;
+  const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
   const long long o = (long long)(k + HS) * P.sz + c2;
   const long long ke = (long long)k * P.nens + e;

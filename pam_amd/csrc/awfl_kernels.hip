@@ -38,6 +38,20 @@ __device__ __forceinline__ long long to_global(long long t, int nens, EnsRange R
   return r * nens + R.e0 + (t - r * R.ne);
 }
 
+// Pointwise kernels: grid (ceil(nx*ne/256), ny, nz); k and j come from the block indices, (i, local member) from one
+// 32-bit division.
+__device__ __forceinline__ bool grid_cell(const Params &P, EnsRange R, CellId &c) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)P.nx * (unsigned)R.ne) return false;
+  const unsigned i = t / (unsigned)R.ne;
+  c.k = blockIdx.z; c.j = blockIdx.y; c.i = (int)i; c.e = R.e0 + (int)(t - i * (unsigned)R.ne);
+  c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
+  return true;
+}
+static inline dim3 cell_grid(const Params &P, EnsRange r) {
+  return dim3((unsigned)(((long long)P.nx * r.ne + 255) / 256), (unsigned)P.ny, (unsigned)P.nz);
+}
+
 struct FluxGrid {
   int nbx, nby, nbz;        // workgroups per sweep
   int spx, spy, spz;        // faces per thread (span) per sweep
@@ -88,8 +102,8 @@ __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, con
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
                                                        double dt) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long long)P.nz * P.ny * P.nx * R.ne) fct_mult_body(P, fx, fy, fz, seed, mult, dt, to_global(t, P.nens, R));
+  CellId c;
+  if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, dt, c);
 }
 
 template <int STAGE>
@@ -98,9 +112,8 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
                                                           const double *__restrict__ fx, const double *__restrict__ fy,
                                                           const double *__restrict__ fz, const double *__restrict__ mult,
                                                           double *__restrict__ seed, double dt_dyn) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long long)P.nz * P.ny * P.nx * R.ne)
-    update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, to_global(t, P.nens, R));
+  CellId c;
+  if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
 
 struct GcmPtrs { const double *p[5]; int use; };
@@ -110,9 +123,9 @@ __global__ void __launch_bounds__(256) awfl_init_prim_kernel(Params P, EnsRange 
                                                              const double *__restrict__ w, const double *__restrict__ temp,
                                                              TracerPtrs trc, GcmPtrs gcm, double *__restrict__ prim,
                                                              double *__restrict__ seed, int subtract_hy) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long long)P.nz * P.ny * P.nx * R.ne)
-    init_prim_body(P, rho_d, u, v, w, temp, trc, gcm.use ? gcm.p : nullptr, prim, seed, subtract_hy != 0, to_global(t, P.nens, R));
+  CellId c;
+  if (grid_cell(P, R, c))
+    init_prim_body(P, rho_d, u, v, w, temp, trc, gcm.use ? gcm.p : nullptr, prim, seed, subtract_hy != 0, c);
 }
 
 __global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, EnsRange R, const double *__restrict__ prim,
@@ -120,8 +133,8 @@ __global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, EnsRange R
                                                             double *__restrict__ u, double *__restrict__ v,
                                                             double *__restrict__ w, double *__restrict__ temp,
                                                             TracerPtrs trc) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (long long)P.nz * P.ny * P.nx * R.ne) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, to_global(t, P.nens, R));
+  CellId c;
+  if (grid_cell(P, R, c)) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, c);
 }
 
 // CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, one atomicMin per wavefront on the
@@ -271,7 +284,7 @@ int launch_init_prim(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, const pam_
     for (int i = 0; i < 5; i++) gp.p[i] = nullptr;
   }
   ScopedTimer st(h, "init_prim", s);
-  hipLaunchKernelGGL(awfl_init_prim_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r,
+  hipLaunchKernelGGL(awfl_init_prim_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r,
                      f->density_dry, f->uvel, f->vvel, f->wvel, f->temp, tp, gp, h->prim0, h->seed, subtract_hy ? 1 : 0);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
@@ -282,7 +295,7 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
   int rc = make_tracer_ptrs(h, f, tp);
   if (rc) return rc;
   ScopedTimer st(h, "finalize", s);
-  hipLaunchKernelGGL(awfl_finalize_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, h->prim0,
+  hipLaunchKernelGGL(awfl_finalize_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, h->prim0,
                      h->seed, f->density_dry, f->uvel, f->vvel, f->wvel, f->temp, tp);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
@@ -339,7 +352,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) 
 
 int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s) {
   ScopedTimer st(h, "fct_mult", s);
-  hipLaunchKernelGGL(awfl_fct_kernel, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
+  hipLaunchKernelGGL(awfl_fct_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
                      h->flux_z, h->seed, h->mult, dt);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
@@ -349,7 +362,7 @@ template <int STAGE>
 int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
                   hipStream_t s) {
   ScopedTimer st(h, "update", s);
-  hipLaunchKernelGGL(awfl_update_kernel<STAGE>, dim3(nblocks(ncell_of(h->P, r), 256)), dim3(256), 0, s, h->P, r, prim_in,
+  hipLaunchKernelGGL(awfl_update_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in,
                      prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;

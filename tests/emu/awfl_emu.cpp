@@ -60,13 +60,14 @@ static void flux_launch(Emu *h, const double *prim) {
 
 static void fct_launch(Emu *h, double dt) {
   for (long long idx = 0; idx < h->P.ncell; idx++)
-    fct_mult_body(h->P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), dt, idx);
+    fct_mult_body(h->P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), dt, cell_of(h->P, idx));
 }
 
 template <int STAGE>
 static void update_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   for (long long idx = 0; idx < h->P.ncell; idx++)
-    update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt, idx);
+    update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt,
+                       cell_of(h->P, idx));
 }
 
 static TracerPtrs tptrs(const Emu *h, double *tracers) {
@@ -137,7 +138,7 @@ static void init_prim(Emu *h, double *rho_d, double *u, double *v, double *w, do
                       const double *const *gcm, bool subtract_hy) {
   TracerPtrs tp = tptrs(h, tracers);
   for (long long idx = 0; idx < h->P.ncell; idx++)
-    init_prim_body(h->P, rho_d, u, v, w, T, tp, gcm, h->prim0.data(), h->seed.data(), subtract_hy, idx);
+    init_prim_body(h->P, rho_d, u, v, w, T, tp, gcm, h->prim0.data(), h->seed.data(), subtract_hy, cell_of(h->P, idx));
 }
 
 void emu_declare_hydrostatic(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers,
@@ -180,7 +181,7 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
   }
   TracerPtrs tp = tptrs(h, tracers);
-  for (long long idx = 0; idx < h->P.ncell; idx++) finalize_body(h->P, p0, h->seed.data(), rho_d, u, v, w, T, tp, idx);
+  for (long long idx = 0; idx < h->P.ncell; idx++) finalize_body(h->P, p0, h->seed.data(), rho_d, u, v, w, T, tp, cell_of(h->P, idx));
   return ncycles;
 }
 
