@@ -24,6 +24,7 @@ Extra objects on the JSON line:
                timed on this host on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import copy
 import json
 import os
 import sys
@@ -72,13 +73,14 @@ def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
     except Exception:
         pass
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
-    nens = 4 if ny > 1 else 32
+    nens = 16 if ny > 1 else 256
     f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tracers, magnitude=0.1)
     if len(tracers) > 1:
         idz.add_tracer_blobs(f, tracers, xlen, ylen, zint)
     o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), pos, mass, idwv, consts=consts, lib=lib)
     o.declare_current_profile_as_hydrostatic(f)
-    dt = 0.5 if ny > 1 else 1.0
+    dt = 1.0
+    o.time_step(copy.deepcopy(f), 0.2)      # warm-up (thread pool, page faults)
     t0 = time.time()
     ncyc, _ = o.time_step(f, dt)
     el = time.time() - t0

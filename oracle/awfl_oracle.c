@@ -230,6 +230,7 @@ void awfl_oracle_variable_matrices(const double locs[6], double s2c[25], double 
 static double *alloc_nan(size_t n) {
   double *p = (double *)malloc((n ? n : 1) * sizeof(double));
   if (!p) { fprintf(stderr, "awfl_oracle: out of memory (%zu doubles)\n", n); abort(); }
+#pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; i++) p[i] = NAN; /* poison: any stale read shows up as NaN */
   return p;
 }
@@ -353,6 +354,7 @@ void awfl_oracle_convert_coupler_to_dynamics(const awfl_oracle_t *o, const doubl
                                              const double *tracers_c, double *state, double *tracers) {
   const int nens = o->nens, nx = o->nx, ny = o->ny, nz = o->nz, nt = o->nt;
   const double R_d = o->R_d, R_v = o->R_v, gamma_d = o->gamma_d, C0 = o->C0;
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
     for (int e = 0; e < nens; e++) {
       double rho_d = rho_d_c[C4(k, j, i, e)];
@@ -378,6 +380,7 @@ void awfl_oracle_convert_dynamics_to_coupler(const awfl_oracle_t *o, const doubl
                                              double *temp_c, double *tracers_c) {
   const int nens = o->nens, nx = o->nx, ny = o->ny, nz = o->nz, nt = o->nt;
   const double R_d = o->R_d, R_v = o->R_v, gamma = o->gamma_d, C0 = o->C0;
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
     for (int e = 0; e < nens; e++) {
       double rho = state[H5(ID_R, HS + k, HS + j, HS + i, e)];
@@ -684,6 +687,7 @@ void awfl_oracle_compute_tendencies(const awfl_oracle_t *o, double *state, doubl
 
   /* Dycore.h:525-550: multiply rho back; FCT.  (Order-independent: a face is only ever scaled by the
    * one adjacent cell it flows out of, Dycore.h:521-524.) */
+#pragma omp parallel for schedule(static)
   for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
     for (int e = 0; e < nens; e++) {
       double r = state[H5(ID_R, HS + k, HS + j, HS + i, e)];
@@ -850,6 +854,7 @@ int awfl_oracle_time_step(awfl_oracle_t *o, double *rho_d_c, double *u_c, double
     for (int l = 0; l < nt; l++) for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++)
       for (int e = 0; e < nens; e++) tracers_tend[C5(l, k, j, i, e)] = tracers[H5(l, HS + k, HS + j, HS + i, e)];
     awfl_oracle_compute_tendencies(o, state, state_tend, tracers, tracers_tend, dt_dyn);
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
       for (int l = 0; l < NUM_STATE; l++)
         state_tmp[H5(l, HS + k, HS + j, HS + i, e)] = state[H5(l, HS + k, HS + j, HS + i, e)] + dt_dyn * state_tend[C5(l, k, j, i, e)];
@@ -862,6 +867,7 @@ int awfl_oracle_time_step(awfl_oracle_t *o, double *rho_d_c, double *u_c, double
     }
     /* stage 2, Dycore.h:180-200 */
     awfl_oracle_compute_tendencies(o, state_tmp, state_tend, tracers_tmp, tracers_tend, (1.0 / 4.0) * dt_dyn);
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
       for (int l = 0; l < NUM_STATE; l++) {
         size_t h = H5(l, HS + k, HS + j, HS + i, e);
@@ -876,6 +882,7 @@ int awfl_oracle_time_step(awfl_oracle_t *o, double *rho_d_c, double *u_c, double
     }
     /* stage 3, Dycore.h:204-221 */
     awfl_oracle_compute_tendencies(o, state_tmp, state_tend, tracers_tmp, tracers_tend, (2.0 / 3.0) * dt_dyn);
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
       for (int l = 0; l < NUM_STATE; l++) {
         size_t h = H5(l, HS + k, HS + j, HS + i, e);
