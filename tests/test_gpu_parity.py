@@ -251,3 +251,53 @@ def test_conservation_and_positivity_at_full_size_slice():
         assert torch.isfinite(t).all() and (t >= 0).all()
     assert torch.isfinite(coupler.dm.get("temp", readonly=True)).all()
     dycore.finalize(coupler)
+
+
+def test_full_baseline_size_c2_properties():
+    """BASELINE.json configs[1] at full size (nens=1024, 32x32x60 L60, NT=1; 63M cells, too large for the oracle):
+    size-independent properties.  (i) dry mass and vapour mass of every member conserved to 1e-10 per timeStep (the
+    reference's PAM_DEBUG invariant, Dycore.h:224-251); (ii) all fields finite, vapour non-negative; (iii) members that
+    start identical stay bit-identical (the inputs are 16 distinct members tiled 64 times: any cross-member leakage or
+    chunk-boundary error would break this); (iv) the automatic 3-chunk overlapped schedule equals the single-chunk one
+    bit for bit."""
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz, ngen = 1024, 32, 32, 60, 16
+    zint = idz.l60_interfaces()
+    f = idz.supercell_fields(ngen, nx, ny, nz, zint, magnitude=0.1)
+    results = []
+    for chunks in (0, 1):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 1.0)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        coupler.set_grid(nx * 1000.0, ny * 1000.0, zint)
+        coupler.add_tracer("water_vapor", "", True, True)
+        dycore = Dycore()
+        dycore.init(coupler)
+        dycore.set_ensemble_chunks(chunks)
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            coupler.dm.get(k).copy_(torch.from_numpy(f[k]).to("cuda:0").repeat(1, 1, 1, nens // ngen))
+        coupler.dm.get("water_vapor").copy_(torch.from_numpy(f["tracers"][0]).to("cuda:0").repeat(1, 1, 1, nens // ngen))
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+        dz = torch.from_numpy(np.diff(zint)).to("cuda:0")[:, None, None, None]
+        rho0 = ((coupler.dm.get("density_dry", readonly=True) + coupler.dm.get("water_vapor", readonly=True)) * dz).sum(dim=(0, 1, 2))
+        wv0 = (coupler.dm.get("water_vapor", readonly=True) * dz).sum(dim=(0, 1, 2))
+        n = dycore.timeStep(coupler)
+        torch.cuda.synchronize()
+        assert n >= 3
+        rho1 = ((coupler.dm.get("density_dry", readonly=True) + coupler.dm.get("water_vapor", readonly=True)) * dz).sum(dim=(0, 1, 2))
+        wv1 = (coupler.dm.get("water_vapor", readonly=True) * dz).sum(dim=(0, 1, 2))
+        assert torch.all((rho1 - rho0).abs() <= 1e-10 * rho0)
+        assert torch.all((wv1 - wv0).abs() <= 1e-10 * wv0)
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"):
+            t = coupler.dm.get(k, readonly=True)
+            assert torch.isfinite(t).all(), k
+            assert torch.equal(t[..., :ngen], t[..., nens - ngen:]), k           # tile 0 == tile 63
+            assert torch.equal(t[..., :ngen], t[..., 384:384 + ngen]), k          # across the chunk boundary at 384
+        assert (coupler.dm.get("water_vapor", readonly=True) >= 0).all()
+        results.append({k: coupler.dm.get(k, readonly=True)[..., ::37].clone() for k in ("density_dry", "wvel", "temp")})
+        dycore.finalize(coupler)
+        del coupler, dycore
+        torch.cuda.empty_cache()
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
