@@ -69,7 +69,10 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
+  // Dispatch order: the z-sweep workgroups first (a whole 61-face column per thread: the longest work items), then
+  // the x/y sweeps -- longest-first scheduling shortens the tail of the launch.
+  int b = (int)blockIdx.x - G.nbz;
+  if (b < 0) b += G.nbx + G.nby + G.nbz;      // blockIdx < nbz  ->  logical index in [nbx+nby, nbx+nby+nbz)
   // x- and y-sweeps read the same horizontal slab of the state: when their workgroups tile the levels evenly they are
   // interleaved level by level, so that the second sweep of a level finds the slab in the Infinity Cache.
   if (G.nbx_l > 0 && b < G.nbx + G.nby) {
