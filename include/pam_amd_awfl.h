@@ -69,6 +69,15 @@ const char *pam_amd_awfl_last_error(void);
  * sets option balance_hydrostasis_with_gravity = true (Dycore.h:866). */
 int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out);
 
+/* The optional idealised initial conditions of Dycore::init (Dycore.h:986-1090, compiled into the reference under
+ * PAM_STANDALONE): init_data is the value of the `initData` key of the YAML file named by option
+ * "standalone_input_file" -- "thermal" (Dycore.h:1021-1088), "supercell" (init_supercell, Dycore.h:1096-1276) or
+ * "external" (no-op); anything else is the reference's endrun("ERROR: Invalid data_spec").  Fills the coupler fields.
+ * vertical_midpoint_height (nz,nens) and vertical_interface_height (nz+1,nens) are the coupler entries of those names
+ * (DEVICE). */
+int pam_amd_awfl_init_idealized(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, const char *init_data,
+                                const double *vertical_midpoint_height, const double *vertical_interface_height);
+
 /* Dycore::finalize (Dycore.h:1548) + release of the handle. */
 int pam_amd_awfl_finalize(pam_amd_awfl_t *h);
 

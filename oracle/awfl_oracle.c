@@ -931,3 +931,189 @@ void awfl_oracle_sponge_layer(int nens, int nx, int ny, int nz, int num_fields, 
       }
   free(havg);
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Optional idealised initial conditions of Dycore::init (Dycore.h:986-1090: data_spec thermal / supercell).
+ * Both fill the halo'd dycore state and finish with convert_dynamics_to_coupler (Dycore.h:1089). */
+static double sample_ellipse_cosine(double amp, double x, double y, double z, double x0, double y0, double z0,
+                                    double xrad, double yrad, double zrad) { /* Dycore.h:753-766 */
+  double dist = sqrt(((x - x0) / xrad) * ((x - x0) / xrad) + ((y - y0) / yrad) * ((y - y0) / yrad) +
+                     ((z - z0) / zrad) * ((z - z0) / zrad)) * M_PI / 2.;
+  if (dist <= M_PI / 2.) return amp * pow(cos(dist), 2.0);
+  return 0.;
+}
+static void hydro_const_theta(double z, double grav, double C0, double cp, double p0, double gamma, double rd,
+                              double *r, double *t) { /* Dycore.h:739-748 */
+  const double theta0 = 300., exner0 = 1.;
+  *t = theta0;
+  double exner = exner0 - grav * z / (cp * theta0);
+  double p = p0 * pow(exner, (cp / rd));
+  double rt = pow((p / C0), (1.0 / gamma));
+  *r = rt / *t;
+}
+
+/* Dycore.h:1021-1088 (DATA_SPEC_THERMAL).  zmid (nz,nens). */
+void awfl_oracle_init_thermal(const awfl_oracle_t *o, const double *zmid, double *rho_d_c, double *u_c, double *v_c,
+                              double *w_c, double *temp_c, double *tracers_c) {
+  const int nens = o->nens, nx = o->nx, ny = o->ny, nz = o->nz, nt = o->nt;
+  const double dx = o->xlen / nx, dy = o->ylen / ny, xlen = o->xlen, ylen = o->ylen;
+  const int sim2d = (ny == 1);
+  const double qpoints[9] = AWFL_GLL9_PTS_INIT, qweights[9] = AWFL_GLL9_WTS_INIT;
+  size_t nh = awfl_oracle_halo_elems(o);
+  double *state = alloc_nan(NUM_STATE * nh), *tracers = alloc_nan((size_t)nt * nh);
+  double *hyd = alloc_nan((size_t)nz * nens), *hyp = alloc_nan((size_t)nz * nens);
+  for (int k = 0; k < nz; k++) for (int e = 0; e < nens; e++) {
+    hyd[(size_t)k * nens + e] = 0.; hyp[(size_t)k * nens + e] = 0.;
+    for (int kk = 0; kk < 9; kk++) {
+      double z = zmid[(size_t)k * nens + e] + qpoints[kk] * DZ(k, e), hr, ht;
+      hydro_const_theta(z, o->grav, o->C0, o->cp_d, o->p0, o->gamma_d, o->R_d, &hr, &ht);
+      hyd[(size_t)k * nens + e] += hr * qweights[kk];
+      hyp[(size_t)k * nens + e] += o->C0 * pow(hr * ht, o->gamma_d) * qweights[kk];
+    }
+  }
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    for (int l = 0; l < NUM_STATE; l++) state[H5(l, HS + k, HS + j, HS + i, e)] = 0.;
+    for (int l = 0; l < nt; l++) tracers[H5(l, HS + k, HS + j, HS + i, e)] = 0.;
+    for (int kk = 0; kk < 9; kk++) for (int jj = 0; jj < 9; jj++) for (int ii = 0; ii < 9; ii++) {
+      double x = (i + 0.5) * dx + qpoints[ii] * dx;
+      double y = (j + 0.5) * dy + qpoints[jj] * dy; if (sim2d) y = ylen / 2;
+      double z = zmid[(size_t)k * nens + e] + qpoints[kk] * DZ(k, e);
+      double hr = hyd[(size_t)k * nens + e], hp = hyp[(size_t)k * nens + e];
+      double ht = pow(hp / o->C0, 1.0 / o->gamma_d) / hr;
+      double rho = hr, u = 0, v = 0, w = 0, rho_v = 0;
+      double theta = ht + sample_ellipse_cosine(2.0, x, y, z, xlen / 2, ylen / 2, 2000., 2000., 2000., 2000.);
+      if (sim2d) v = 0;
+      double wt = qweights[ii] * qweights[jj] * qweights[kk];
+      state[H5(ID_R, HS + k, HS + j, HS + i, e)] += rho * wt;
+      state[H5(ID_U, HS + k, HS + j, HS + i, e)] += rho * u * wt;
+      state[H5(ID_V, HS + k, HS + j, HS + i, e)] += rho * v * wt;
+      state[H5(ID_W, HS + k, HS + j, HS + i, e)] += rho * w * wt;
+      state[H5(ID_T, HS + k, HS + j, HS + i, e)] += rho * theta * wt;
+      for (int tr = 0; tr < nt; tr++) {
+        if (tr == o->idWV) tracers[H5(tr, HS + k, HS + j, HS + i, e)] += rho_v * wt;
+        else tracers[H5(tr, HS + k, HS + j, HS + i, e)] += 0 * wt;
+      }
+    }
+  }
+  awfl_oracle_convert_dynamics_to_coupler(o, state, tracers, rho_d_c, u_c, v_c, w_c, temp_c, tracers_c);
+  free(state); free(tracers); free(hyd); free(hyp);
+}
+
+/* Dycore.h:777-830 supercell profile helpers */
+static double sc_temperature(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top) {
+  if (z <= z_trop) { double lapse = -(T_trop - T_0) / (z_trop - z_0); return T_0 - lapse * (z - z_0); }
+  double lapse = -(T_top - T_trop) / (z_top - z_trop);
+  return T_trop - lapse * (z - z_trop);
+}
+static double sc_pressure_dry(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top,
+                              double p_0, double R_d, double grav) {
+  if (z <= z_trop) {
+    double lapse = -(T_trop - T_0) / (z_trop - z_0);
+    double T = sc_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+    return p_0 * pow(T / T_0, grav / (R_d * lapse));
+  }
+  double lapse = -(T_trop - T_0) / (z_trop - z_0);
+  double p_trop = p_0 * pow(T_trop / T_0, grav / (R_d * lapse));
+  lapse = -(T_top - T_trop) / (z_top - z_trop);
+  if (lapse != 0) {
+    double T = sc_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+    return p_trop * pow(T / T_trop, grav / (R_d * lapse));
+  }
+  return p_trop * exp(-grav * (z - z_trop) / (R_d * T_trop));
+}
+static double sc_relhum(double z, double z_0, double z_trop) {
+  if (z <= z_trop) return 1.0 - 0.75 * pow(z / z_trop, 1.25);
+  return 0.25;
+}
+static double sc_sat_mix_dry(double press, double T) { return 380 / (press)*exp(17.27 * (T - 273) / (T - 36)); }
+
+/* Dycore.h:1096-1276 init_supercell.  zmid (nz,nens), zint (nz+1,nens). */
+void awfl_oracle_init_supercell(const awfl_oracle_t *o, const double *zmid, const double *zint, double *rho_d_c,
+                                double *u_c, double *v_c, double *w_c, double *temp_c, double *tracers_c) {
+  const int nens = o->nens, nx = o->nx, ny = o->ny, nz = o->nz, nt = o->nt;
+  const double dx = o->xlen / nx, dy = o->ylen / ny, ylen = o->ylen;
+  const int sim2d = (ny == 1);
+  const double z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
+  const double gll_pts[9] = AWFL_GLL9_PTS_INIT, gll_wts[9] = AWFL_GLL9_WTS_INIT;
+  const double R_d = o->R_d, R_v = o->R_v, grav = o->grav, gamma = o->gamma_d, C0 = o->C0;
+  size_t nh = awfl_oracle_halo_elems(o);
+  double *state = alloc_nan(NUM_STATE * nh), *tracers = alloc_nan((size_t)nt * nh);
+  double *hyd = alloc_nan((size_t)nz * nens), *hyp = alloc_nan((size_t)nz * nens);
+  double *quad = alloc_nan((size_t)nz * 8 * 9 * nens), *pg = alloc_nan((size_t)nz * 9 * nens);
+  double *dg = alloc_nan((size_t)nz * 9 * nens), *dtg = alloc_nan((size_t)nz * 9 * nens), *dvg = alloc_nan((size_t)nz * 9 * nens);
+#define QT(k, kk, kkk, e) quad[((((size_t)(k)) * 8 + (kk)) * 9 + (kkk)) * nens + (e)]
+#define G3(a, k, kk, e) a[(((size_t)(k)) * 9 + (kk)) * nens + (e)]
+#define ZTOP(e) zint[(size_t)nz * nens + (e)]
+  for (int k = 0; k < nz; k++) for (int kk = 0; kk < 8; kk++) for (int kkk = 0; kkk < 9; kkk++) for (int e = 0; e < nens; e++) {
+    double cellmid = zmid[(size_t)k * nens + e];
+    double ngll_b = cellmid + gll_pts[kk] * DZ(k, e), ngll_t = cellmid + gll_pts[kk + 1] * DZ(k, e);
+    double ngll_m = 0.5 * (ngll_b + ngll_t);
+    double ngll_dz = DZ(k, e) * (gll_pts[kk + 1] - gll_pts[kk]);
+    double zloc = ngll_m + ngll_dz * gll_pts[kkk];
+    double temp = sc_temperature(zloc, z_0, z_trop, ZTOP(e), T_0, T_trop, T_top);
+    double press_dry = sc_pressure_dry(zloc, z_0, z_trop, ZTOP(e), T_0, T_trop, T_top, p_0, R_d, grav);
+    double qvs = sc_sat_mix_dry(press_dry, temp);
+    double relhum = sc_relhum(zloc, z_0, z_trop);
+    if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+    double qv = fmin(0.014, qvs * relhum);
+    QT(k, kk, kkk, e) = -(1 + qv) * grav / (R_d + qv * R_v) / temp;
+  }
+  for (int e = 0; e < nens; e++) {
+    G3(pg, 0, 0, e) = p_0;
+    for (int k = 0; k < nz; k++) for (int kk = 0; kk < 8; kk++) {
+      double tot = 0;
+      for (int kkk = 0; kkk < 9; kkk++) tot += QT(k, kk, kkk, e) * gll_wts[kkk];
+      tot *= DZ(k, e) * (gll_pts[kk + 1] - gll_pts[kk]);
+      G3(pg, k, kk + 1, e) = G3(pg, k, kk, e) * exp(tot);
+      if (kk == 7 && k < nz - 1) G3(pg, k + 1, 0, e) = G3(pg, k, 8, e);
+    }
+  }
+  for (int k = 0; k < nz; k++) for (int kk = 0; kk < 9; kk++) for (int e = 0; e < nens; e++) {
+    double zloc = zmid[(size_t)k * nens + e] + gll_pts[kk] * DZ(k, e);
+    double temp = sc_temperature(zloc, z_0, z_trop, ZTOP(e), T_0, T_trop, T_top);
+    double press_tmp = sc_pressure_dry(zloc, z_0, z_trop, ZTOP(e), T_0, T_trop, T_top, p_0, R_d, grav);
+    double qvs = sc_sat_mix_dry(press_tmp, temp);
+    double relhum = sc_relhum(zloc, z_0, z_trop);
+    if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+    double qv = fmin(0.014, qvs * relhum);
+    double press = G3(pg, k, kk, e);
+    double dens_dry = press / (R_d + qv * R_v) / temp, dens_vap = qv * dens_dry;
+    G3(dg, k, kk, e) = dens_dry + dens_vap;
+    G3(dtg, k, kk, e) = pow(press / C0, 1.0 / gamma);
+    G3(dvg, k, kk, e) = dens_vap;
+  }
+  /* cell means; the reference's inner `for iens` broadcast (:1226-1229) writes the same per-(k,iens) value for every
+   * member because the lambda index shadows it -- the LAST outer iens wins for all members (quirk Q10). */
+  for (int k = 0; k < nz; k++) for (int e = 0; e < nens; e++) {
+    double press_tot = 0, dens_tot = 0;
+    for (int kk = 0; kk < 9; kk++) { press_tot += G3(pg, k, kk, e) * gll_wts[kk]; dens_tot += G3(dg, k, kk, e) * gll_wts[kk]; }
+    for (int e2 = 0; e2 < nens; e2++) { hyd[(size_t)k * nens + e2] = dens_tot; hyp[(size_t)k * nens + e2] = press_tot; }
+  }
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    for (int l = 0; l < NUM_STATE; l++) state[H5(l, HS + k, HS + j, HS + i, e)] = 0;
+    for (int tr = 0; tr < nt; tr++) tracers[H5(tr, HS + k, HS + j, HS + i, e)] = 0;
+    double pres = hyp[(size_t)k * nens + e];
+    state[H5(ID_R, HS + k, HS + j, HS + i, e)] = hyd[(size_t)k * nens + e];
+    state[H5(ID_T, HS + k, HS + j, HS + i, e)] = pow(pres / C0, 1.0 / gamma);
+    for (int kk = 0; kk < 9; kk++) for (int jj = 0; jj < 9; jj++) for (int ii = 0; ii < 9; ii++) {
+      double zloc = zmid[(size_t)k * nens + e] + gll_pts[kk] * DZ(k, e);
+      const double zs = 5000, us = 30, uc = 15;
+      double uvel = zloc < zs ? us * (zloc / zs) - uc : us - uc;
+      double vvel = 0, wvel = 0;
+      double dens_vap = G3(dvg, k, kk, e);
+      double factor = gll_wts[ii] * gll_wts[jj] * gll_wts[kk];
+      double r = state[H5(ID_R, HS + k, HS + j, HS + i, e)];
+      state[H5(ID_U, HS + k, HS + j, HS + i, e)] += r * uvel * factor;
+      state[H5(ID_V, HS + k, HS + j, HS + i, e)] += r * vvel * factor;
+      state[H5(ID_W, HS + k, HS + j, HS + i, e)] += r * wvel * factor;
+      tracers[H5(o->idWV, HS + k, HS + j, HS + i, e)] += dens_vap * factor;
+    }
+  }
+  (void)dx; (void)dy; (void)ylen; (void)sim2d;
+  awfl_oracle_convert_dynamics_to_coupler(o, state, tracers, rho_d_c, u_c, v_c, w_c, temp_c, tracers_c);
+  free(state); free(tracers); free(hyd); free(hyp); free(quad); free(pg); free(dg); free(dtg); free(dvg);
+#undef QT
+#undef G3
+#undef ZTOP
+}

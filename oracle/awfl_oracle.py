@@ -61,6 +61,8 @@ def load(path=None):
     lib.awfl_oracle_convert_dynamics_to_coupler.argtypes = [C.c_void_p] + [_DP] * 8
     lib.awfl_oracle_compute_tendencies.argtypes = [C.c_void_p] + [_DP] * 4 + [C.c_double]
     lib.awfl_oracle_set_flux_taps.argtypes = [C.c_void_p, _DP, _DP, _DP]
+    lib.awfl_oracle_init_thermal.argtypes = [C.c_void_p, _DP] + [_DP] * 6
+    lib.awfl_oracle_init_supercell.argtypes = [C.c_void_p, _DP, _DP] + [_DP] * 6
     lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
     if path is None:
         _LIB = lib
@@ -180,6 +182,18 @@ class OracleDycore:
         out = C.c_double(0)
         n = self.lib.awfl_oracle_time_step(self.h, *self._f(fields), float(crm_dt), float(dt_dyn), C.byref(out))
         return n, out.value
+
+    def init_idealized(self, fields, init_data, zint):
+        """Dycore::init's optional idealised data (Dycore.h:986-1090).  zint: (nz+1,) or (nz+1,nens); fills `fields`."""
+        zi = np.ascontiguousarray(np.broadcast_to(np.asarray(zint, dtype=np.float64).reshape(self.nz + 1, -1),
+                                                  (self.nz + 1, self.nens)))
+        zm = np.ascontiguousarray(0.5 * (zi[:-1] + zi[1:]))
+        if init_data == "thermal":
+            self.lib.awfl_oracle_init_thermal(self.h, _p(zm), *self._f(fields))
+        elif init_data == "supercell":
+            self.lib.awfl_oracle_init_supercell(self.h, _p(zm), _p(zi), *self._f(fields))
+        elif init_data != "external":
+            raise ValueError("ERROR: Invalid data_spec")
 
     # --- intermediates, for kernel-level parity tests -------------------------------------------
     def halo_shape(self):

@@ -37,6 +37,7 @@ SYMBOLS = {
     "pam_amd_awfl_abi_version": (C.c_int, []),
     "pam_amd_awfl_last_error": (C.c_char_p, []),
     "pam_amd_awfl_init": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "pam_amd_awfl_init_idealized": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_char_p, C.c_void_p, C.c_void_p]),
     "pam_amd_awfl_finalize": (C.c_int, [C.c_void_p]),
     "pam_amd_awfl_dycore_name": (C.c_char_p, [C.c_void_p]),
     "pam_amd_awfl_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _DP]),

@@ -703,6 +703,104 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optional idealised initial conditions of Dycore::init (Dycore.h:986-1090).  Both build the conserved cell averages
+// with 9x9x9-point Gauss-Lobatto quadrature, accumulated in the reference's loop order (kk, jj, ii), and convert them to
+// coupler fields exactly as convert_dynamics_to_coupler does (Dycore.h:1313-1330).
+PAMA_D double sample_ellipse_cosine(double amp, double x, double y, double z, double x0, double y0, double z0, double xrad,
+                                    double yrad, double zrad) {   // Dycore.h:753-766
+  double dist = sqrt(((x - x0) / xrad) * ((x - x0) / xrad) + ((y - y0) / yrad) * ((y - y0) / yrad) +
+                     ((z - z0) / zrad) * ((z - z0) / zrad)) * M_PI / 2.;
+  if (dist <= M_PI / 2.) return amp * pow(cos(dist), 2.0);
+  return 0.;
+}
+
+// conserved (rho, rho u, rho v, rho w, rho theta, rho_t...) -> coupler fields of one cell
+PAMA_D void store_coupler_cell(const Params &P, double rho, double ru, double rv, double rw, double rt, double rho_v_wv,
+                               double *__restrict__ rho_d_c, double *__restrict__ u_c, double *__restrict__ v_c,
+                               double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc, long long idx) {
+  double theta = rt / rho;
+  double press = P.C0 * pow(rho * theta, P.gamma);
+  double rho_d = rho;
+  for (int t = 0; t < P.nt; t++) {
+    double r = (t == P.idWV) ? rho_v_wv : 0.0;
+    if ((P.mass_mask >> t) & 1ull) rho_d -= r;
+    trc.p[t][idx] = r;
+  }
+  rho_d_c[idx] = rho_d;
+  u_c[idx] = ru / rho;
+  v_c[idx] = rv / rho;
+  w_c[idx] = rw / rho;
+  temp_c[idx] = press / (rho_d * P.R_d + rho_v_wv * P.R_v);
+}
+
+// DATA_SPEC_THERMAL (Dycore.h:1021-1088): theta = 300 K hydrostatic atmosphere + 2 K cos^2 bubble at (xlen/2, ylen/2, 2 km)
+PAMA_D void init_thermal_body(const Params &P, double xlen, double ylen, double cp_d, double p0,
+                              const double *__restrict__ zmid, double *__restrict__ rho_d_c, double *__restrict__ u_c,
+                              double *__restrict__ v_c, double *__restrict__ w_c, double *__restrict__ temp_c,
+                              const TracerPtrs &trc, const CellId &c) {
+  const double qp[9] = AWFL_GLL9_PTS_INIT, qw[9] = AWFL_GLL9_WTS_INIT;
+  const long long ke = (long long)c.k * P.nens + c.e;
+  const double dzk = P.dz[ke], zm = zmid[ke];
+  // hydrostatic background cell averages (Dycore.h:1035-1047)
+  double hr = 0., hp = 0.;
+  for (int kk = 0; kk < 9; kk++) {
+    double z = zm + qp[kk] * dzk;
+    const double theta0 = 300.;
+    double exner = 1. - P.grav * z / (cp_d * theta0);            // hydro_const_theta, Dycore.h:739-748
+    double p = p0 * pow(exner, (cp_d / P.R_d));
+    double rt = pow((p / P.C0), (1.0 / P.gamma));
+    double r = rt / theta0;
+    hr += r * qw[kk];
+    hp += P.C0 * pow(r * theta0, P.gamma) * qw[kk];
+  }
+  const double ht = pow(hp / P.C0, 1.0 / P.gamma) / hr;
+  double sR = 0., sU = 0., sV = 0., sW = 0., sT = 0., sQ = 0.;
+  for (int kk = 0; kk < 9; kk++)
+    for (int jj = 0; jj < 9; jj++)
+      for (int ii = 0; ii < 9; ii++) {
+        double x = (c.i + 0.5) * P.dx + qp[ii] * P.dx;
+        double y = (c.j + 0.5) * P.dy + qp[jj] * P.dy;
+        if (P.sim2d) y = ylen / 2;
+        double z = zm + qp[kk] * dzk;
+        double rho = hr, u = 0, v = 0, w = 0, rho_v = 0;
+        double theta = ht + sample_ellipse_cosine(2.0, x, y, z, xlen / 2, ylen / 2, 2000., 2000., 2000., 2000.);
+        double wt = qw[ii] * qw[jj] * qw[kk];
+        sR += rho * wt; sU += rho * u * wt; sV += rho * v * wt; sW += rho * w * wt; sT += rho * theta * wt;
+        sQ += rho_v * wt;
+      }
+  store_coupler_cell(P, sR, sU, sV, sW, sT, sQ, rho_d_c, u_c, v_c, w_c, temp_c, trc, c.idx);
+}
+
+// init_supercell (Dycore.h:1096-1276): the column quantities (hydrostatic cell means, vapour density at the 9 GLL
+// levels of each cell) are integrated on the host at init (awfl_vertical.h); this is the 3-D fill (Dycore.h:1233-1275).
+//   hy_dens, hy_pres (nz,nens); dens_vap_gll (nz,9,nens)
+PAMA_D void init_supercell_body(const Params &P, const double *__restrict__ zmid, const double *__restrict__ hy_dens,
+                                const double *__restrict__ hy_pres, const double *__restrict__ dens_vap_gll,
+                                double *__restrict__ rho_d_c, double *__restrict__ u_c, double *__restrict__ v_c,
+                                double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc,
+                                const CellId &c) {
+  const double qp[9] = AWFL_GLL9_PTS_INIT, qw[9] = AWFL_GLL9_WTS_INIT;
+  const long long ke = (long long)c.k * P.nens + c.e;
+  const double dzk = P.dz[ke], zm = zmid[ke];
+  const double rho = hy_dens[ke];
+  const double rt = pow(hy_pres[ke] / P.C0, 1.0 / P.gamma);
+  double sU = 0., sV = 0., sW = 0., sQ = 0.;
+  for (int kk = 0; kk < 9; kk++) {
+    const double zloc = zm + qp[kk] * dzk;
+    const double zs = 5000, us = 30, uc = 15;
+    const double uvel = zloc < zs ? us * (zloc / zs) - uc : us - uc;
+    const double dens_vap = dens_vap_gll[((long long)c.k * 9 + kk) * P.nens + c.e];
+    for (int jj = 0; jj < 9; jj++)
+      for (int ii = 0; ii < 9; ii++) {
+        double factor = qw[ii] * qw[jj] * qw[kk];
+        sU += rho * uvel * factor; sV += rho * 0.0 * factor; sW += rho * 0.0 * factor;
+        sQ += dens_vap * factor;
+      }
+  }
+  store_coupler_cell(P, rho, sU, sV, sW, rt, sQ, rho_d_c, u_c, v_c, w_c, temp_c, trc, c.idx);
+}
+
+// ------------------------------------------------------------------------------------------------
 // declare_current_profile_as_hydrostatic (Dycore.h:1439-1501).
 // interface pressure 0.5*(p_L + p_R) at face k of column (j,i,e) from the vertical WENO (Dycore.h:1457-1482)
 template <bool VZ_PER_ENS>

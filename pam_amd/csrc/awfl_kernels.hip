@@ -119,6 +119,26 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
 
+__global__ void __launch_bounds__(256) awfl_init_thermal_kernel(Params P, EnsRange R, double xlen, double ylen, double cp_d,
+                                                                double p0, const double *__restrict__ zmid,
+                                                                double *__restrict__ rho_d, double *__restrict__ u,
+                                                                double *__restrict__ v, double *__restrict__ w,
+                                                                double *__restrict__ temp, TracerPtrs trc) {
+  CellId c;
+  if (grid_cell(P, R, c)) init_thermal_body(P, xlen, ylen, cp_d, p0, zmid, rho_d, u, v, w, temp, trc, c);
+}
+
+__global__ void __launch_bounds__(256) awfl_init_supercell_kernel(Params P, EnsRange R, const double *__restrict__ zmid,
+                                                                  const double *__restrict__ hy_dens,
+                                                                  const double *__restrict__ hy_pres,
+                                                                  const double *__restrict__ dens_vap_gll,
+                                                                  double *__restrict__ rho_d, double *__restrict__ u,
+                                                                  double *__restrict__ v, double *__restrict__ w,
+                                                                  double *__restrict__ temp, TracerPtrs trc) {
+  CellId c;
+  if (grid_cell(P, R, c)) init_supercell_body(P, zmid, hy_dens, hy_pres, dens_vap_gll, rho_d, u, v, w, temp, trc, c);
+}
+
 struct GcmPtrs { const double *p[5]; int use; };
 
 __global__ void __launch_bounds__(256) awfl_init_prim_kernel(Params P, EnsRange R, const double *__restrict__ rho_d,
@@ -759,6 +779,51 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       HIP_TRY(hipStreamWaitEvent(h->stream, c.done, 0));
     }
   }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_init_idealized(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, const char *init_data,
+                                const double *vertical_midpoint_height, const double *vertical_interface_height) {
+  if (!h || !init_data || !vertical_midpoint_height || !vertical_interface_height)
+    return fail(PAM_AMD_EINVAL, "init_idealized: null argument");
+  USE_DEVICE(h);
+  const std::string kind(init_data);
+  if (kind == "external") return PAM_AMD_OK;                                       // Dycore.h:1009: nothing to do
+  if (kind != "thermal" && kind != "supercell") return fail(PAM_AMD_EINVAL, "ERROR: Invalid data_spec");   // Dycore.h:1002
+  TracerPtrs tp;
+  int rc = make_tracer_ptrs(h, fields, tp);
+  if (rc) return rc;
+  const Params &P = h->P;
+  const EnsRange r = full_range(P);
+  if (kind == "thermal") {
+    ScopedTimer st(h, "init_idealized", h->stream);
+    hipLaunchKernelGGL(awfl_init_thermal_kernel, cell_grid(P, r), dim3(256), 0, h->stream, P, r, h->cfg.xlen, h->cfg.ylen,
+                       h->cp_d, h->p0, vertical_midpoint_height, fields->density_dry, fields->uvel, fields->vvel, fields->wvel,
+                       fields->temp, tp);
+    HIP_TRY(hipGetLastError());
+    return PAM_AMD_OK;
+  }
+  // supercell: integrate the sounding column on the host (once), then fill the 3-D fields on the device
+  const size_t nzn = (size_t)P.nz * P.nens;
+  std::vector<double> dz(nzn), zmid(nzn), zint(nzn + P.nens);
+  HIP_TRY(hipMemcpy(dz.data(), h->dz, nzn * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(zmid.data(), vertical_midpoint_height, nzn * 8, hipMemcpyDefault));
+  HIP_TRY(hipMemcpy(zint.data(), vertical_interface_height, (nzn + P.nens) * 8, hipMemcpyDefault));
+  SupercellColumns sc = supercell_columns(dz.data(), zmid.data(), zint.data(), P.nz, P.nens, h->R_d, h->R_v, h->grav,
+                                          h->gamma_d, h->C0);
+  double *d_hd = nullptr, *d_hp = nullptr, *d_dv = nullptr;
+  HIP_TRY(hipMalloc(&d_hd, nzn * 8));
+  HIP_TRY(hipMalloc(&d_hp, nzn * 8));
+  HIP_TRY(hipMalloc(&d_dv, nzn * 9 * 8));
+  HIP_TRY(hipMemcpy(d_hd, sc.hy_dens.data(), nzn * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_hp, sc.hy_pres.data(), nzn * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_dv, sc.dens_vap_gll.data(), nzn * 9 * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(awfl_init_supercell_kernel, cell_grid(P, r), dim3(256), 0, h->stream, P, r, vertical_midpoint_height,
+                     d_hd, d_hp, d_dv, fields->density_dry, fields->uvel, fields->vvel, fields->wvel, fields->temp, tp);
+  hipError_t err = hipGetLastError();
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(d_hd); (void)hipFree(d_hp); (void)hipFree(d_dv);
+  if (err != hipSuccess) return fail(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
 }
 

@@ -67,6 +67,23 @@ class Dycore:
             dm.register_existing(name, "", self._owned_array(name))
         dm.register_existing("tracer_adds_mass", "", torch.tensor(list(mass), dtype=torch.bool, device=coupler.device))
         dm.register_existing("tracer_positive", "", torch.tensor(list(pos), dtype=torch.bool, device=coupler.device))
+        # optional idealised initial data (Dycore.h:986-1090; the reference compiles this under PAM_STANDALONE and reads the
+        # `initData` key of the YAML file named by option "standalone_input_file")
+        if coupler.option_exists("standalone_input_file"):
+            import yaml
+            with open(coupler.get_option("standalone_input_file")) as fh:
+                data_str = str(yaml.safe_load(fh)["initData"])
+            self.init_idealized(coupler, data_str)
+
+    def init_idealized(self, coupler, init_data):
+        """init_data: "thermal" | "supercell" | "external" (anything else: ERROR: Invalid data_spec, Dycore.h:1002)."""
+        self._need()
+        f = self._mk_fields(coupler)
+        dm = coupler.get_data_manager_device_readonly()
+        zmid = dm.get("vertical_midpoint_height", readonly=True)
+        zint = dm.get("vertical_interface_height", readonly=True)
+        check(self._lib.pam_amd_awfl_init_idealized(self._h, C.byref(f), str(init_data).encode(), zmid.data_ptr(),
+                                                    zint.data_ptr()))
 
     def _owned_array(self, name):
         ptr, dims, nd = C.c_void_p(), (C.c_int * 5)(), C.c_int()
