@@ -3,11 +3,13 @@
 //
 //   coupler.allocate_coupler_state -> set_grid -> [micro.init: tracer registration + constants] -> dycore.init
 //   -> (host model fills the coupler fields) -> dycore.declare_current_profile_as_hydrostatic
-//   -> N x coupler.run_module("dycore", dycore.timeStep) -> output
+//   -> N x { coupler.run_module("dycore", dycore.timeStep); [sponge_layer]; [micro.timeStep] } -> output
 //
 // Input/output are raw little-endian fp64 files written/read by tests/test_cpp_driver.py (the reference reads YAML and
 // writes netCDF; neither library exists in this image and I/O is out of scope):
-//   header (8 x int64): nens nx ny nz num_tracers nsteps mode_a has_consts ; then xlen ylen crm_dt (3 x f64),
+//   header (8 x int64): nens nx ny nz num_tracers nsteps flags has_consts ; then xlen ylen crm_dt (3 x f64),
+//   (flags: bit0 = hydrostasis mode A, bit1 = run modules::sponge_layer, bit2 = Kessler Microphysics: its init registers
+//   the three water tracers, so num_tracers must be 3, and "precl" (ny*nx*nens) is appended to the output)
 //   6 constants (R_d cp_d R_v cp_v p0 grav), zint (nz+1), tracer flags (num_tracers x 2 bytes positive/adds_mass,
 //   then idWV int64), then density_dry,uvel,vvel,wvel,temp,(tracers...) each nz*ny*nx*nens f64.
 #include <cstdint>
@@ -15,6 +17,8 @@
 #include <fstream>
 
 #include "dynamics/awfl_amd/Dycore.h"
+#include "modules/sponge_layer.h"
+#include "physics/micro/kessler_amd/Microphysics.h"
 
 static void die(const char *m) { std::fprintf(stderr, "driver: %s\n", m); std::exit(2); }
 
@@ -25,7 +29,8 @@ int main(int argc, char **argv) {
   int64_t hdr[8];
   in.read((char *)hdr, sizeof(hdr));
   const int nens = hdr[0], nx = hdr[1], ny = hdr[2], nz = hdr[3], nt = hdr[4], nsteps = hdr[5];
-  const bool mode_a = hdr[6] != 0;
+  const bool mode_a = (hdr[6] & 1) != 0, with_sponge = (hdr[6] & 2) != 0, with_micro = (hdr[6] & 4) != 0;
+  if (with_micro && nt != 3) die("the Kessler microphysics registers exactly 3 tracers");
   double geo[3], consts[6];
   in.read((char *)geo, sizeof(geo));
   in.read((char *)consts, sizeof(consts));
@@ -44,8 +49,13 @@ int main(int argc, char **argv) {
     // what micro.init()/sgs.init() do for the dycore: constants + tracer registration, BEFORE dycore.init (driver.cpp:189-191)
     const char *cn[6] = {"R_d", "cp_d", "R_v", "cp_v", "p0", "grav"};
     if (hdr[7]) for (int i = 0; i < 6; i++) coupler.set_option<real>(cn[i], consts[i]);
-    for (int t = 0; t < nt; t++)
-      coupler.add_tracer(t == idWV ? "water_vapor" : "tracer_" + std::to_string(t), "", flags[2 * t] != 0, flags[2 * t + 1] != 0);
+    Microphysics micro;
+    if (with_micro) {
+      micro.init(coupler);                                                   // driver.cpp:189
+    } else {
+      for (int t = 0; t < nt; t++)
+        coupler.add_tracer(t == idWV ? "water_vapor" : "tracer_" + std::to_string(t), "", flags[2 * t] != 0, flags[2 * t + 1] != 0);
+    }
     Dycore dycore;
     dycore.init(coupler);                                                    // driver.cpp:191
     std::printf("Dycore: %s\n", dycore.dycore_name());                       // driver.cpp:203
@@ -60,13 +70,21 @@ int main(int argc, char **argv) {
     }
     if (!mode_a) coupler.set_option<bool>("balance_hydrostasis_with_gravity", false);   // after init(), SURVEY 8c
     dycore.declare_current_profile_as_hydrostatic(coupler);                  // the host model does this once per GCM step
-    for (int s = 0; s < nsteps; s++)
+    for (int s = 0; s < nsteps; s++) {
       coupler.run_module("dycore", [&](pam::PamCoupler &c) { dycore.timeStep(c); });    // driver.cpp:248
+      if (with_sponge) coupler.run_module("sponge_layer", modules::sponge_layer);       // driver.cpp:250
+      if (with_micro) coupler.run_module("micro", [&](pam::PamCoupler &c) { micro.timeStep(c); });   // driver.cpp:253
+    }
     if (hipDeviceSynchronize() != hipSuccess) die("device error");
     std::ofstream out(argv[2], std::ios::binary);
     for (auto &n : names) {
       if (hipMemcpy(buf.data(), dm.get<real, 4>(n).data(), ncell * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) die("memcpy");
       out.write((char *)buf.data(), ncell * sizeof(real));
+    }
+    if (with_micro) {
+      const size_t n2 = (size_t)ny * nx * nens;
+      if (hipMemcpy(buf.data(), dm.get<real, 3>("precl").data(), n2 * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) die("memcpy");
+      out.write((char *)buf.data(), n2 * sizeof(real));
     }
     dycore.finalize(coupler);                                                // driver.cpp:285
   } catch (std::string &msg) {

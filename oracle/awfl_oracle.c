@@ -1117,3 +1117,87 @@ void awfl_oracle_init_supercell(const awfl_oracle_t *o, const double *zmid, cons
 #undef G3
 #undef ZTOP
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Kessler microphysics, "next row" N4 (physics/micro/kessler/Microphysics.h:120-268 timeStep, :346-457 kessler()).
+ * Arrays are the coupler's (nz, ncol) collapsed views, ncol = ny*nx*nens (get_lev_col); zmid (nz,nens); precl (ncol).
+ * rainsplit_in > 0 overrides the sub-cycle count (ensemble shards must agree on the global minimum).  Returns rainsplit. */
+int awfl_oracle_kessler(int nens, int nx, int ny, int nz, double *rho_v, double *rho_c, double *rho_r, const double *rho_dry,
+                        double *temp, double *precl, const double *zmid_in, double dt, double R_d, double R_v, double cp_d,
+                        double p0, int rainsplit_in) {
+  const size_t ncol = (size_t)ny * nx * nens;
+  const size_t n = (size_t)nz * ncol;
+#define A2(a, k, i) a[(size_t)(k) * ncol + (i)]
+  double *qv = alloc_nan(n), *qc = alloc_nan(n), *qr = alloc_nan(n), *pressure = alloc_nan(n), *theta = alloc_nan(n);
+  double *exner = alloc_nan(n), *zmid = alloc_nan(n);
+  for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) A2(zmid, k, i) = zmid_in[(size_t)k * nens + (i % nens)]; /* :156-158 */
+  for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) {                                                        /* :167-174 */
+    A2(qv, k, i) = A2(rho_v, k, i) / A2(rho_dry, k, i);
+    A2(qc, k, i) = A2(rho_c, k, i) / A2(rho_dry, k, i);
+    A2(qr, k, i) = A2(rho_r, k, i) / A2(rho_dry, k, i);
+    A2(pressure, k, i) = R_d * A2(rho_dry, k, i) * A2(temp, k, i) + R_v * A2(rho_v, k, i) * A2(temp, k, i);
+    A2(exner, k, i) = pow(A2(pressure, k, i) / p0, R_d / cp_d);
+    A2(theta, k, i) = A2(temp, k, i) / A2(exner, k, i);
+  }
+  /* kessler(theta, qv, qc, qr, rho_dry, precl, zmid, exner, dt, R_d, cp_d, p0)  :346-457 */
+  const double *rho = rho_dry, *z = zmid, *pk = exner;
+  const double Rd = R_d, cp = cp_d;
+  const double psl = p0 / 100, rhoqr = 1000., lv = 2.5e6;
+  double *r = alloc_nan(n), *rhalf = alloc_nan(n), *pc = alloc_nan(n), *velqr = alloc_nan(n), *sed = alloc_nan(n);
+  double dt_max = INFINITY;
+  for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) {
+    A2(r, k, i) = 0.001 * A2(rho, k, i);
+    A2(rhalf, k, i) = sqrt(A2(rho, 0, i) / A2(rho, k, i));
+    A2(pc, k, i) = 3.8 / (pow(A2(pk, k, i), cp / Rd) * psl);
+    A2(velqr, k, i) = 36.34 * pow(A2(qr, k, i) * A2(r, k, i), 0.1364) * A2(rhalf, k, i);
+    if (k == 0) precl[i] = 0;
+  }
+  for (int k = 0; k < nz - 1; k++) for (size_t i = 0; i < ncol; i++) {
+    double d = (A2(velqr, k, i) > 1.e-10) ? 0.8 * (A2(z, k + 1, i) - A2(z, k, i)) / A2(velqr, k, i) : dt;
+    if (d < dt_max) dt_max = d;
+  }
+  int rainsplit = rainsplit_in > 0 ? rainsplit_in : (int)ceil(dt / dt_max);
+  double dt0 = dt / (double)rainsplit;
+  for (int nt = 0; nt < rainsplit; nt++) {
+    for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) {
+      if (k == 0) precl[i] = precl[i] + A2(rho, 0, i) * A2(qr, 0, i) * A2(velqr, 0, i) / rhoqr;
+      if (k == nz - 1) {
+        A2(sed, nz - 1, i) = -dt0 * A2(qr, nz - 1, i) * A2(velqr, nz - 1, i) / (0.5 * (A2(z, nz - 1, i) - A2(z, nz - 2, i)));
+      } else {
+        A2(sed, k, i) = dt0 * (A2(r, k + 1, i) * A2(qr, k + 1, i) * A2(velqr, k + 1, i) - A2(r, k, i) * A2(qr, k, i) * A2(velqr, k, i)) /
+                        (A2(r, k, i) * (A2(z, k + 1, i) - A2(z, k, i)));
+      }
+    }
+    for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) {
+      double qrprod = A2(qc, k, i) - (A2(qc, k, i) - dt0 * fmax(0.001 * (A2(qc, k, i) - 0.001), 0.)) /
+                                         (1 + dt0 * 2.2 * pow(A2(qr, k, i), 0.875));
+      A2(qc, k, i) = fmax(A2(qc, k, i) - qrprod, 0.);
+      A2(qr, k, i) = fmax(A2(qr, k, i) + qrprod + A2(sed, k, i), 0.);
+      double tmp = A2(pk, k, i) * A2(theta, k, i) - 36.;
+      double qvs = A2(pc, k, i) * exp(17.27 * (A2(pk, k, i) * A2(theta, k, i) - 273.) / tmp);
+      double prod = (A2(qv, k, i) - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+      double tmp1 = dt0 * (((1.6 + 124.9 * pow(A2(r, k, i) * A2(qr, k, i), 0.2046)) * pow(A2(r, k, i) * A2(qr, k, i), 0.525)) /
+                           (2550000. * A2(pc, k, i) / (3.8 * qvs) + 540000.)) *
+                    (fmax(qvs - A2(qv, k, i), 0.) / (A2(r, k, i) * qvs));
+      double tmp2 = fmax(-prod - A2(qc, k, i), 0.);
+      double tmp3 = A2(qr, k, i);
+      double ern = fmin(tmp1, fmin(tmp2, tmp3));
+      A2(theta, k, i) = A2(theta, k, i) + lv / (cp * A2(pk, k, i)) * (fmax(prod, -A2(qc, k, i)) - ern);
+      A2(qv, k, i) = fmax(A2(qv, k, i) - fmax(prod, -A2(qc, k, i)) + ern, 0.);
+      A2(qc, k, i) = A2(qc, k, i) + fmax(prod, -A2(qc, k, i));
+      A2(qr, k, i) = A2(qr, k, i) - ern;
+      A2(velqr, k, i) = 36.34 * pow(A2(qr, k, i) * A2(r, k, i), 0.1364) * A2(rhalf, k, i);
+      if (k == 0 && nt == rainsplit - 1) precl[i] = precl[i] / (double)rainsplit;
+    }
+  }
+  for (int k = 0; k < nz; k++) for (size_t i = 0; i < ncol; i++) {   /* :243-250 */
+    A2(rho_v, k, i) = A2(qv, k, i) * A2(rho_dry, k, i);
+    A2(rho_c, k, i) = A2(qc, k, i) * A2(rho_dry, k, i);
+    A2(rho_r, k, i) = A2(qr, k, i) * A2(rho_dry, k, i);
+    A2(temp, k, i) = A2(theta, k, i) * A2(exner, k, i);
+  }
+  free(qv); free(qc); free(qr); free(pressure); free(theta); free(exner); free(zmid);
+  free(r); free(rhalf); free(pc); free(velqr); free(sed);
+#undef A2
+  return rainsplit;
+}

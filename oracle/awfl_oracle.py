@@ -63,6 +63,8 @@ def load(path=None):
     lib.awfl_oracle_set_flux_taps.argtypes = [C.c_void_p, _DP, _DP, _DP]
     lib.awfl_oracle_init_thermal.argtypes = [C.c_void_p, _DP] + [_DP] * 6
     lib.awfl_oracle_init_supercell.argtypes = [C.c_void_p, _DP, _DP] + [_DP] * 6
+    lib.awfl_oracle_kessler.restype = C.c_int
+    lib.awfl_oracle_kessler.argtypes = [C.c_int] * 4 + [_DP] * 7 + [C.c_double] * 5 + [C.c_int]
     lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
     if path is None:
         _LIB = lib
@@ -238,3 +240,15 @@ def sponge_layer(fields, zint, zmid, dt, num_layers=5, time_scale=60.0, lib=None
     zi = np.ascontiguousarray(zint, dtype=np.float64)
     zm = np.ascontiguousarray(zmid, dtype=np.float64)
     lib.awfl_oracle_sponge_layer(nens, nx, ny, nz, len(arrs), ptrs, _p(zi), _p(zm), float(dt), int(num_layers), float(time_scale))
+
+
+def kessler(rho_v, rho_c, rho_r, rho_dry, temp, zmid, dt, consts, rainsplit=0, lib=None):
+    """Kessler microphysics time step (physics/micro/kessler/Microphysics.h:120-268) on (nz,ny,nx,nens) numpy arrays,
+    updated in place.  Returns (precl (ny,nx,nens), rainsplit)."""
+    lib = lib or load()
+    nz, ny, nx, nens = temp.shape
+    precl = np.zeros((ny, nx, nens))
+    zm = np.ascontiguousarray(zmid, dtype=np.float64)
+    n = lib.awfl_oracle_kessler(nens, nx, ny, nz, _p(rho_v), _p(rho_c), _p(rho_r), _p(rho_dry), _p(temp), _p(precl), _p(zm),
+                                float(dt), consts["R_d"], consts["R_v"], consts["cp_d"], consts["p0"], int(rainsplit))
+    return precl, n

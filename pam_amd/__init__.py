@@ -8,3 +8,4 @@ from .coupler import PamCoupler, DataManager, Options  # noqa: F401
 from .dycore import Dycore  # noqa: F401
 from . import parallel  # noqa: F401
 from . import modules  # noqa: F401
+from .micro import Microphysics  # noqa: F401

@@ -54,6 +54,128 @@ __global__ void __launch_bounds__(256) sponge_relax_kernel(FieldPtrs F, int nens
   *f += (h - *f) * factor;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kessler microphysics (physics/micro/kessler/Microphysics.h:120-268 timeStep, :346-457 kessler()).
+// Columns are independent; col = (j*nx+i)*nens+e is the fastest index of every (nz, ncol) array, so consecutive lanes
+// read consecutive doubles at every level.  The reference's per-step temporaries (qv,qc,qr,theta) live IN PLACE in the
+// coupler arrays between the two kernels; only the old Exner function needs scratch.  velqr, r, rhalf, pc are pure
+// functions of stored values and are recomputed (bitwise the same as the reference's stored temporaries).
+
+__device__ __forceinline__ double kessler_velqr(double qr, double r, double rhalf) {
+  return 36.34 * pow(qr * r, 0.1364) * rhalf;   // :375, :449
+}
+
+// timeStep :167-174 + kessler "main 1" :369-386.  WRITE=false only evaluates the sedimentation time-step limit.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long ncol, int nens, double *rho_v, double *rho_c,
+                                                           double *rho_r, const double *__restrict__ rho_dry, double *temp,
+                                                           double *precl, const double *__restrict__ zmid, double dt,
+                                                           double R_d, double R_v, double cp_d, double p0, double *exner_out,
+                                                           unsigned long long *dt_max_bits) {
+  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  double dt2d = dt;
+  bool have = false;
+  if (col < ncol) {
+    const long long idx = (long long)k * ncol + col;
+    const int e = (int)(col % nens);
+    const double rho = rho_dry[idx];
+    const double qr = rho_r[idx] / rho;
+    const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho_dry[col] / rho));
+    if (k < nz - 1) {
+      have = true;
+      if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
+    }
+    if (WRITE) {
+      const double rv = rho_v[idx], T = temp[idx];
+      const double pressure = R_d * rho * T + R_v * rv * T;
+      const double ex = pow(pressure / p0, R_d / cp_d);
+      rho_v[idx] = rv / rho;
+      rho_c[idx] = rho_c[idx] / rho;
+      rho_r[idx] = qr;
+      temp[idx] = T / ex;
+      exner_out[idx] = ex;
+      if (k == 0) precl[col] = 0;
+    }
+  }
+  // block minimum -> one atomic per wavefront (positive doubles order like their bit patterns)
+  unsigned long long bits = have ? (unsigned long long)__double_as_longlong(dt2d) : ~0ull;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(bits, off);
+    bits = o < bits ? o : bits;
+  }
+  if ((threadIdx.x & 63) == 0 && bits != ~0ull) atomicMin(dt_max_bits, bits);
+}
+
+// kessler "main 2" + "main 3" (:394-453) for all sub-cycles, then timeStep :243-250.  One thread marches one column
+// upwards: sed(k) needs the not-yet-adjusted values of levels k and k+1, which an upward march has at hand.
+__global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long ncol, int nens, double *qv_a, double *qc_a,
+                                                            double *qr_a, const double *__restrict__ rho_dry, double *theta_a,
+                                                            double *precl, const double *__restrict__ zmid,
+                                                            const double *__restrict__ exner, double dt, int rainsplit,
+                                                            double Rd, double cp, double p0) {
+  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const int e = (int)(col % nens);
+  const double psl = p0 / 100, rhoqr = 1000., lv = 2.5e6;
+  const double dt0 = dt / (double)rainsplit;
+  const double rho0 = rho_dry[col];
+  double pr = precl[col];
+  for (int nt = 0; nt < rainsplit; nt++) {
+    const bool last = nt == rainsplit - 1;
+    // level-k values carried from the previous iteration's "k+1" loads
+    double rho_k = rho0, z_k = zmid[e], qr_k = qr_a[col];
+    double r_k = 0.001 * rho_k, rhalf_k = sqrt(rho0 / rho_k);
+    double vel_k = kessler_velqr(qr_k, r_k, rhalf_k);
+    double z_km1 = 0;
+    pr = pr + rho0 * qr_k * vel_k / rhoqr;                                       // :397
+    for (int k = 0; k < nz; k++) {
+      const long long idx = (long long)k * ncol + col;
+      double sed, rho_n = 0, z_n = 0, qr_n = 0, r_n = 0, rhalf_n = 0, vel_n = 0;
+      if (k == nz - 1) {
+        sed = -dt0 * qr_k * vel_k / (0.5 * (z_k - z_km1));                        // :400
+      } else {
+        rho_n = rho_dry[idx + ncol]; z_n = zmid[(long long)(k + 1) * nens + e]; qr_n = qr_a[idx + ncol];
+        r_n = 0.001 * rho_n; rhalf_n = sqrt(rho0 / rho_n);
+        vel_n = kessler_velqr(qr_n, r_n, rhalf_n);
+        sed = dt0 * (r_n * qr_n * vel_n - r_k * qr_k * vel_k) / (r_k * (z_n - z_k));   // :403
+      }
+      double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k;
+      const double pk = exner[idx];
+      const double pc = 3.8 / (pow(pk, cp / Rd) * psl);                            // :374
+      // autoconversion and accretion (:412-414)
+      const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * pow(qr, 0.875));
+      qc = fmax(qc - qrprod, 0.);
+      qr = fmax(qr + qrprod + sed, 0.);
+      // saturation vapour mixing ratio (:417-422)
+      const double tmp = pk * theta - 36.;
+      const double qvs = pc * exp(17.27 * (pk * theta - 273.) / tmp);
+      const double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+      // evaporation of rain (:425-430)
+      const double rq = r_k * qr;
+      const double tmp1 = dt0 * (((1.6 + 124.9 * pow(rq, 0.2046)) * pow(rq, 0.525)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
+                          (fmax(qvs - qv, 0.) / (r_k * qvs));
+      const double tmp2 = fmax(-prod - qc, 0.);
+      const double ern = fmin(tmp1, fmin(tmp2, qr));
+      // saturation adjustment (:433-439)
+      const double cond = fmax(prod, -qc);
+      theta = theta + lv / (cp * pk) * (cond - ern);
+      qv = fmax(qv - cond + ern, 0.);
+      qc = qc + cond;
+      qr = qr - ern;
+      if (last) {   // timeStep :243-250 (temp from the OLD Exner function)
+        qv_a[idx] = qv * rho_k; qc_a[idx] = qc * rho_k; qr_a[idx] = qr * rho_k; theta_a[idx] = theta * pk;
+      } else {
+        qv_a[idx] = qv; qc_a[idx] = qc; qr_a[idx] = qr; theta_a[idx] = theta;
+      }
+      z_km1 = z_k;
+      rho_k = rho_n; z_k = z_n; qr_k = qr_n; r_k = r_n; rhalf_k = rhalf_n; vel_k = vel_n;
+    }
+  }
+  precl[col] = pr / (double)rainsplit;                                            // :452
+}
+
 }  // namespace
 
 extern "C" int pam_amd_set_last_error_(int code, const char *msg);   // defined in awfl_kernels.hip
@@ -86,5 +208,71 @@ extern "C" int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fi
                      num_layers, workspace, zint, zmid, crm_dt / time_scale);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  return PAM_AMD_OK;
+}
+
+namespace {
+int kessler_check(int nens, int nx, int ny, int nz, const void *a, const void *b, const void *c, const void *d, const void *e,
+                  const void *f, const void *g, double dt, double R_d, double R_v, double cp_d, double p0) {
+  if (nens < 1 || nx < 1 || ny < 1 || nz < 2) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: bad dimensions (nz >= 2)");
+  if (!a || !b || !c || !d || !e || !f || !g) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null pointer");
+  if (!(dt > 0) || !(R_d > 0) || !(R_v > 0) || !(cp_d > 0) || !(p0 > 0))
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: dt and the constants must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "kessler: no HIP device available (this library has no CPU path)");
+  return PAM_AMD_OK;
+}
+
+int kessler_read_dt_max(const double *slot, hipStream_t s, double *out) {
+  double v = 0;
+  if (hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
+  if (!(v > 0)) return pam_amd_set_last_error_(PAM_AMD_ESTATE, "kessler: sedimentation time-step limit is not positive (NaN or negative rain/density in the coupler state)");
+  *out = v;
+  return PAM_AMD_OK;
+}
+}  // namespace
+
+extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, const double *rho_r, const double *rho_dry,
+                                             const double *zmid, double dt, double *workspace, void *stream, double *dt_max) {
+  if (!dt_max) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null dt_max");
+  if (int rc = kessler_check(nens, nx, ny, nz, rho_r, rho_r, rho_r, rho_dry, rho_dry, zmid, workspace, dt, 1, 1, 1, 1)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const long long ncol = (long long)ny * nx * nens;
+  unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
+  hipMemsetAsync(slot, 0x7f, 8, s);
+  hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
+                     (double *)nullptr, (double *)nullptr, const_cast<double *>(rho_r), rho_dry, (double *)nullptr,
+                     (double *)nullptr, zmid, dt, 1., 1., 1., 1., (double *)nullptr, slot);
+  return kessler_read_dt_max((const double *)slot, s, dt_max);
+}
+
+extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, double *rho_v, double *rho_c, double *rho_r,
+                                         const double *rho_dry, double *temp, double *precl, const double *zmid, double dt,
+                                         double R_d, double R_v, double cp_d, double p0, double *workspace, void *stream,
+                                         int rainsplit_hint, int *rainsplit) {
+  if (!precl) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null precl");
+  if (int rc = kessler_check(nens, nx, ny, nz, rho_v, rho_c, rho_r, rho_dry, temp, zmid, workspace, dt, R_d, R_v, cp_d, p0)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const long long ncol = (long long)ny * nx * nens;
+  unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
+  hipMemsetAsync(slot, 0x7f, 8, s);
+  hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
+                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
+  int n = rainsplit_hint;
+  if (n <= 0) {   // the reference's yakl::intrinsics::minval (:389-390): one 8-byte read-back
+    double dt_max;
+    if (int rc = kessler_read_dt_max((const double *)slot, s, &dt_max)) return rc;
+    const double want = ceil(dt / dt_max);
+    if (!(want < 1.e6)) return pam_amd_set_last_error_(PAM_AMD_ESTATE, "kessler: more than 1e6 sedimentation sub-cycles requested");
+    n = (int)want;
+    if (n < 1) n = 1;
+  }
+  hipLaunchKernelGGL(kessler_column_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
+                     rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, cp_d, p0);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  if (rainsplit) *rainsplit = n;
   return PAM_AMD_OK;
 }

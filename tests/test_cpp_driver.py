@@ -64,3 +64,54 @@ def test_cpp_driver_matches_oracle(tmp_path, mode_a):
     for i, e in enumerate(exp):
         tol = 1e-12 if i in (0, 4, 5 + idwv) else 1e-9
         assert np.abs(raw[i] - e).max() <= tol * max(np.abs(e).max(), 1e-300), i
+
+
+@pytest.mark.gpu
+def test_cpp_driver_crm_loop_dycore_sponge_kessler(tmp_path):
+    """The CRM step loop of the reference driver minus SGS (driver.cpp:248-253): dycore -> sponge_layer -> Kessler
+    micro, all three through their C++ plug-in mirrors, against the same sequence of oracle calls."""
+    from oracle import awfl_oracle as ao
+    nens, nx, ny, nz, nsteps, crm_dt = 4, 8, 1, 20, 3, 4.0
+    tr = (("water_vapor", True, True), ("cloud_liquid", True, True), ("precip_liquid", True, True))
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    consts = dict(R_d=287.0, cp_d=1003.0, R_v=461.0, cp_v=1859.0, p0=1.0e5, grav=9.81)    # Microphysics.h:66-71
+    zint = idz.stretched_interfaces(nz, 15000.0)
+    zi = np.ascontiguousarray(np.broadcast_to(zint[:, None], (nz + 1, nens)))
+    zm = 0.5 * (zi[:-1] + zi[1:])
+    xlen, ylen = nx * 500.0, ny * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5, consts=consts)
+    f["tracers"][0] *= 1.0 + 0.5 * np.cos(np.arange(nx))[None, None, :, None] ** 2       # supersaturate some columns
+    f["tracers"][2][0:8] = 2e-3 * f["density_dry"][0:8]                                    # rain that reaches the ground
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as fh:
+        fh.write(struct.pack("<8q", nens, nx, ny, nz, 3, nsteps, 1 | 2 | 4, 0))
+        fh.write(struct.pack("<3d", xlen, ylen, crm_dt))
+        fh.write(struct.pack("<6d", *([0.0] * 6)))
+        fh.write(np.asarray(zint, dtype="<f8").tobytes())
+        fh.write(bytes(bytearray([1, 1] * 3)))
+        fh.write(struct.pack("<q", idwv))
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            fh.write(f[k].astype("<f8").tobytes())
+        for t in range(3):
+            fh.write(f["tracers"][t].astype("<f8").tobytes())
+    r = subprocess.run([DRIVER, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(outp, dtype="<f8")
+    ncell = nz * ny * nx * nens
+    got = raw[:8 * ncell].reshape(8, nz, ny, nx, nens)
+    got_precl = raw[8 * ncell:].reshape(ny, nx, nens)
+    o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), pos, mass, idwv, consts=consts)
+    o.declare_current_profile_as_hydrostatic(f)
+    for _ in range(nsteps):
+        o.time_step(f, crm_dt)
+        ao.sponge_layer(f, zi, zm, crm_dt)
+        trc = [np.ascontiguousarray(f["tracers"][t]) for t in range(3)]
+        precl, _ = ao.kessler(trc[0], trc[1], trc[2], f["density_dry"], f["temp"], zm, crm_dt, consts)
+        for t in range(3):
+            f["tracers"][t] = trc[t]
+    exp = [f["density_dry"], f["uvel"], f["vvel"], f["wvel"], f["temp"]] + [f["tracers"][t] for t in range(3)]
+    assert precl.max() > 0 and f["tracers"][1].max() > 0      # it rained and cloud formed
+    for i, e in enumerate(exp):
+        tol = 1e-11 if i in (0, 4, 5) else 1e-8
+        assert np.abs(got[i] - e).max() <= tol * max(np.abs(e).max(), 1e-300), i
+    assert np.abs(got_precl - precl).max() <= 1e-10 * precl.max()
