@@ -124,8 +124,9 @@ int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 /* flux-kernel tuning knobs; results do not depend on them.
- *   segment: faces per chunk = LDS face slots per thread (default 8; 1..16)
- *   span:    faces swept by one thread (0 = automatic: the whole line/column when the ensemble fills the chip) */
+ *   segment: shortest span a line may be cut into when the ensemble alone does not fill the chip (default 8; 1..32)
+ *   span:    faces swept by one thread, at most 32 = the thread's LDS slots (0 = automatic: the whole 32-cell line /
+ *            half of a 61-face column when the ensemble fills the chip) */
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
 int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
 /* Ensemble chunking inside one handle: the members are split into `chunks` contiguous ranges advanced on internal HIP

@@ -42,6 +42,8 @@ namespace pama {
 constexpr int HS = 3;          // ghost levels (Dycore.h:23)
 constexpr int MAXT = 50;       // pam_const.h:24 max_fields
 constexpr int FLUX_THREADS = 256;
+constexpr int FLUX_WAVES = FLUX_THREADS / 64;
+constexpr int FLUX_MAX_SPAN = 32; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
 constexpr int VZ_STRIDE = 38;  // per-level vertical table in difference form (struct DTable)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
@@ -287,17 +289,19 @@ PAMA_D int wrap(int c, int n) {
 
 // Body of the reconstruction + flux kernel for one thread.
 //   DIR      sweep direction; item = flattened (line, iens)
-//   f0,span  this thread sweeps the faces f0 .. min(f0+span, nfaces)-1 of its line (a whole 32-cell line or a whole
-//            60-level column when the ensemble is large enough to fill the chip with such threads)
+//   f0,span  this thread sweeps the faces f0 .. min(f0+span, nfaces)-1 of its line (span <= FLUX_MAX_SPAN: a whole 32-cell
+//            line, or half of a 60-level column)
 //   lds      per-thread private slots (stride nthr doubles, conflict-free ds_read/write_b64):
-//              lds[(2*s+0)*nthr + tid] = mass flux of face cf0+s, lds[(2*s+1)*nthr + tid] = face pressure   (s < seg)
-//              lds[(2*seg + v)*nthr + tid] = right-edge value of the last cell of the previous chunk, per swept
-//                                            quantity v (0 rho*u_n, 1 p, 2.. advected fields)
-// The span is processed in chunks of P.seg faces: per chunk first the acoustic pair, then one advected field at a
-// time, each with a 5-cell sliding window in registers.  Every cell polynomial is computed once and evaluated at both
-// edges; the right-edge value of a chunk's last cell is carried to the next chunk through the thread's LDS slot, so
-// the only redundant polynomial is the one of cell f0-1 at the start of the span ((span+1)/span work: 33/32 for a
-// whole line, against 9/8 when every 8-face segment starts from scratch).
+//              lds[s*nthr + tid] = mass flux of face f0+s   (s < span)
+// The span is swept once per quantity with a 5-cell sliding window in registers, so every state value is loaded once
+// per sweep (plus the 5-cell overlap at the start of a span):
+//   pass 1   rho*u_n, p and u_n together: the acoustic pair gives the face mass flux ruf and face pressure ppf
+//            (Dycore.h:341-366); ruf goes to flux field 0 and to the thread's LDS slots; the normal-momentum flux
+//            ruf*upwind(u_n) + ppf is finished in the same pass, so ppf never needs storing;
+//   pass 2.. one advected field at a time (the other velocity components, theta, tracers), upwinded by the ruf read back
+//            from LDS (Dycore.h:367-385).
+// Every cell polynomial is computed once and evaluated at both edges; the only redundant polynomial is the one of cell
+// f0-1 at the start of the span ((span+1)/span work).
 // Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
 // with vertical ghosts already filled (Dycore.h:662-710).
 template <int DIR, bool VZ_PER_ENS>
@@ -324,7 +328,6 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive
   const double cs = 350.0, rcs = 1.0 / 350.0;                        // Dycore.h:335
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
-  double *carry = lds + (long long)2 * P.seg * nthr;
 
   auto cell_off = [&](int c) -> long long {
     if (DIR == 2) return pbase + (long long)(c > P.nz + 2 ? P.nz + 2 : c) * g.cs;   // ghosts exist for c in [-3, nz+2]
@@ -335,87 +338,86 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   };
   const long long vts = VZ_PER_ENS ? (long long)P.nens : 1;
   const int nadv = 4 + P.nt;
+  const int cstart = f0 - 1;                                           // the sweep also builds cell f0-1
+  double *ruf_slot = lds + tid;
 
-  for (int cf0 = f0; cf0 < fend; cf0 += P.seg) {
-    const int flast = (cf0 + P.seg < fend) ? cf0 + P.seg : fend;       // exclusive
-    const bool first = (cf0 == f0);
-    const int cstart = first ? cf0 - 1 : cf0;                          // the first chunk also builds cell f0-1
-    // ---------------- acoustic part: mass flux and pressure at the faces (Dycore.h:341-366) -------------
-    {
-      const double *pr = prim + (long long)P_RHO * P.prim_fs;
-      const double *pn = prim + (long long)ncomp * P.prim_fs;
-      const double *pp = prim + (long long)P_PRES * P.prim_fs;
-      double wm[5], wp[5];   // windows: rho*u_n product and pressure, cells c-2..c+2
-      int c = cstart;
+  // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
+  {
+    const double *pr = prim + (long long)P_RHO * P.prim_fs;
+    const double *pn = prim + (long long)ncomp * P.prim_fs;
+    const double *pp = prim + (long long)P_PRES * P.prim_fs;
+    double *fl0 = flux + fbase;
+    double *fln = flux + (long long)(1 + ncomp - P_U) * g.fs_flux + fbase;
+    double wm[5], wp[5], wn[5];   // windows: rho*u_n product, pressure, u_n; cells c-2..c+2
+    int c = cstart;
 #pragma unroll
-      for (int s = 0; s < 5; s++) {
-        long long o = cell_off(c - 2 + s);
-        wm[s] = pr[o] * pn[o];
-        wp[s] = pp[o];
-      }
-      double prevR_m = first ? 0.0 : carry[0 * nthr + tid];
-      double prevR_p = first ? 0.0 : carry[1 * nthr + tid];
-      for (; c < flast; c++) {
-        long long on = cell_off(c + 3);                    // prefetch the next cell entering the window
-        double nm = pr[on] * pn[on], np_ = pp[on];
-        double Lm, Rm, Lp, Rp;
-        if (DIR == 2) {
-          weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
-          weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
-        } else {
-          weno5_const(wm, wc, Lm, Rm);
-          weno5_const(wp, wc, Lp, Rp);
-        }
-        if (c >= cf0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
-          double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
-          bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
-          if (wall) { ru_L = 0.0; ru_R = 0.0; }
-          double w1 = 0.5 * (pp_R - cs * ru_R);
-          double w2 = 0.5 * (pp_L + cs * ru_L);
-          double ppf = w1 + w2;
-          double ruf = (w2 - w1) * rcs;
-          if (wall) ruf = 0.0;
-          flux[fbase + (long long)c * g.cs] = ruf;            // flux field 0
-          lds[(2 * (c - cf0) + 0) * nthr + tid] = ruf;
-          lds[(2 * (c - cf0) + 1) * nthr + tid] = ppf;
-        }
-        prevR_m = Rm; prevR_p = Rp;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; }
-        wm[4] = nm; wp[4] = np_;
-      }
-      carry[0 * nthr + tid] = prevR_m;
-      carry[1 * nthr + tid] = prevR_p;
+    for (int s = 0; s < 5; s++) {
+      long long o = cell_off(c - 2 + s);
+      wn[s] = pn[o];
+      wm[s] = pr[o] * wn[s];
+      wp[s] = pp[o];
     }
-    // ---------------- advected quantities, one field at a time (Dycore.h:367-385) -----------------------
-    for (int a = 0; a < nadv; a++) {
-      const int pf = P_U + a;                 // prim field
-      const double *q = prim + (long long)pf * P.prim_fs;
-      double *fl = flux + (long long)(1 + a) * g.fs_flux;
-      const bool addp = (pf == ncomp);
-      double w[5];
-      int c = cstart;
-#pragma unroll
-      for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
-      double prevR = first ? 0.0 : carry[(2 + a) * nthr + tid];
-      for (; c < flast; c++) {
-        double nq = q[cell_off(c + 3)];
-        double L, R;
-        if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
-        else weno5_const(w, wc, L, R);
-        if (c >= cf0) {
-          double ruf = lds[(2 * (c - cf0) + 0) * nthr + tid];
-          double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
-          double f = ruf * val;
-          if (addp) f += lds[(2 * (c - cf0) + 1) * nthr + tid];
-          fl[fbase + (long long)c * g.cs] = f;
-        }
-        prevR = R;
-#pragma unroll
-        for (int s = 0; s < 4; s++) w[s] = w[s + 1];
-        w[4] = nq;
+    double prevR_m = 0.0, prevR_p = 0.0, prevR_n = 0.0;
+    for (; c < fend; c++) {
+      long long on = cell_off(c + 3);                    // the next cell entering the window
+      double nn = pn[on], nm = pr[on] * nn, np_ = pp[on];
+      double Lm, Rm, Lp, Rp, Ln, Rn;
+      if (DIR == 2) {
+        weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
+        weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
+        weno5_table(wn, vtab(c), vts, wc, Ln, Rn);
+      } else {
+        weno5_const(wm, wc, Lm, Rm);
+        weno5_const(wp, wc, Lp, Rp);
+        weno5_const(wn, wc, Ln, Rn);
       }
-      carry[(2 + a) * nthr + tid] = prevR;
+      if (c >= f0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
+        double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
+        bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
+        if (wall) { ru_L = 0.0; ru_R = 0.0; }
+        double w1 = 0.5 * (pp_R - cs * ru_R);
+        double w2 = 0.5 * (pp_L + cs * ru_L);
+        double ppf = w1 + w2;
+        double ruf = (w2 - w1) * rcs;
+        if (wall) ruf = 0.0;
+        fl0[(long long)c * g.cs] = ruf;                       // flux field 0
+        ruf_slot[(c - f0) * nthr] = ruf;
+        double val = (ruf > 0.0) ? prevR_n : Ln;              // upwind (Dycore.h:368)
+        double f = ruf * val;
+        f += ppf;
+        fln[(long long)c * g.cs] = f;
+      }
+      prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
+#pragma unroll
+      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
+      wm[4] = nm; wp[4] = np_; wn[4] = nn;
+    }
+  }
+  // ---------------- the other advected quantities, one field at a time (Dycore.h:367-385) -----------------------
+  for (int a = 0; a < nadv; a++) {
+    const int pf = P_U + a;                 // prim field
+    if (pf == ncomp) continue;
+    const double *q = prim + (long long)pf * P.prim_fs;
+    double *fl = flux + (long long)(1 + a) * g.fs_flux + fbase;
+    double w[5];
+    int c = cstart;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
+    double prevR = 0.0;
+    for (; c < fend; c++) {
+      double nq = q[cell_off(c + 3)];
+      double L, R;
+      if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
+      else weno5_const(w, wc, L, R);
+      if (c >= f0) {
+        double ruf = ruf_slot[(c - f0) * nthr];
+        double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
+        fl[(long long)c * g.cs] = ruf * val;
+      }
+      prevR = R;
+#pragma unroll
+      for (int s = 0; s < 4; s++) w[s] = w[s + 1];
+      w[4] = nq;
     }
   }
 }

@@ -69,8 +69,7 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Dispatch order: the z-sweep workgroups first (a whole 61-face column per thread: the longest work items), then
-  // the x/y sweeps -- longest-first scheduling shortens the tail of the launch.
+  // Dispatch order: the z-sweep workgroups first, then the x/y sweeps.
   int b = (int)blockIdx.x - G.nbz;
   if (b < 0) b += G.nbx + G.nby + G.nbz;      // blockIdx < nbz  ->  logical index in [nbx+nby, nbx+nby+nbz)
   // x- and y-sweeps read the same horizontal slab of the state: when their workgroups tile the levels evenly they are
@@ -81,19 +80,19 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
     b = (r < G.nbx_l) ? lev * G.nbx_l + r : G.nbx + lev * G.nby_l + (r - G.nbx_l);
   }
   if (b < G.nbx) {
-    const long long u = (long long)b * 4 + wave;
+    const long long u = (long long)b * FLUX_WAVES + wave;
     const long long item = (u / G.nsx) * 64 + lane;
     if (u < G.nux && item < (long long)P.nz * P.ny * R.ne)
       flux_line_body<0, VZ_PER_ENS>(P, prim, fx, to_global(item, P.nens, R), (int)(u % G.nsx) * G.spx, G.spx, lds,
                                     FLUX_THREADS, tid);
   } else if (b < G.nbx + G.nby) {
-    const long long u = (long long)(b - G.nbx) * 4 + wave;
+    const long long u = (long long)(b - G.nbx) * FLUX_WAVES + wave;
     const long long item = (u / G.nsy) * 64 + lane;
     if (u < G.nuy && item < (long long)P.nz * P.nx * R.ne)
       flux_line_body<1, VZ_PER_ENS>(P, prim, fy, to_global(item, P.nens, R), (int)(u % G.nsy) * G.spy, G.spy, lds,
                                     FLUX_THREADS, tid);
   } else {
-    const long long u = (long long)(b - G.nbx - G.nby) * 4 + wave;
+    const long long u = (long long)(b - G.nbx - G.nby) * FLUX_WAVES + wave;
     const long long item = (u / G.nsz) * 64 + lane;
     if (u < G.nuz && item < (long long)P.ny * P.nx * R.ne)
       flux_line_body<2, VZ_PER_ENS>(P, prim, fz, to_global(item, P.nens, R), (int)(u % G.nsz) * G.spz, G.spz, lds,
@@ -108,7 +107,6 @@ __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, con
   CellId c;
   if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, dt, c);
 }
-
 template <int STAGE>
 __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, const double *prim_in,
                                                           const double *prim0, double *prim_out,
@@ -118,7 +116,6 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
   CellId c;
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
-
 __global__ void __launch_bounds__(256) awfl_init_thermal_kernel(Params P, EnsRange R, double xlen, double ylen, double cp_d,
                                                                 double p0, const double *__restrict__ zmid,
                                                                 double *__restrict__ rho_d, double *__restrict__ u,
@@ -324,20 +321,22 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
   return PAM_AMD_OK;
 }
 
-// Span (faces per thread) of one sweep: the whole line if that still leaves enough wavefronts to fill the chip
-// (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail), otherwise the line is cut into equal spans, rounded
-// up to whole chunks, down to one chunk per thread.  `span_override` > 0 forces a value (tests / tuning).
-static void choose_span(int nfaces, long long nitems, int seg, int span_override, int &span, int &nspan, long long &nunits) {
+// Span (faces per thread) of one sweep: the longest piece of the line that fits the thread's LDS slots
+// (FLUX_MAX_SPAN faces: a whole 32-cell line, half of a 61-face column) if that still leaves enough wavefronts to fill
+// the chip (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail); otherwise the line is cut further, down to
+// `min_span` faces per thread (each span re-reads a 5-cell overlap and rebuilds one polynomial).  `span_override` > 0
+// forces a value (tests / tuning).
+static void choose_span(int nfaces, long long nitems, int min_span, int span_override, int &span, int &nspan, long long &nunits) {
   const long long nib = (nitems + 63) / 64;
   const long long want_units = 6144;
-  int pieces = 1;
   if (span_override > 0) {
-    span = ((span_override + seg - 1) / seg) * seg;
+    span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
   } else {
-    while (nib * pieces < want_units && ((nfaces + pieces - 1) / pieces) > seg) pieces *= 2;
-    span = (((nfaces + pieces - 1) / pieces + seg - 1) / seg) * seg;
+    int pieces = (nfaces + FLUX_MAX_SPAN - 1) / FLUX_MAX_SPAN;
+    while (nib * pieces < want_units && ((nfaces + pieces - 1) / pieces) > min_span) pieces *= 2;
+    span = (nfaces + pieces - 1) / pieces;
   }
-  if (span < seg) span = seg;
+  if (span < 1) span = 1;
   nspan = (nfaces + span - 1) / span;
   nunits = nib * nspan;
 }
@@ -352,16 +351,18 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) 
   G.nux = (((long long)P.nz * P.ny * r.ne + 63) / 64) * G.nsx;
   G.nuy = P.sim2d ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
   G.nuz = (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz;
-  G.nbx = (int)((G.nux + 3) / 4); G.nby = (int)((G.nuy + 3) / 4); G.nbz = (int)((G.nuz + 3) / 4);
+  G.nbx = (int)((G.nux + FLUX_WAVES - 1) / FLUX_WAVES); G.nby = (int)((G.nuy + FLUX_WAVES - 1) / FLUX_WAVES);
+  G.nbz = (int)((G.nuz + FLUX_WAVES - 1) / FLUX_WAVES);
   G.nbx_l = G.nby_l = 0;
-  if (h->interleave_xy && !P.sim2d && G.nux % (4LL * P.nz) == 0 && G.nuy % (4LL * P.nz) == 0) {
+  if (h->interleave_xy && !P.sim2d && G.nux % ((long long)FLUX_WAVES * P.nz) == 0 && G.nuy % ((long long)FLUX_WAVES * P.nz) == 0) {
     G.nbx_l = G.nbx / P.nz;
     G.nby_l = G.nby / P.nz;
   }
-  // per-thread LDS: 2*seg face slots + one carried edge value per swept quantity (2 acoustic + 4+NT advected)
-  size_t lds_bytes = ((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS * sizeof(double);
+  // per-thread LDS: one mass-flux slot per face of the span
+  int spmax = G.spx > G.spz ? G.spx : G.spz;
+  if (!P.sim2d && G.spy > spmax) spmax = G.spy;
+  size_t lds_bytes = (size_t)spmax * FLUX_THREADS * sizeof(double);
   if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
-  if (lds_bytes > 160 * 1024) return fail(PAM_AMD_EINVAL, "flux kernel: chunk length x tracer count exceeds the 160 KiB LDS of a CU");
   ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
     hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
@@ -594,8 +595,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMemset(h->hy_pres, 0xFF, nzn * 8));
   P.dz = h->dz; P.grav_var = h->grav_var; P.hy_dens = h->hy_dens; P.hy_pres = h->hy_pres; P.vz = h->vz;
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap, or many tracers: one carry
-  // slot per tracer per thread -> 144 KiB at the reference's maximum of 50 tracers)
+  // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
@@ -852,7 +852,7 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h) {
 
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (faces < 1 || faces > 16) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,16] (LDS slots per thread)");
+  if (faces < 1 || faces > FLUX_MAX_SPAN) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,32]");
   h->P.seg = faces;
   return PAM_AMD_OK;
 }

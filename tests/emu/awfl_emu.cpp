@@ -25,14 +25,15 @@ struct Emu {
 
 static void flux_launch(Emu *h, const double *prim) {
   const Params &P = h->P;
-  std::vector<double> lds(((size_t)2 * P.seg + 6 + P.nt) * FLUX_THREADS);
+  std::vector<double> lds((size_t)FLUX_MAX_SPAN * FLUX_THREADS);
   for (int dir = 0; dir < 3; dir++) {
     if (dir == 1 && P.sim2d) continue;
     const int nfaces = dir == 0 ? P.nx : (dir == 1 ? P.ny : P.nz + 1);
     const long long nitems = dir == 0 ? (long long)P.nz * P.ny * P.nens
                                       : (dir == 1 ? (long long)P.nz * P.nx * P.nens : (long long)P.ny * P.nx * P.nens);
     // span as in awfl_kernels.hip::choose_span with an override (h->span; 0 = whole line)
-    int span = h->span > 0 ? ((h->span + P.seg - 1) / P.seg) * P.seg : ((nfaces + P.seg - 1) / P.seg) * P.seg;
+    const int pieces = (nfaces + FLUX_MAX_SPAN - 1) / FLUX_MAX_SPAN;
+    int span = h->span > 0 ? (h->span < FLUX_MAX_SPAN ? h->span : FLUX_MAX_SPAN) : (nfaces + pieces - 1) / pieces;
     const int nspan = (nfaces + span - 1) / span;
     const long long nunits = ((nitems + 63) / 64) * nspan;
     double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());

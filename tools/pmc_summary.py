@@ -15,7 +15,7 @@ from collections import defaultdict
 def short(name):
     for k in ("awfl_flux_kernel", "awfl_update_kernel<1>", "awfl_update_kernel<2>", "awfl_update_kernel<3>",
               "awfl_fct_kernel", "awfl_init_prim_kernel", "awfl_finalize_kernel", "awfl_cfl_kernel", "awfl_hydro_kernel",
-              "awfl_stage_kernel"):
+              "awfl_stage_kernel", "awfl_update_kernel_kt"):
         if k in name:
             return k
     return None
