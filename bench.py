@@ -241,8 +241,9 @@ def main():
                                 "overlap the update kernels (see kernels)",
                         "valu": {"bound": "fp64-valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                 "note": "the kernel is FP64-VALU-bound (SURVEY F5; SQ counters: VALU issuing ~85% of "
-                                         "cycles at the ~2.0 GHz clock held): this is the roofline that binds"}}
+                                 "note": "the kernel is FP64-VALU-bound (SURVEY F5; counters: SQ_INSTS_VALU x 4 cycles "
+                                         "over GRBM_GUI_ACTIVE -> VALU issuing in ~74% of the cycles at the ~2.2 GHz clock "
+                                         "held; profiles/r01_c2_pmc_summary.txt): this is the roofline that binds"}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

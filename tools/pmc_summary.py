@@ -39,6 +39,15 @@ def main():
                 if c == "FETCH_SIZE":
                     extra += "  (x2 gfx950 correction: %.3f GB)" % (2 * mean * 1024 / 1e9)
             print("%-26s %-22s n=%4d mean=%.6g%s" % (k, c, len(v), mean, extra))
+    for k in sorted(acc):
+        a = acc[k]
+        if "GRBM_GUI_ACTIVE" in a and "SQ_INSTS_VALU" in a:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; a 64-lane fp64 VALU instruction occupies its SIMD for 4 cycles;
+            # 256 CUs x 4 SIMDs
+            cyc = sum(a["GRBM_GUI_ACTIVE"]) / len(a["GRBM_GUI_ACTIVE"]) / 8.0
+            inst = sum(a["SQ_INSTS_VALU"]) / len(a["SQ_INSTS_VALU"])
+            print("%-26s derived: %.3g busy cycles per XCD, VALU issue occupancy (4 cycles per wave-instruction, 1024 SIMDs) = %.1f %%"
+                  % (k, cyc, 100.0 * inst * 4.0 / (cyc * 1024.0)))
     if "--flux-json" in sys.argv and "awfl_flux_kernel" in acc:
         import json
         f = acc["awfl_flux_kernel"]
