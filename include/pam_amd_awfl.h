@@ -131,7 +131,7 @@ int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
 int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
 /* Ensemble chunking inside one handle: the members are split into `chunks` contiguous ranges advanced on internal HIP
  * streams (forked from / joined to the handle's stream with events), so that the HBM-bound update kernels of one range
- * overlap the FP64-bound flux kernel of another.  chunks = 0: automatic (1-3, from the number of wavefronts a whole-ensemble flux launch has).
+ * overlap the FP64-bound flux kernel of another.  chunks = 0: automatic (1-16, from the number of wavefronts a whole-ensemble flux launch has).
  * flux_lds_floor_bytes: minimum LDS requested per flux workgroup when chunks > 1 (caps its residency per CU so the
  * other range's blocks can co-reside; default 64 KiB = 2 workgroups per CU).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
