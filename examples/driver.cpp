@@ -17,6 +17,7 @@
 #include <fstream>
 
 #include "dynamics/awfl_amd/Dycore.h"
+#include "modules/gcm_forcing.h"     // compiled here; exercised from Python (tests/test_modules.py)
 #include "modules/sponge_layer.h"
 #include "physics/micro/kessler_amd/Microphysics.h"
 

@@ -46,6 +46,28 @@ int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, double *rho_v, d
 int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, const double *rho_r, const double *rho_dry,
                                   const double *zmid, double dt, double *workspace, void *stream, double *dt_max);
 
+/* modules::compute_gcm_forcing_tendencies(coupler)  (pam_core/modules/gcm_forcing.h:17-210; once per GCM step).
+ * Host arrays of DEVICE pointers, in this order:
+ *   crm[10]   (nz,ny,nx,nens): density_dry, uvel, vvel, temp, water_vapor, cloud_water, ice, cloud_water_num, ice_num, rain_num
+ *   gcm[10]   (nz,nens): gcm_density_dry, gcm_uvel, gcm_vvel, gcm_temp, gcm_water_vapor, gcm_cloud_water, gcm_cloud_ice,
+ *             gcm_num_liq, gcm_num_ice, gcm_num_rain
+ *   tend[14]  (nz,nens): gcm_forcing_tend_{rho_d,uvel,vvel,temp,qtot,qv,ql,qi,rho_v,rho_l,rho_i,nc,ni,nr}
+ * Writes every tend entry except rho_v, rho_l, rho_i (those are diagnostics of the apply step).  Horizontal means are summed
+ * in the reference's serial order (deterministic; the reference uses atomicAdd). */
+int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
+                                double *const *tend, double gcm_physics_dt, void *stream);
+
+/* modules::apply_gcm_forcing_tendencies(coupler)  (gcm_forcing.h:297-440, fill_holes :213-284; every CRM step): adds
+ * tend*crm_dt to the CRM state, clips number concentrations, diagnoses tend rho_v/rho_l/rho_i, and fills negative water
+ * with the reference's multiplicative hole filler (per level; over the whole CRM when a level lacks the mass).
+ *   dz          DEVICE "vertical_cell_dz" (nz,nens)
+ *   workspace   DEVICE scratch of 6*nz*nens + 2*nens + 4 doubles
+ *   mask        out (may be NULL): bit s (0 vapour, 1 liquid, 2 ice) = hole filling ran, bit 4+s = its whole-CRM pass ran
+ * Synchronises `stream` once (the reference's host reads of sum(neg_mass) and neg_too_large). */
+int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, double *const *crm, const double *const *gcm,
+                              double *const *tend, const double *dz, double crm_dt, double gcm_physics_dt, double *workspace,
+                              void *stream, int *mask);
+
 #ifdef __cplusplus
 }
 #endif

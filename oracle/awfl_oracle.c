@@ -1201,3 +1201,145 @@ int awfl_oracle_kessler(int nens, int nx, int ny, int nz, double *rho_v, double 
 #undef A2
   return rainsplit;
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* GCM forcing of the CRM mean state, "next row" N1 (pam_core/modules/gcm_forcing.h).  Sums run in the reference's serial
+ * atomicAdd order: for each (k, iens) over j (outer), i (inner).
+ *   crm[10]   (nz,ny,nx,nens): density_dry, uvel, vvel, temp, water_vapor, cloud_water, ice, cloud_water_num, ice_num, rain_num
+ *   gcm[10]   (nz,nens): gcm_density_dry, gcm_uvel, gcm_vvel, gcm_temp, gcm_water_vapor, gcm_cloud_water, gcm_cloud_ice,
+ *             gcm_num_liq, gcm_num_ice, gcm_num_rain
+ *   tend[14]  (nz,nens): gcm_forcing_tend_{rho_d,uvel,vvel,temp,qtot,qv,ql,qi,rho_v,rho_l,rho_i,nc,ni,nr} */
+enum { GF_RHOD, GF_U, GF_V, GF_T, GF_RV, GF_RL, GF_RI, GF_NC, GF_NI, GF_NR };
+enum { GT_RHOD, GT_U, GT_V, GT_T, GT_QTOT, GT_QV, GT_QL, GT_QI, GT_RV, GT_RL, GT_RI, GT_NC, GT_NI, GT_NR };
+#define K2(k, e) ((size_t)(k) * nens + (e))
+
+/* compute_gcm_forcing_tendencies  (gcm_forcing.h:17-210); writes tend[] except GT_RV, GT_RL, GT_RI */
+void awfl_oracle_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
+                                     double *const *tend, double dt_gcm) {
+  const size_t n2 = (size_t)nz * nens;
+  double *ca[10];
+  for (int f = 0; f < 10; f++) ca[f] = (double *)calloc(n2, sizeof(double));
+  const double r_nx_ny = 1.0 / (nx * ny);
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    const size_t c = C4(k, j, i, e);
+    ca[GF_RHOD][K2(k, e)] += crm[GF_RHOD][c] * r_nx_ny;
+    ca[GF_U][K2(k, e)] += crm[GF_U][c] * r_nx_ny;
+    ca[GF_V][K2(k, e)] += crm[GF_V][c] * r_nx_ny;
+    ca[GF_T][K2(k, e)] += crm[GF_T][c] * r_nx_ny;
+    double tmp_qv = crm[GF_RV][c] / (crm[GF_RHOD][c] + crm[GF_RV][c]);
+    double tmp_ql = crm[GF_RL][c] / (crm[GF_RHOD][c] + crm[GF_RV][c]);
+    double tmp_qi = crm[GF_RI][c] / (crm[GF_RHOD][c] + crm[GF_RV][c]);
+    ca[GF_RV][K2(k, e)] += tmp_qv * r_nx_ny;
+    ca[GF_RL][K2(k, e)] += tmp_ql * r_nx_ny;
+    ca[GF_RI][K2(k, e)] += tmp_qi * r_nx_ny;
+    ca[GF_NC][K2(k, e)] += crm[GF_NC][c] * r_nx_ny;
+    ca[GF_NI][K2(k, e)] += crm[GF_NI][c] * r_nx_ny;
+    ca[GF_NR][K2(k, e)] += crm[GF_NR][c] * r_nx_ny;
+  }
+  const double r_dt_gcm = 1.0 / dt_gcm;
+  for (int k = 0; k < nz; k++) for (int e = 0; e < nens; e++) {
+    const size_t c = K2(k, e);
+    tend[GT_RHOD][c] = (gcm[GF_RHOD][c] - ca[GF_RHOD][c]) * r_dt_gcm;
+    tend[GT_U][c] = (gcm[GF_U][c] - ca[GF_U][c]) * r_dt_gcm;
+    tend[GT_V][c] = (gcm[GF_V][c] - ca[GF_V][c]) * r_dt_gcm;
+    tend[GT_T][c] = (gcm[GF_T][c] - ca[GF_T][c]) * r_dt_gcm;
+    double tmp_qv_gcm = gcm[GF_RV][c] / (gcm[GF_RHOD][c] + gcm[GF_RV][c]);
+    double tmp_ql_gcm = gcm[GF_RL][c] / (gcm[GF_RHOD][c] + gcm[GF_RV][c]);
+    double tmp_qi_gcm = gcm[GF_RI][c] / (gcm[GF_RHOD][c] + gcm[GF_RV][c]);
+    tend[GT_QV][c] = (tmp_qv_gcm - ca[GF_RV][c]) * r_dt_gcm;
+    tend[GT_QL][c] = (tmp_ql_gcm - ca[GF_RL][c]) * r_dt_gcm;
+    tend[GT_QI][c] = (tmp_qi_gcm - ca[GF_RI][c]) * r_dt_gcm;
+    tend[GT_NC][c] = (gcm[GF_NC][c] - ca[GF_NC][c]) * r_dt_gcm;
+    tend[GT_NI][c] = (gcm[GF_NI][c] - ca[GF_NI][c]) * r_dt_gcm;
+    tend[GT_NR][c] = (gcm[GF_NR][c] - ca[GF_NR][c]) * r_dt_gcm;
+    tend[GT_QTOT][c] = tend[GT_QV][c] + tend[GT_QL][c] + tend[GT_QI][c];
+  }
+  for (int f = 0; f < 10; f++) free(ca[f]);
+}
+
+static double yakl_max(double a, double b) { return a > b ? a : b; }   /* yakl::max: NaN in b propagates */
+
+/* fill_holes  (gcm_forcing.h:213-284).  Returns 1 when the whole-CRM fallback ran. */
+static int gcm_fill_holes(int nens, int nx, int ny, int nz, const double *dz, double *rho_x, const double *neg_mass) {
+  const size_t n2 = (size_t)nz * nens;
+  double *pos_mass = (double *)calloc(n2, sizeof(double));
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++)
+    if (rho_x[C4(k, j, i, e)] > 0) pos_mass[K2(k, e)] += rho_x[C4(k, j, i, e)] * dz[K2(k, e)];
+  int neg_too_large = 0;
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    if (i == 0 && j == 0) { if (neg_mass[K2(k, e)] > pos_mass[K2(k, e)]) neg_too_large = 1; }
+    if (pos_mass[K2(k, e)] > 0) {
+      double factor = rho_x[C4(k, j, i, e)] * dz[K2(k, e)] / pos_mass[K2(k, e)];
+      rho_x[C4(k, j, i, e)] = yakl_max(0., rho_x[C4(k, j, i, e)] - (neg_mass[K2(k, e)] * factor) / dz[K2(k, e)]);
+    }
+  }
+  if (neg_too_large) {
+    double *neg_glob = (double *)calloc(nens, sizeof(double)), *pos_glob = (double *)calloc(nens, sizeof(double));
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+      if (i == 0 && j == 0) neg_glob[e] += yakl_max(0., neg_mass[K2(k, e)] - pos_mass[K2(k, e)]);
+      pos_glob[e] += rho_x[C4(k, j, i, e)] * dz[K2(k, e)];
+    }
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+      double factor = rho_x[C4(k, j, i, e)] * dz[K2(k, e)] / pos_glob[e];
+      rho_x[C4(k, j, i, e)] = yakl_max(0., rho_x[C4(k, j, i, e)] - (neg_glob[e] * factor) / dz[K2(k, e)]);
+    }
+    free(neg_glob); free(pos_glob);
+  }
+  free(pos_mass);
+  return neg_too_large;
+}
+
+/* apply_gcm_forcing_tendencies  (gcm_forcing.h:297-440).  crm[] updated in place; tend[GT_RV..GT_RI] written.
+ * Returns a bit mask: bit s (0 vapour, 1 liquid, 2 ice) = hole filling ran, bit 4+s = its whole-CRM fallback ran. */
+int awfl_oracle_gcm_forcing_apply(int nens, int nx, int ny, int nz, double *const *crm, const double *const *gcm,
+                                  double *const *tend, const double *dz, double dt, double dt_gcm) {
+  const size_t n2 = (size_t)nz * nens;
+  double *neg[3], *colavg[3];
+  for (int s = 0; s < 3; s++) { neg[s] = (double *)calloc(n2, sizeof(double)); colavg[s] = (double *)calloc(n2, sizeof(double)); }
+  const double r_nx_ny = 1.0 / (nx * ny);
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    const size_t c = C4(k, j, i, e), c2 = K2(k, e);
+    double rho_d_old = crm[GF_RHOD][c];
+    crm[GF_RHOD][c] += tend[GT_RHOD][c2] * dt;
+    crm[GF_U][c] += tend[GT_U][c2] * dt;
+    crm[GF_V][c] += tend[GT_V][c2] * dt;
+    crm[GF_T][c] += tend[GT_T][c2] * dt;
+    double tmp_qv_old = crm[GF_RV][c] / (rho_d_old + crm[GF_RV][c]);
+    double tmp_ql_old = crm[GF_RL][c] / (rho_d_old + crm[GF_RV][c]);
+    double tmp_qi_old = crm[GF_RI][c] / (rho_d_old + crm[GF_RV][c]);
+    double tmp_qv_new = (tmp_qv_old + tend[GT_QV][c2] * dt);
+    double tmp_ql_new = (tmp_ql_old + tend[GT_QL][c2] * dt);
+    double tmp_qi_new = (tmp_qi_old + tend[GT_QI][c2] * dt);
+    crm[GF_RV][c] = tmp_qv_new * crm[GF_RHOD][c] / (1 - tmp_qv_new);
+    crm[GF_RL][c] = tmp_ql_new * (crm[GF_RHOD][c] + crm[GF_RV][c]);
+    crm[GF_RI][c] = tmp_qi_new * (crm[GF_RHOD][c] + crm[GF_RV][c]);
+    crm[GF_NC][c] += tend[GT_NC][c2] * dt;
+    crm[GF_NI][c] += tend[GT_NI][c2] * dt;
+    crm[GF_NR][c] += tend[GT_NR][c2] * dt;
+    if (crm[GF_NC][c] < 0) crm[GF_NC][c] = 0;
+    if (crm[GF_NI][c] < 0) crm[GF_NI][c] = 0;
+    if (crm[GF_NR][c] < 0) crm[GF_NR][c] = 0;
+    for (int s = 0; s < 3; s++) {
+      colavg[s][c2] += crm[GF_RV + s][c] * r_nx_ny;
+    }
+    for (int s = 0; s < 3; s++)
+      if (crm[GF_RV + s][c] < 0) {
+        neg[s][c2] += -crm[GF_RV + s][c] * dz[c2];
+        crm[GF_RV + s][c] = 0;
+      }
+  }
+  const double r_dt_gcm = 1.0 / dt_gcm;
+  for (size_t c2 = 0; c2 < n2; c2++)
+    for (int s = 0; s < 3; s++) tend[GT_RV + s][c2] = (gcm[GF_RV + s][c2] - colavg[s][c2]) * r_dt_gcm;
+  int mask = 0;
+  for (int s = 0; s < 3; s++) {
+    double sum = 0;
+    for (size_t c2 = 0; c2 < n2; c2++) sum += neg[s][c2];
+    if (sum > 0) {
+      mask |= 1 << s;
+      if (gcm_fill_holes(nens, nx, ny, nz, dz, crm[GF_RV + s], neg[s])) mask |= 16 << s;
+    }
+  }
+  for (int s = 0; s < 3; s++) { free(neg[s]); free(colavg[s]); }
+  return mask;
+}

@@ -63,6 +63,9 @@ def load(path=None):
     lib.awfl_oracle_set_flux_taps.argtypes = [C.c_void_p, _DP, _DP, _DP]
     lib.awfl_oracle_init_thermal.argtypes = [C.c_void_p, _DP] + [_DP] * 6
     lib.awfl_oracle_init_supercell.argtypes = [C.c_void_p, _DP, _DP] + [_DP] * 6
+    lib.awfl_oracle_gcm_forcing_compute.argtypes = [C.c_int] * 4 + [C.POINTER(_DP)] * 3 + [C.c_double]
+    lib.awfl_oracle_gcm_forcing_apply.restype = C.c_int
+    lib.awfl_oracle_gcm_forcing_apply.argtypes = [C.c_int] * 4 + [C.POINTER(_DP)] * 3 + [_DP, C.c_double, C.c_double]
     lib.awfl_oracle_kessler.restype = C.c_int
     lib.awfl_oracle_kessler.argtypes = [C.c_int] * 4 + [_DP] * 7 + [C.c_double] * 5 + [C.c_int]
     lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
@@ -252,3 +255,38 @@ def kessler(rho_v, rho_c, rho_r, rho_dry, temp, zmid, dt, consts, rainsplit=0, l
     n = lib.awfl_oracle_kessler(nens, nx, ny, nz, _p(rho_v), _p(rho_c), _p(rho_r), _p(rho_dry), _p(temp), _p(precl), _p(zm),
                                 float(dt), consts["R_d"], consts["R_v"], consts["cp_d"], consts["p0"], int(rainsplit))
     return precl, n
+
+
+GCM_FORCING_CRM = ("density_dry", "uvel", "vvel", "temp", "water_vapor", "cloud_water", "ice", "cloud_water_num", "ice_num",
+                   "rain_num")
+GCM_FORCING_GCM = ("gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_temp", "gcm_water_vapor", "gcm_cloud_water", "gcm_cloud_ice",
+                   "gcm_num_liq", "gcm_num_ice", "gcm_num_rain")
+GCM_FORCING_TEND = tuple("gcm_forcing_tend_" + n for n in ("rho_d", "uvel", "vvel", "temp", "qtot", "qv", "ql", "qi", "rho_v",
+                                                           "rho_l", "rho_i", "nc", "ni", "nr"))
+
+
+def _ptrs(d, names):
+    arrs = [d[n] for n in names]
+    for a in arrs:
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == np.float64
+    return (_DP * len(arrs))(*[_p(a) for a in arrs])
+
+
+def compute_gcm_forcing_tendencies(crm, gcm, dt_gcm, lib=None):
+    """modules::compute_gcm_forcing_tendencies (pam_core/modules/gcm_forcing.h:17-210).  crm: dict name -> (nz,ny,nx,nens),
+    gcm: dict name -> (nz,nens).  Returns the dict of the 14 gcm_forcing_tend_* arrays (rho_v/l/i still zero)."""
+    lib = lib or load()
+    nz, ny, nx, nens = crm["density_dry"].shape
+    tend = {n: np.zeros((nz, nens)) for n in GCM_FORCING_TEND}
+    lib.awfl_oracle_gcm_forcing_compute(nens, nx, ny, nz, _ptrs(crm, GCM_FORCING_CRM), _ptrs(gcm, GCM_FORCING_GCM),
+                                        _ptrs(tend, GCM_FORCING_TEND), float(dt_gcm))
+    return tend
+
+
+def apply_gcm_forcing_tendencies(crm, gcm, tend, dz, crm_dt, dt_gcm, lib=None):
+    """modules::apply_gcm_forcing_tendencies (gcm_forcing.h:297-440), crm updated in place.  Returns the hole-filling mask."""
+    lib = lib or load()
+    nz, ny, nx, nens = crm["density_dry"].shape
+    dz = np.ascontiguousarray(dz, dtype=np.float64)
+    return lib.awfl_oracle_gcm_forcing_apply(nens, nx, ny, nz, _ptrs(crm, GCM_FORCING_CRM), _ptrs(gcm, GCM_FORCING_GCM),
+                                             _ptrs(tend, GCM_FORCING_TEND), _p(dz), float(crm_dt), float(dt_gcm))

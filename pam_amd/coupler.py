@@ -150,7 +150,7 @@ class PamCoupler:
         self.dm.register_and_allocate("vertical_cell_dz", "vertical grid spacing", (nz, nens), ("z", "nens"))
         self.dm.register_and_allocate("vertical_midpoint_height", "vertical midpoint height", (nz, nens), ("z", "nens"))
         for name in ("gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_wvel", "gcm_temp", "gcm_water_vapor",
-                     "gcm_cloud_water", "gcm_cloud_ice"):
+                     "gcm_cloud_water", "gcm_cloud_ice", "gcm_num_liq", "gcm_num_ice", "gcm_num_rain"):   # pam_coupler.h:271-281
             self.dm.register_and_allocate(name, "GCM column " + name[4:], (nz, nens), ("z", "nens"))
 
     def set_grid(self, xlen, ylen, zint_in):

@@ -169,7 +169,8 @@ class PamCoupler {
     dm.register_and_allocate<real>("vertical_interface_height", "", {nz + 1, nens}, {"zp1", "nens"});
     dm.register_and_allocate<real>("vertical_cell_dz", "", {nz, nens}, {"z", "nens"});
     dm.register_and_allocate<real>("vertical_midpoint_height", "", {nz, nens}, {"z", "nens"});
-    for (auto n : {"gcm_density_dry", "gcm_temp", "gcm_water_vapor", "gcm_cloud_water", "gcm_cloud_ice"})
+    for (auto n : {"gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_wvel", "gcm_temp", "gcm_water_vapor", "gcm_cloud_water",
+                   "gcm_cloud_ice", "gcm_num_liq", "gcm_num_ice", "gcm_num_rain"})   // pam_coupler.h:270-281
       dm.register_and_allocate<real>(n, "", {nz, nens}, {"z", "nens"});
   }
 

@@ -176,6 +176,158 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
   precl[col] = pr / (double)rainsplit;                                            // :452
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// GCM forcing of the CRM mean state (pam_core/modules/gcm_forcing.h).  The reference accumulates its horizontal means
+// and hole-filling masses with atomicAdd; here one thread owns one (level, member) pair and walks its ny*nx cells in the
+// reference's serial order (j outer, i inner), so every sum is deterministic and equal to the serial reference's.
+// Consecutive lanes are consecutive members: each step of the walk is one coalesced row per field.
+struct Gcm10 { double *p[10]; };
+struct Gcm14 { double *p[14]; };
+enum { GF_RHOD, GF_U, GF_V, GF_T, GF_RV, GF_RL, GF_RI, GF_NC, GF_NI, GF_NR };
+enum { GT_RHOD, GT_U, GT_V, GT_T, GT_QTOT, GT_QV, GT_QL, GT_QI, GT_RV, GT_RL, GT_RI, GT_NC, GT_NI, GT_NR };
+
+__device__ __forceinline__ double yakl_max(double a, double b) { return a > b ? a : b; }   // NaN in b propagates, as yakl::max
+
+// compute_gcm_forcing_tendencies (gcm_forcing.h:17-210)
+__global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+                                                                 double r_dt_gcm) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nz * nens) return;
+  const int e = (int)(t % nens), k = (int)(t / nens);
+  const double r_nx_ny = 1.0 / (nx * ny);
+  double ca[10];
+#pragma unroll
+  for (int f = 0; f < 10; f++) ca[f] = 0;
+  const long long base = (long long)k * ny * nx * nens + e;
+  for (int c = 0; c < ny * nx; c++) {
+    const long long o = base + (long long)c * nens;
+    const double rd = crm.p[GF_RHOD][o], rv = crm.p[GF_RV][o];
+    ca[GF_RHOD] += rd * r_nx_ny;
+    ca[GF_U] += crm.p[GF_U][o] * r_nx_ny;
+    ca[GF_V] += crm.p[GF_V][o] * r_nx_ny;
+    ca[GF_T] += crm.p[GF_T][o] * r_nx_ny;
+    ca[GF_RV] += (rv / (rd + rv)) * r_nx_ny;
+    ca[GF_RL] += (crm.p[GF_RL][o] / (rd + rv)) * r_nx_ny;
+    ca[GF_RI] += (crm.p[GF_RI][o] / (rd + rv)) * r_nx_ny;
+    ca[GF_NC] += crm.p[GF_NC][o] * r_nx_ny;
+    ca[GF_NI] += crm.p[GF_NI][o] * r_nx_ny;
+    ca[GF_NR] += crm.p[GF_NR][o] * r_nx_ny;
+  }
+  tend.p[GT_RHOD][t] = (gcm.p[GF_RHOD][t] - ca[GF_RHOD]) * r_dt_gcm;
+  tend.p[GT_U][t] = (gcm.p[GF_U][t] - ca[GF_U]) * r_dt_gcm;
+  tend.p[GT_V][t] = (gcm.p[GF_V][t] - ca[GF_V]) * r_dt_gcm;
+  tend.p[GT_T][t] = (gcm.p[GF_T][t] - ca[GF_T]) * r_dt_gcm;
+  const double den = gcm.p[GF_RHOD][t] + gcm.p[GF_RV][t];
+  const double tqv = (gcm.p[GF_RV][t] / den - ca[GF_RV]) * r_dt_gcm;
+  const double tql = (gcm.p[GF_RL][t] / den - ca[GF_RL]) * r_dt_gcm;
+  const double tqi = (gcm.p[GF_RI][t] / den - ca[GF_RI]) * r_dt_gcm;
+  tend.p[GT_QV][t] = tqv; tend.p[GT_QL][t] = tql; tend.p[GT_QI][t] = tqi;
+  tend.p[GT_NC][t] = (gcm.p[GF_NC][t] - ca[GF_NC]) * r_dt_gcm;
+  tend.p[GT_NI][t] = (gcm.p[GF_NI][t] - ca[GF_NI]) * r_dt_gcm;
+  tend.p[GT_NR][t] = (gcm.p[GF_NR][t] - ca[GF_NR]) * r_dt_gcm;
+  tend.p[GT_QTOT][t] = tqv + tql + tqi;
+}
+
+// apply_gcm_forcing_tendencies, main kernel + diagnostics (gcm_forcing.h:361-429) fused with the first two kernels of
+// fill_holes (positive mass per level, "negative too large" test; :236-250).
+//   work: neg[3], pos[3] (nz,nens) ; flags[0..2] = some negative mass for species s, flags[3..5] = negative > positive somewhere
+__global__ void __launch_bounds__(64) gcm_forcing_apply_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+                                                               const double *__restrict__ dz, double dt, double r_dt_gcm,
+                                                               double *__restrict__ work, int *__restrict__ flags) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n2 = (long long)nz * nens;
+  if (t >= n2) return;
+  const int e = (int)(t % nens), k = (int)(t / nens);
+  const double r_nx_ny = 1.0 / (nx * ny);
+  const double dzk = dz[t];
+  const double t_rd = tend.p[GT_RHOD][t] * dt, t_u = tend.p[GT_U][t] * dt, t_v = tend.p[GT_V][t] * dt, t_t = tend.p[GT_T][t] * dt;
+  const double t_qv = tend.p[GT_QV][t] * dt, t_ql = tend.p[GT_QL][t] * dt, t_qi = tend.p[GT_QI][t] * dt;
+  const double t_nc = tend.p[GT_NC][t] * dt, t_ni = tend.p[GT_NI][t] * dt, t_nr = tend.p[GT_NR][t] * dt;
+  double colavg[3] = {0, 0, 0}, neg[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
+  const long long base = (long long)k * ny * nx * nens + e;
+  for (int c = 0; c < ny * nx; c++) {
+    const long long o = base + (long long)c * nens;
+    const double rho_d_old = crm.p[GF_RHOD][o];
+    const double rho_d = rho_d_old + t_rd;
+    crm.p[GF_RHOD][o] = rho_d;
+    crm.p[GF_U][o] += t_u;
+    crm.p[GF_V][o] += t_v;
+    crm.p[GF_T][o] += t_t;
+    const double rv_old = crm.p[GF_RV][o];
+    const double qv_new = rv_old / (rho_d_old + rv_old) + t_qv;
+    const double ql_new = crm.p[GF_RL][o] / (rho_d_old + rv_old) + t_ql;
+    const double qi_new = crm.p[GF_RI][o] / (rho_d_old + rv_old) + t_qi;
+    double w[3];
+    w[0] = qv_new * rho_d / (1 - qv_new);
+    w[1] = ql_new * (rho_d + w[0]);
+    w[2] = qi_new * (rho_d + w[0]);
+    double nc = crm.p[GF_NC][o] + t_nc, ni = crm.p[GF_NI][o] + t_ni, nr = crm.p[GF_NR][o] + t_nr;   // :388-393
+    if (nc < 0) nc = 0;
+    if (ni < 0) ni = 0;
+    if (nr < 0) nr = 0;
+    crm.p[GF_NC][o] = nc; crm.p[GF_NI][o] = ni; crm.p[GF_NR][o] = nr;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      colavg[s] += w[s] * r_nx_ny;
+      if (w[s] < 0) { neg[s] += -w[s] * dzk; w[s] = 0; }
+      if (w[s] > 0) pos[s] += w[s] * dzk;
+      crm.p[GF_RV + s][o] = w[s];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    tend.p[GT_RV + s][t] = (gcm.p[GF_RV + s][t] - colavg[s]) * r_dt_gcm;
+    work[(long long)s * n2 + t] = neg[s];
+    work[(long long)(3 + s) * n2 + t] = pos[s];
+    if (neg[s] > 0) atomicOr(&flags[s], 1);
+    if (neg[s] > pos[s]) atomicOr(&flags[3 + s], 1);
+  }
+}
+
+// fill_holes, level pass (:243-250)
+__global__ void __launch_bounds__(256) gcm_fill_level_kernel(int nens, long long per_level, long long ncell, double *__restrict__ rho_x,
+                                                             const double *__restrict__ dz, const double *__restrict__ neg,
+                                                             const double *__restrict__ pos) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncell) return;
+  const long long t = (idx / per_level) * nens + idx % nens;
+  const double p = pos[t];
+  if (p > 0) {
+    const double d = dz[t], r = rho_x[idx];
+    const double factor = r * d / p;
+    rho_x[idx] = yakl_max(0.0, r - (neg[t] * factor) / d);
+  }
+}
+
+// fill_holes, whole-CRM fallback: per-member sums in serial order (:262-266), one thread per member
+__global__ void __launch_bounds__(64) gcm_fill_glob_sum_kernel(int nens, int nx, int ny, int nz, const double *__restrict__ rho_x,
+                                                               const double *__restrict__ dz, const double *__restrict__ neg,
+                                                               const double *__restrict__ pos, double *__restrict__ glob) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nens) return;
+  double ng = 0, pg = 0;
+  for (int k = 0; k < nz; k++) {
+    const long long t = (long long)k * nens + e;
+    ng += yakl_max(0.0, neg[t] - pos[t]);
+    const double d = dz[t];
+    const long long base = (long long)k * ny * nx * nens + e;
+    for (int c = 0; c < ny * nx; c++) pg += rho_x[base + (long long)c * nens] * d;
+  }
+  glob[e] = ng;
+  glob[nens + e] = pg;
+}
+
+// fill_holes, whole-CRM fallback: removal (:269-272)
+__global__ void __launch_bounds__(256) gcm_fill_glob_kernel(int nens, long long per_level, long long ncell, double *__restrict__ rho_x,
+                                                            const double *__restrict__ dz, const double *__restrict__ glob) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncell) return;
+  const int e = (int)(idx % nens);
+  const double d = dz[(idx / per_level) * nens + e], r = rho_x[idx];
+  const double factor = r * d / glob[nens + e];
+  rho_x[idx] = yakl_max(0.0, r - (glob[e] * factor) / d);
+}
+
 }  // namespace
 
 extern "C" int pam_amd_set_last_error_(int code, const char *msg);   // defined in awfl_kernels.hip
@@ -274,5 +426,79 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   if (rainsplit) *rainsplit = n;
+  return PAM_AMD_OK;
+}
+
+namespace {
+int gcm_check(const char *who, int nens, int nx, int ny, int nz, const void *const *a, int na, const void *const *b, int nb,
+              const void *const *c, int nc) {
+  if (nens < 1 || nx < 1 || ny < 1 || nz < 1 || !a || !b || !c)
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, (std::string(who) + ": bad dimensions or null pointer table").c_str());
+  for (int i = 0; i < na; i++) if (!a[i]) return pam_amd_set_last_error_(PAM_AMD_EINVAL, (std::string(who) + ": null CRM field pointer").c_str());
+  for (int i = 0; i < nb; i++) if (!b[i]) return pam_amd_set_last_error_(PAM_AMD_EINVAL, (std::string(who) + ": null GCM column pointer").c_str());
+  for (int i = 0; i < nc; i++) if (!c[i]) return pam_amd_set_last_error_(PAM_AMD_EINVAL, (std::string(who) + ": null tendency pointer").c_str());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, (std::string(who) + ": no HIP device available (this library has no CPU path)").c_str());
+  return PAM_AMD_OK;
+}
+}  // namespace
+
+extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
+                                           double *const *tend, double gcm_physics_dt, void *stream) {
+  if (int rc = gcm_check("compute_gcm_forcing_tendencies", nens, nx, ny, nz, (const void *const *)crm, 10,
+                         (const void *const *)gcm, 10, (const void *const *)tend, 14)) return rc;
+  if (!(gcm_physics_dt > 0)) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "compute_gcm_forcing_tendencies: gcm_physics_dt must be positive");
+  Gcm10 C, G; Gcm14 T;
+  for (int i = 0; i < 10; i++) { C.p[i] = const_cast<double *>(crm[i]); G.p[i] = const_cast<double *>(gcm[i]); }
+  for (int i = 0; i < 14; i++) T.p[i] = tend[i];
+  const long long n2 = (long long)nz * nens;
+  hipLaunchKernelGGL(gcm_forcing_compute_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, nens, nx, ny, nz,
+                     C, G, T, 1.0 / gcm_physics_dt);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  return PAM_AMD_OK;
+}
+
+extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, double *const *crm, const double *const *gcm,
+                                         double *const *tend, const double *dz, double crm_dt, double gcm_physics_dt,
+                                         double *workspace, void *stream, int *mask_out) {
+  if (int rc = gcm_check("apply_gcm_forcing_tendencies", nens, nx, ny, nz, (const void *const *)crm, 10, (const void *const *)gcm,
+                         10, (const void *const *)tend, 14)) return rc;
+  if (!dz || !workspace) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "apply_gcm_forcing_tendencies: null dz or workspace");
+  if (!(gcm_physics_dt > 0)) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "apply_gcm_forcing_tendencies: gcm_physics_dt must be positive");
+  Gcm10 C, G; Gcm14 T;
+  for (int i = 0; i < 10; i++) { C.p[i] = crm[i]; G.p[i] = const_cast<double *>(gcm[i]); }
+  for (int i = 0; i < 14; i++) T.p[i] = tend[i];
+  hipStream_t s = (hipStream_t)stream;
+  const long long n2 = (long long)nz * nens, per_level = (long long)ny * nx * nens, ncell = per_level * nz;
+  double *glob = workspace + 6 * n2;
+  int *flags = (int *)(glob + 2 * (long long)nens);
+  hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
+  hipLaunchKernelGGL(gcm_forcing_apply_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz, C, G, T, dz,
+                     crm_dt, 1.0 / gcm_physics_dt, workspace, flags);
+  // "Only do the hole filling if there's negative mass" (:432-436) and ScalarLiveOut neg_too_large (:241,:252): one read-back
+  int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
+  int mask = 0;
+  for (int sp = 0; sp < 3; sp++) {
+    if (!h[sp]) continue;
+    mask |= 1 << sp;
+    double *rho_x = crm[GF_RV + sp];
+    const double *neg = workspace + (long long)sp * n2, *pos = workspace + (long long)(3 + sp) * n2;
+    hipLaunchKernelGGL(gcm_fill_level_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, nens, per_level, ncell, rho_x, dz,
+                       neg, pos);
+    if (h[3 + sp]) {
+      mask |= 16 << sp;
+      hipLaunchKernelGGL(gcm_fill_glob_sum_kernel, dim3((unsigned)((nens + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz, rho_x, dz, neg,
+                         pos, glob);
+      hipLaunchKernelGGL(gcm_fill_glob_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, nens, per_level, ncell, rho_x,
+                         dz, glob);
+    }
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  if (mask_out) *mask_out = mask;
   return PAM_AMD_OK;
 }

@@ -27,3 +27,55 @@ def sponge_layer(coupler):
                                        float(coupler.get_option("crm_dt")), int(num_layers), float(time_scale),
                                        work.data_ptr(), torch.cuda.current_stream(coupler.device).cuda_stream))
     return work   # keeps the scratch alive until the caller drops it (the launch is asynchronous)
+
+
+GCM_FORCING_CRM = ("density_dry", "uvel", "vvel", "temp", "water_vapor", "cloud_water", "ice", "cloud_water_num", "ice_num",
+                   "rain_num")
+GCM_FORCING_GCM = ("gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_temp", "gcm_water_vapor", "gcm_cloud_water", "gcm_cloud_ice",
+                   "gcm_num_liq", "gcm_num_ice", "gcm_num_rain")
+GCM_FORCING_TEND = (("rho_d", "dry density"), ("uvel", "u-velocity"), ("vvel", "v-velocity"), ("temp", "temperature"),
+                    ("qtot", "tot water mix ratio"), ("qv", "vap water mix ratio"), ("ql", "liq water mix ratio"),
+                    ("qi", "ice water mix ratio"), ("rho_v", "water vapor density"), ("rho_l", "cloud water density"),
+                    ("rho_i", "cloud ice density"), ("nc", "liq number"), ("ni", "ice number"), ("nr", "rain number"))
+
+
+def _ptr_table(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def compute_gcm_forcing_tendencies(coupler):
+    """modules::compute_gcm_forcing_tendencies(coupler)  (pam_core/modules/gcm_forcing.h:17-210): once per GCM step.
+    Reads option "gcm_physics_dt"; registers the 14 "gcm_forcing_tend_*" (nz,nens) entries on first use (:132-147)."""
+    lib = capi.load()
+    nz, ny, nx, nens = coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens()
+    dm = coupler.get_data_manager_device_readwrite()
+    crm = [dm.get(n, readonly=True) for n in GCM_FORCING_CRM]
+    gcm = [dm.get(n, readonly=True) for n in GCM_FORCING_GCM[:7]] + [dm.get(n) for n in GCM_FORCING_GCM[7:]]   # :51-53 non-const
+    if not dm.entry_exists("gcm_forcing_tend_uvel"):
+        for n, d in GCM_FORCING_TEND:
+            dm.register_and_allocate("gcm_forcing_tend_" + n, "GCM forcing for " + d, (nz, nens), ("z", "nens"))
+    tend = [dm.get("gcm_forcing_tend_" + n) for n, _ in GCM_FORCING_TEND]
+    with torch.cuda.device(coupler.device):
+        check(lib.pam_amd_gcm_forcing_compute(nens, nx, ny, nz, _ptr_table(crm), _ptr_table(gcm), _ptr_table(tend),
+                                              float(coupler.get_option("gcm_physics_dt")),
+                                              torch.cuda.current_stream(coupler.device).cuda_stream))
+
+
+def apply_gcm_forcing_tendencies(coupler):
+    """modules::apply_gcm_forcing_tendencies(coupler)  (gcm_forcing.h:297-440): every CRM step.  Options "crm_dt",
+    "gcm_physics_dt".  Returns the hole-filling mask (bit s: species s filled; bit 4+s: whole-CRM fallback)."""
+    lib = capi.load()
+    nz, ny, nx, nens = coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens()
+    dm = coupler.get_data_manager_device_readwrite()
+    crm = [dm.get(n) for n in GCM_FORCING_CRM]
+    gcm = [dm.get(n, readonly=True) for n in GCM_FORCING_GCM]
+    tend = [dm.get("gcm_forcing_tend_" + n, readonly=n not in ("rho_v", "rho_l", "rho_i")) for n, _ in GCM_FORCING_TEND]
+    dz = dm.get("vertical_cell_dz")
+    work = torch.empty(6 * nz * nens + 2 * nens + 4, dtype=torch.float64, device=coupler.device)
+    mask = C.c_int()
+    with torch.cuda.device(coupler.device):
+        check(lib.pam_amd_gcm_forcing_apply(nens, nx, ny, nz, _ptr_table(crm), _ptr_table(gcm), _ptr_table(tend), dz.data_ptr(),
+                                            float(coupler.get_option("crm_dt")), float(coupler.get_option("gcm_physics_dt")),
+                                            work.data_ptr(), torch.cuda.current_stream(coupler.device).cuda_stream,
+                                            C.byref(mask)))
+    return mask.value   # the call synchronised the stream, so `work` may be dropped

@@ -95,3 +95,114 @@ def test_gpu_dry_crm_step_dycore_then_sponge():
     for k in ("uvel", "wvel"):
         assert np.abs(got[k] - f[k]).max() <= 1e-9 * np.abs(f[k]).max(), k
     dycore.finalize(coupler)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "next row" N1: modules::compute_gcm_forcing_tendencies / apply_gcm_forcing_tendencies (pam_core/modules/gcm_forcing.h)
+P3_TRACERS = idz.TRACERS_P3_SHOC
+
+
+def _gcm_case(nens=3, nx=5, ny=2, nz=8, seed=1, starve_liquid=False, starve_level=False):
+    rng = np.random.default_rng(seed)
+    crm = {n: np.ascontiguousarray(rng.uniform(0.5, 1.5, (nz, ny, nx, nens))) for n in ao.GCM_FORCING_CRM}
+    for n in ("water_vapor", "cloud_water", "ice"):
+        crm[n] *= 0.01
+    crm["ice"][nz // 2:] = 0.0
+    crm["temp"] += 270.0
+    if starve_level:       # every other column has almost no liquid
+        crm["cloud_water"][:, :, ::2] *= 0.02
+    # GCM state close to the CRM's column means (a weak forcing that leaves every cell positive) ...
+    gcm = {g: np.ascontiguousarray(crm[c].mean(axis=(1, 2)) * rng.uniform(0.9, 1.1, (nz, nens)))
+           for g, c in zip(ao.GCM_FORCING_GCM, ao.GCM_FORCING_CRM)}
+    if starve_level:       # ... or asking for half the liquid: the poor columns go negative, their level can pay
+        gcm["gcm_cloud_water"] *= 0.5
+    if starve_liquid:      # ... or for less than nothing at one level: that level cannot pay -> whole-CRM fallback.  (A GCM
+        # column with no liquid anywhere would end in 0/0 = NaN in the reference's fallback, gcm_forcing.h:270.)
+        gcm["gcm_cloud_water"][1] *= -0.2
+    dz = np.ascontiguousarray(rng.uniform(50.0, 400.0, (nz, nens)))
+    return crm, gcm, dz
+
+
+def test_oracle_gcm_forcing_relaxes_column_means_to_the_gcm_state():
+    crm, gcm, dz = _gcm_case()
+    dt_gcm, crm_dt = 1200.0, 300.0
+    tend = ao.compute_gcm_forcing_tendencies(crm, gcm, dt_gcm)
+    assert np.allclose(tend["gcm_forcing_tend_qtot"], tend["gcm_forcing_tend_qv"] + tend["gcm_forcing_tend_ql"] +
+                       tend["gcm_forcing_tend_qi"], rtol=0, atol=1e-18)
+    for _ in range(4):     # forcing alone over one GCM step: state_crm_new == state_gcm (gcm_forcing.h:9-16)
+        ao.apply_gcm_forcing_tendencies(crm, gcm, tend, dz, crm_dt, dt_gcm)
+    for a, b in (("density_dry", "gcm_density_dry"), ("uvel", "gcm_uvel"), ("vvel", "gcm_vvel"), ("temp", "gcm_temp"),
+                 ("cloud_water_num", "gcm_num_liq")):
+        assert np.abs(crm[a].mean(axis=(1, 2)) - gcm[b]).max() < 1e-12 * np.abs(gcm[b]).max(), a
+    # water is forced as a mixing ratio w.r.t. (rho_d + rho_v), which is not linear in the densities: the diagnosed
+    # density forcing left after the last application is small but not zero
+    assert np.abs(tend["gcm_forcing_tend_rho_v"]).max() * dt_gcm < 0.2 * gcm["gcm_water_vapor"].max()
+
+
+GCM_CASES = [({}, 0), ({"starve_level": True}, 2), ({"starve_liquid": True}, 2 | 32)]   # union over the 4 applications
+
+
+@pytest.mark.parametrize("kw,want", GCM_CASES)
+def test_oracle_gcm_forcing_hole_filling_paths(kw, want):
+    crm, gcm, dz = _gcm_case(**kw)
+    tend = ao.compute_gcm_forcing_tendencies(crm, gcm, 1200.0)
+    mask = 0
+    for _ in range(4):
+        mask |= ao.apply_gcm_forcing_tendencies(crm, gcm, tend, dz, 300.0, 1200.0)
+    assert mask == want
+    for n in ("water_vapor", "cloud_water", "ice", "cloud_water_num", "ice_num", "rain_num"):
+        assert crm[n].min() >= 0.0 and np.all(np.isfinite(crm[n])), n
+
+
+def _gcm_gpu_coupler(crm, gcm, dz, dt_gcm, crm_dt):
+    import torch
+    from pam_amd import PamCoupler
+    nz, ny, nx, nens = crm["density_dry"].shape
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", crm_dt)
+    coupler.set_option("gcm_physics_dt", dt_gcm)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    zint = np.concatenate([np.zeros((1, nens)), np.cumsum(dz, axis=0)], axis=0)
+    coupler.set_grid(nx * 500.0, ny * 500.0, zint)
+    for n, p, m in P3_TRACERS:      # registration order of physics/micro/p3/Microphysics.h:119-127 + SHOC's tke
+        coupler.add_tracer(n, "", p, m)
+    dm = coupler.get_data_manager_device_readwrite()
+    for n, a in list(crm.items()) + list(gcm.items()):
+        dm.get(n).copy_(torch.from_numpy(a))
+    return coupler, dm, zint
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,want", GCM_CASES)
+def test_gpu_gcm_forcing_matches_oracle(kw, want):
+    import torch
+    from pam_amd import modules
+    crm, gcm, dz = _gcm_case(nens=70, nx=6, ny=3, nz=9, **kw)
+    dt_gcm, crm_dt = 1200.0, 300.0
+    coupler, dm, zint = _gcm_gpu_coupler(crm, gcm, dz, dt_gcm, crm_dt)
+    dz_used = np.diff(zint, axis=0)       # what set_grid stored (cumsum round trip)
+    dirty = coupler.run_module("compute_gcm_forcing_tendencies", modules.compute_gcm_forcing_tendencies)
+    assert "gcm_forcing_tend_uvel" in dirty and "density_dry" not in dirty
+    tend = ao.compute_gcm_forcing_tendencies(crm, gcm, dt_gcm)
+    for n in tend:
+        if n[-5:] in ("rho_v", "rho_l", "rho_i"):
+            continue
+        got = dm.get(n, readonly=True).cpu().numpy()
+        # a tendency is (gcm - mean)/dt_gcm: its round-off scales with the state, not with the (small) difference
+        scale = max(np.abs(g).max() for g in gcm.values()) / dt_gcm
+        assert np.abs(got - tend[n]).max() <= 1e-14 * scale, n
+    mask = 0
+    for _ in range(4):
+        out = {}
+        coupler.run_module("apply_gcm_forcing_tendencies", lambda c: out.setdefault("m", modules.apply_gcm_forcing_tendencies(c)))
+        mask |= out["m"]
+        mref = ao.apply_gcm_forcing_tendencies(crm, gcm, tend, dz_used, crm_dt, dt_gcm)
+        assert out["m"] == mref
+    torch.cuda.synchronize()
+    assert mask == want
+    for n in ao.GCM_FORCING_CRM:
+        got = dm.get(n, readonly=True).cpu().numpy()
+        assert np.abs(got - crm[n]).max() <= 1e-12 * max(np.abs(crm[n]).max(), 1e-300), n
+    for n in ("gcm_forcing_tend_rho_v", "gcm_forcing_tend_rho_l", "gcm_forcing_tend_rho_i"):
+        got = dm.get(n, readonly=True).cpu().numpy()
+        assert np.abs(got - tend[n]).max() <= 1e-13 * 0.015 / dt_gcm, n
