@@ -68,6 +68,20 @@ int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, double *const *c
                               double *const *tend, const double *dz, double crm_dt, double gcm_physics_dt, double *workspace,
                               void *stream, int *mask);
 
+/* modules::broadcast_initial_gcm_column(coupler)  (pam_core/modules/broadcast_initial_gcm_column.h:8-41): num_fields = 6,
+ * gcm[] = DEVICE (nz,nens) gcm_density_dry, gcm_uvel, gcm_vvel, gcm_wvel, gcm_temp, gcm_water_vapor copied to every column of
+ * crm[] = DEVICE (nz,ny,nx,nens) density_dry, uvel, vvel, wvel, temp, water_vapor.  num_fields = 1 is
+ * broadcast_initial_gcm_column_dry_density (:44-62). */
+int pam_amd_broadcast_initial_gcm_column(int nens, int nx, int ny, int nz, int num_fields, const double *const *gcm,
+                                         double *const *crm, void *stream);
+
+/* modules::perturb_temperature(coupler, id, magnitude)  (pam_core/modules/perturb_temperature.h:10-63): random
+ * perturbation of "temp" in the lowest nz/4 levels, decaying linearly with height, rescaled per level to the
+ * unperturbed horizontal mean.  id: DEVICE int[nens], one stream id per member.  NOT bit-comparable with the reference:
+ * its generator is yakl::Random (third-party, absent from the reference tree); splitmix64 of the reference's seed
+ * formula is used instead -- everything else (seed, range, decay, rescale, summation order) follows the reference. */
+int pam_amd_perturb_temperature(int nens, int nx, int ny, int nz, double *temp, const int *id, double magnitude, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@
  *      elimination without pivoting, (col,row) index order.
  */
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1342,4 +1343,46 @@ int awfl_oracle_gcm_forcing_apply(int nens, int nx, int ny, int nz, double *cons
   }
   for (int s = 0; s < 3; s++) { free(neg[s]); free(colavg[s]); }
   return mask;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* modules::broadcast_initial_gcm_column  (pam_core/modules/broadcast_initial_gcm_column.h:8-41; nfields = 6:
+ * density_dry, uvel, vvel, wvel, temp, water_vapor <- gcm_density_dry, gcm_uvel, gcm_vvel, gcm_wvel, gcm_temp,
+ * gcm_water_vapor) and ..._dry_density (:44-62; nfields = 1). */
+void awfl_oracle_broadcast_gcm_column(int nens, int nx, int ny, int nz, int nfields, const double *const *gcm, double *const *crm) {
+  for (int f = 0; f < nfields; f++)
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++)
+      crm[f][C4(k, j, i, e)] = gcm[f][K2(k, e)];
+}
+
+/* modules::perturb_temperature  (pam_core/modules/perturb_temperature.h:10-63).  The reference draws its numbers from
+ * yakl::Random (third-party, absent: not reproducible); this restatement keeps everything else -- seed formula (:44),
+ * [-1,1] range and clamp (:46-48), linear decay over the lowest nz/4 levels (:49), horizontal means summed in serial
+ * order and the energy-conserving rescale (:33-36,:51,:55-60) -- and takes splitmix64(seed) as the generator. */
+static double splitmix64_unit(uint64_t seed) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+void awfl_oracle_perturb_temperature(int nens, int nx, int ny, int nz, double *temp, const int *id, double magnitude) {
+  const int num_levels = nz / 4;
+  const size_t n2 = (size_t)nz * nens;
+  double *hmean1 = (double *)calloc(n2, sizeof(double)), *hmean2 = (double *)calloc(n2, sizeof(double));
+  const double r_nx_ny = 1.0 / (nx * ny);
+  for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++)
+    hmean1[K2(k, e)] += temp[C4(k, j, i, e)] * r_nx_ny;
+  for (int k = 0; k < num_levels; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++) {
+    int64_t seed = (int64_t)id[e] * num_levels * ny * nx + (int64_t)k * ny * nx + (int64_t)j * nx + i;
+    double rnd = splitmix64_unit((uint64_t)seed) * 2. - 1.;
+    rnd = fmin(rnd, 1.0);
+    rnd = fmax(rnd, -1.0);
+    double scaling = (num_levels - (double)k) / num_levels;
+    temp[C4(k, j, i, e)] += rnd * magnitude * scaling;
+    hmean2[K2(k, e)] += temp[C4(k, j, i, e)] * r_nx_ny;
+  }
+  for (int k = 0; k < num_levels; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) for (int e = 0; e < nens; e++)
+    temp[C4(k, j, i, e)] = temp[C4(k, j, i, e)] * hmean1[K2(k, e)] / hmean2[K2(k, e)];
+  free(hmean1); free(hmean2);
 }

@@ -66,6 +66,8 @@ def load(path=None):
     lib.awfl_oracle_gcm_forcing_compute.argtypes = [C.c_int] * 4 + [C.POINTER(_DP)] * 3 + [C.c_double]
     lib.awfl_oracle_gcm_forcing_apply.restype = C.c_int
     lib.awfl_oracle_gcm_forcing_apply.argtypes = [C.c_int] * 4 + [C.POINTER(_DP)] * 3 + [_DP, C.c_double, C.c_double]
+    lib.awfl_oracle_broadcast_gcm_column.argtypes = [C.c_int] * 5 + [C.POINTER(_DP)] * 2
+    lib.awfl_oracle_perturb_temperature.argtypes = [C.c_int] * 4 + [_DP, C.POINTER(C.c_int), C.c_double]
     lib.awfl_oracle_kessler.restype = C.c_int
     lib.awfl_oracle_kessler.argtypes = [C.c_int] * 4 + [_DP] * 7 + [C.c_double] * 5 + [C.c_int]
     lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
@@ -290,3 +292,24 @@ def apply_gcm_forcing_tendencies(crm, gcm, tend, dz, crm_dt, dt_gcm, lib=None):
     dz = np.ascontiguousarray(dz, dtype=np.float64)
     return lib.awfl_oracle_gcm_forcing_apply(nens, nx, ny, nz, _ptrs(crm, GCM_FORCING_CRM), _ptrs(gcm, GCM_FORCING_GCM),
                                              _ptrs(tend, GCM_FORCING_TEND), _p(dz), float(crm_dt), float(dt_gcm))
+
+
+BROADCAST_GCM = ("gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_wvel", "gcm_temp", "gcm_water_vapor")
+BROADCAST_CRM = ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor")
+
+
+def broadcast_initial_gcm_column(crm, gcm, dry_density_only=False, lib=None):
+    """modules::broadcast_initial_gcm_column[_dry_density] (pam_core/modules/broadcast_initial_gcm_column.h)."""
+    lib = lib or load()
+    nz, ny, nx, nens = crm["density_dry"].shape
+    n = 1 if dry_density_only else 6
+    lib.awfl_oracle_broadcast_gcm_column(nens, nx, ny, nz, n, _ptrs(gcm, BROADCAST_GCM[:n]), _ptrs(crm, BROADCAST_CRM[:n]))
+
+
+def perturb_temperature(temp, ids, magnitude=0.1, lib=None):
+    """modules::perturb_temperature (pam_core/modules/perturb_temperature.h:10-63) with splitmix64 in place of yakl::Random."""
+    lib = lib or load()
+    nz, ny, nx, nens = temp.shape
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    assert ids.shape == (nens,) and temp.flags["C_CONTIGUOUS"]
+    lib.awfl_oracle_perturb_temperature(nens, nx, ny, nz, _p(temp), ids.ctypes.data_as(C.POINTER(C.c_int)), float(magnitude))

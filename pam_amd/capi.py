@@ -69,6 +69,8 @@ MODULE_SYMBOLS = {
     "pam_amd_gcm_forcing_compute": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_void_p)] * 3 + [C.c_double, C.c_void_p]),
     "pam_amd_gcm_forcing_apply": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_void_p)] * 3 + [C.c_void_p, C.c_double, C.c_double,
                                                                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "pam_amd_broadcast_initial_gcm_column": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p)] * 2 + [C.c_void_p]),
+    "pam_amd_perturb_temperature": (C.c_int, [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "pam_amd_kessler_max_stable_dt": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_double, C.c_void_p, C.c_void_p,
                                                                                    C.POINTER(C.c_double)]),
 }

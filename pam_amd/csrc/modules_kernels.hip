@@ -328,6 +328,52 @@ __global__ void __launch_bounds__(256) gcm_fill_glob_kernel(int nens, long long 
   rho_x[idx] = yakl_max(0.0, r - (glob[e] * factor) / d);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// modules::broadcast_initial_gcm_column[_dry_density]  (pam_core/modules/broadcast_initial_gcm_column.h:8-62)
+struct Ptr6 { double *crm[6]; const double *gcm[6]; };
+__global__ void __launch_bounds__(256) broadcast_gcm_kernel(int nens, long long per_level, long long ncell, int nfields, Ptr6 F) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncell) return;
+  const long long t = (idx / per_level) * nens + idx % nens;
+  for (int f = 0; f < nfields; f++) F.crm[f][idx] = F.gcm[f][t];
+}
+
+// modules::perturb_temperature  (pam_core/modules/perturb_temperature.h:10-63) with splitmix64 for yakl::Random (absent
+// third-party generator; see the oracle).  One thread per (level < nz/4, member) walks its cells three times in the
+// reference's serial order: mean before, perturb + mean after, rescale.
+__device__ __forceinline__ double splitmix64_unit(unsigned long long seed) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ void __launch_bounds__(64) perturb_temperature_kernel(int nens, int nx, int ny, int num_levels, double *temp,
+                                                                 const int *__restrict__ id, double magnitude) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)num_levels * nens) return;
+  const int e = (int)(t % nens), k = (int)(t / nens);
+  const double r_nx_ny = 1.0 / (nx * ny);
+  const long long base = (long long)k * ny * nx * nens + e;
+  const int ncol = ny * nx;
+  double hmean1 = 0, hmean2 = 0;
+  for (int c = 0; c < ncol; c++) hmean1 += temp[base + (long long)c * nens] * r_nx_ny;
+  const long long seed0 = (long long)id[e] * num_levels * ny * nx + (long long)k * ny * nx;   // + j*nx + i = + c
+  const double scaling = (num_levels - (double)k) / num_levels;
+  for (int c = 0; c < ncol; c++) {
+    double rnd = splitmix64_unit((unsigned long long)(seed0 + c)) * 2. - 1.;
+    rnd = fmin(rnd, 1.0);
+    rnd = fmax(rnd, -1.0);
+    const double v = temp[base + (long long)c * nens] + rnd * magnitude * scaling;
+    temp[base + (long long)c * nens] = v;
+    hmean2 += v * r_nx_ny;
+  }
+  for (int c = 0; c < ncol; c++) {
+    const long long o = base + (long long)c * nens;
+    temp[o] = temp[o] * hmean1 / hmean2;
+  }
+}
+
 }  // namespace
 
 extern "C" int pam_amd_set_last_error_(int code, const char *msg);   // defined in awfl_kernels.hip
@@ -500,5 +546,45 @@ extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, doubl
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   if (mask_out) *mask_out = mask;
+  return PAM_AMD_OK;
+}
+
+extern "C" int pam_amd_broadcast_initial_gcm_column(int nens, int nx, int ny, int nz, int num_fields, const double *const *gcm,
+                                                    double *const *crm, void *stream) {
+  if (nens < 1 || nx < 1 || ny < 1 || nz < 1 || !gcm || !crm)
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, "broadcast_initial_gcm_column: bad dimensions or null pointer table");
+  if (num_fields != 1 && num_fields != 6)
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, "broadcast_initial_gcm_column: num_fields must be 6 (all) or 1 (dry density only)");
+  Ptr6 F;
+  for (int f = 0; f < 6; f++) { F.crm[f] = nullptr; F.gcm[f] = nullptr; }
+  for (int f = 0; f < num_fields; f++) {
+    if (!gcm[f] || !crm[f]) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "broadcast_initial_gcm_column: null field pointer");
+    F.crm[f] = crm[f]; F.gcm[f] = gcm[f];
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "broadcast_initial_gcm_column: no HIP device available (this library has no CPU path)");
+  const long long per_level = (long long)ny * nx * nens, ncell = per_level * nz;
+  hipLaunchKernelGGL(broadcast_gcm_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nens, per_level,
+                     ncell, num_fields, F);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  return PAM_AMD_OK;
+}
+
+extern "C" int pam_amd_perturb_temperature(int nens, int nx, int ny, int nz, double *temp, const int *id, double magnitude,
+                                           void *stream) {
+  if (nens < 1 || nx < 1 || ny < 1 || nz < 1 || !temp || !id)
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, "perturb_temperature: bad dimensions or null pointer");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "perturb_temperature: no HIP device available (this library has no CPU path)");
+  const int num_levels = nz / 4;
+  if (num_levels == 0) return PAM_AMD_OK;
+  const long long n = (long long)num_levels * nens;
+  hipLaunchKernelGGL(perturb_temperature_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, nens, nx, ny,
+                     num_levels, temp, id, magnitude);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
 }

@@ -79,3 +79,45 @@ def apply_gcm_forcing_tendencies(coupler):
                                             work.data_ptr(), torch.cuda.current_stream(coupler.device).cuda_stream,
                                             C.byref(mask)))
     return mask.value   # the call synchronised the stream, so `work` may be dropped
+
+
+BROADCAST_GCM = ("gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_wvel", "gcm_temp", "gcm_water_vapor")
+BROADCAST_CRM = ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor")
+
+
+def _broadcast(coupler, n):
+    lib = capi.load()
+    dm = coupler.get_data_manager_device_readwrite()
+    gcm = [dm.get(name, readonly=True) for name in BROADCAST_GCM[:n]]
+    crm = [dm.get(name) for name in BROADCAST_CRM[:n]]
+    with torch.cuda.device(coupler.device):
+        check(lib.pam_amd_broadcast_initial_gcm_column(coupler.get_nens(), coupler.get_nx(), coupler.get_ny(), coupler.get_nz(), n,
+                                                       _ptr_table(gcm), _ptr_table(crm),
+                                                       torch.cuda.current_stream(coupler.device).cuda_stream))
+
+
+def broadcast_initial_gcm_column(coupler):
+    """modules::broadcast_initial_gcm_column(coupler)  (pam_core/modules/broadcast_initial_gcm_column.h:8-41)."""
+    _broadcast(coupler, 6)
+
+
+def broadcast_initial_gcm_column_dry_density(coupler):
+    """modules::broadcast_initial_gcm_column_dry_density(coupler)  (broadcast_initial_gcm_column.h:44-62)."""
+    _broadcast(coupler, 1)
+
+
+def perturb_temperature(coupler, ids, magnitude=0.1):
+    """modules::perturb_temperature(coupler, id, magnitude)  (pam_core/modules/perturb_temperature.h:10-63); `ids` is one
+    integer per member.  splitmix64 stands in for the reference's yakl::Random (see include/pam_amd_modules.h)."""
+    lib = capi.load()
+    nens = coupler.get_nens()
+    ids = torch.as_tensor(ids, dtype=torch.int32, device=coupler.device).contiguous()
+    if ids.numel() != nens:
+        from .coupler import endrun
+        endrun("ERROR: size of id array must be the same as nens")        # perturb_temperature.h:20
+    temp = coupler.get_data_manager_device_readwrite().get("temp")
+    with torch.cuda.device(coupler.device):
+        check(lib.pam_amd_perturb_temperature(nens, coupler.get_nx(), coupler.get_ny(), coupler.get_nz(), temp.data_ptr(),
+                                              ids.data_ptr(), float(magnitude),
+                                              torch.cuda.current_stream(coupler.device).cuda_stream))
+    return ids   # keeps the id array alive until the caller drops it (the launch is asynchronous)

@@ -206,3 +206,57 @@ def test_gpu_gcm_forcing_matches_oracle(kw, want):
     for n in ("gcm_forcing_tend_rho_v", "gcm_forcing_tend_rho_l", "gcm_forcing_tend_rho_i"):
         got = dm.get(n, readonly=True).cpu().numpy()
         assert np.abs(got - tend[n]).max() <= 1e-13 * 0.015 / dt_gcm, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rest of "next row" N2: broadcast_initial_gcm_column, perturb_temperature
+def test_oracle_perturb_temperature_shape():
+    nz, ny, nx, nens = 16, 3, 5, 4
+    T0 = np.full((nz, ny, nx, nens), 300.0) + np.arange(nz)[:, None, None, None]
+    T = T0.copy()
+    ao.perturb_temperature(T, np.arange(nens) + 7, 0.1)
+    nl = nz // 4
+    assert np.array_equal(T[nl:], T0[nl:])                                         # only the lowest nz/4 levels
+    d = np.abs(T[:nl] - T0[:nl]).max(axis=(1, 2, 3))
+    assert np.all(np.diff(d) < 0) and 0.05 < d[0] <= 0.1 * 1.2                     # decays with height, bounded by magnitude
+    assert np.abs(T[:nl].mean(axis=(1, 2)) - T0[:nl].mean(axis=(1, 2))).max() < 1e-12   # horizontal mean restored
+    assert not np.array_equal(T[0, :, :, 0], T[0, :, :, 1])                        # members draw different numbers
+    T2 = T0.copy()
+    idz.perturb_temperature(T2, 0.1, id0=7)                                        # the numpy generator of the bench inputs
+    assert np.abs(T - T2).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_broadcast_and_perturb_match_oracle():
+    import torch
+    from pam_amd import PamCoupler, modules
+    nens, nx, ny, nz = 70, 5, 3, 17
+    rng = np.random.default_rng(3)
+    coupler = PamCoupler("cuda:0")
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(nx * 500.0, ny * 500.0, np.linspace(0, 12000.0, nz + 1))
+    coupler.add_tracer("water_vapor", "", True, True)
+    dm = coupler.get_data_manager_device_readwrite()
+    gcm = {n: np.ascontiguousarray(rng.uniform(0.5, 1.5, (nz, nens))) for n in ao.BROADCAST_GCM}
+    gcm["gcm_temp"] += 280.0
+    for n, a in gcm.items():
+        dm.get(n).copy_(torch.from_numpy(a))
+    crm = {n: np.zeros((nz, ny, nx, nens)) for n in ao.BROADCAST_CRM}
+    dirty = coupler.run_module("broadcast", modules.broadcast_initial_gcm_column_dry_density)
+    assert "density_dry" in dirty and "temp" not in dirty
+    ao.broadcast_initial_gcm_column(crm, gcm, dry_density_only=True)
+    for n in ao.BROADCAST_CRM:
+        assert np.array_equal(dm.get(n, readonly=True).cpu().numpy(), crm[n]), n
+    coupler.run_module("broadcast", modules.broadcast_initial_gcm_column)
+    ao.broadcast_initial_gcm_column(crm, gcm)
+    for n in ao.BROADCAST_CRM:
+        assert np.array_equal(dm.get(n, readonly=True).cpu().numpy(), crm[n]), n
+    ids = np.arange(nens) * 3 + 11
+    keep = modules.perturb_temperature(coupler, ids, 0.25)
+    torch.cuda.synchronize()
+    ao.perturb_temperature(crm["temp"], ids, 0.25)
+    got = dm.get("temp", readonly=True).cpu().numpy()
+    assert np.abs(got - crm["temp"]).max() <= 1e-14 * crm["temp"].max()
+    assert np.abs(got - gcm["gcm_temp"][:, None, None, :]).max() > 0.1
+    with pytest.raises(Exception):
+        modules.perturb_temperature(coupler, ids[:-1], 0.25)
