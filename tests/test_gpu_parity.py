@@ -82,6 +82,14 @@ CASES = {
     "3d_ragged_nens70": (70, 5, 3, 7, idz.TRACERS_NONE, idz.stretched_interfaces(7, 9000.0), {}, True, 1),
     # smallest legal grid: one member, 3 cells per direction (the periodic stencil wraps the whole line twice)
     "3d_minimal_1x3x3x3": (1, 3, 3, 3, idz.TRACERS_NONE, idz.uniform_interfaces(3, 3000.0), {}, True, 2),
+    # BASELINE configs at their true grid (32 x {32,1} x 60, L60 levels; the 61-face column is swept as two spans) with few
+    # members so that the oracle finishes in seconds: C1 exactly (dry bubble, nens=2), C2's grid, C3's and C4's tracer sets
+    # (the theta = 300 K bubble atmosphere ends at cp*theta/g = 30.7 km: C1 uses the reference's 20 km box, uniform levels)
+    "c1_bubble_32x32x60_20km_nens2": (2, 32, 32, 60, idz.TRACERS_NONE, idz.uniform_interfaces(60, 20000.0),
+                                      dict(supercell=False, dxy=625.0), True, 1),
+    "c2_grid_32x32x60_L60_nens2": (2, 32, 32, 60, idz.TRACERS_NONE, idz.l60_interfaces(), {}, True, 1),
+    "c3_grid_32x1x60_L60_nt4": (66, 32, 1, 60, idz.TRACERS_KESSLER_SHOC, idz.l60_interfaces(), {}, True, 1),
+    "c4_grid_32x1x60_L60_nt10": (5, 32, 1, 60, idz.TRACERS_P3_SHOC, idz.l60_interfaces(), dict(consts=idz.CONSTS_P3), True, 1),
     # the reference's maximum tracer count (pam_const.h:24 max_fields = 50): water_vapor + 49 more, mixed flags
     "2d_nt50_max_tracers": (2, 6, 1, 6, [("t%02d" % i, i % 3 != 0, i % 4 == 0) for i in range(20)] +
                             [("water_vapor", True, True)] + [("u%02d" % i, i % 2 == 0, False) for i in range(29)],
