@@ -36,6 +36,26 @@ def test_sponge_layer_rejects_bad_arguments():
     assert b"sponge_layer" in lib.pam_amd_awfl_last_error()
 
 
+def test_other_modules_reject_bad_arguments_before_touching_a_device():
+    lib = capi.load()
+    T10, T14, T6 = (C.c_void_p * 10)(), (C.c_void_p * 14)(), (C.c_void_p * 6)()      # tables of NULL device pointers
+    cases = [
+        ("kessler", lambda: lib.pam_amd_kessler_time_step(2, 4, 1, 1, None, None, None, None, None, None, None, 1.0, 287., 461.,
+                                                          1003., 1e5, None, None, 0, None)),
+        ("kessler", lambda: lib.pam_amd_kessler_max_stable_dt(2, 4, 1, 8, None, None, None, 1.0, None, None, None)),
+        ("compute_gcm_forcing_tendencies", lambda: lib.pam_amd_gcm_forcing_compute(2, 4, 1, 8, T10, T10, T14, 1200.0, None)),
+        ("compute_gcm_forcing_tendencies", lambda: lib.pam_amd_gcm_forcing_compute(2, 4, 1, 8, None, T10, T14, 1200.0, None)),
+        ("apply_gcm_forcing_tendencies", lambda: lib.pam_amd_gcm_forcing_apply(2, 4, 1, 0, T10, T10, T14, None, 1.0, 1200.0, None,
+                                                                               None, None)),
+        ("broadcast_initial_gcm_column", lambda: lib.pam_amd_broadcast_initial_gcm_column(2, 4, 1, 8, 3, T6, T6, None)),
+        ("broadcast_initial_gcm_column", lambda: lib.pam_amd_broadcast_initial_gcm_column(2, 4, 1, 8, 6, T6, T6, None)),
+        ("perturb_temperature", lambda: lib.pam_amd_perturb_temperature(2, 4, 1, 8, None, None, 0.1, None)),
+    ]
+    for who, call in cases:
+        assert call() == -1, who                                   # PAM_AMD_EINVAL
+        assert who.encode() in lib.pam_amd_awfl_last_error(), who
+
+
 def _cfg(**kw):
     cfg = capi.Config()
     cfg.nens, cfg.nx, cfg.ny, cfg.nz, cfg.num_tracers = 2, 8, 1, 8, 1
