@@ -169,6 +169,9 @@ def emit(c):
     o.append("#define AWFL_TV5_A3A3 " + lit(c["tv5"][3][3]))
     o.append("#define AWFL_TV5_A2A4 " + lit(c["tv5"][2][4]))
     o.append("#define AWFL_TV5_A4A4 " + lit(c["tv5"][4][4]))
+    o.append("/* square roots of the a3^2 and a4^2 weights: the HIP tables carry the x^3 / x^4 rows pre-scaled by them */")
+    o.append("#define AWFL_TV5_SQRT_A3A3 " + repr(float(c["tv5"][3][3]) ** 0.5))
+    o.append("#define AWFL_TV5_SQRT_A4A4 " + repr(float(c["tv5"][4][4]) ** 0.5))
     o.append("/* WENO ideal weights / sigma before convexification (WenoLimiter.h:39-44) */")
     o.append("#define AWFL_WENO_SIGMA 0.73564225445964")
     o.append("#define AWFL_WENO_IDL_INIT { 1.0, 73.564225445964, 1.0, 1584.89319246111 }")

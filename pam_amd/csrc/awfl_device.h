@@ -119,21 +119,26 @@ PAMA_D WenoConsts weno_consts() {
 // with E_i = (a0_i - u2) + a2_i/4 (+ a4/16), O_i = a1_i/2 (+ a3/8).  The bridge polynomial (WenoLimiter.h:128-136) is
 // linear in the stencil and is folded into the upper-polynomial coefficients.
 struct WenoLin {
-  double a1[3], a2[3];   // lower candidates: x and x^2 coefficients
-  double h1, h2, h3, h4; // bridged upper polynomial: x .. x^4 coefficients
+  double a1[3], a2[3];   // lower candidates: x coefficient; x^2 coefficient (UNIFORM: the second difference d_{i+1}-d_i = 2 a2)
+  double h1, h2, h3, h4; // bridged upper polynomial: x, x^2 coefficients; x^3, x^4 coefficients times sqrt of their TV weight
   double E[3], Eh;       // even-part edge contributions minus u2
 };
 
 // Non-linear part (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum).
+// UNIFORM (constant-matrix directions): the x^2 coefficient of every lower candidate is half the second difference, so
+// p.a2 holds the second difference itself and the factor 1/4 moves into the TV constant.
+template <bool UNIFORM>
 PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, double &left, double &right) {
+  constexpr double K2 = UNIFORM ? 0.25 * AWFL_TV3_A2A2 : AWFL_TV3_A2A2;
+  constexpr double K13 = AWFL_TV5_A1A3 / AWFL_TV5_SQRT_A3A3, K24 = AWFL_TV5_A2A4 / AWFL_TV5_SQRT_A4A4;
   double tv[4];
 #pragma unroll
-  for (int i = 0; i < 3; i++) tv[i] = p.a1[i] * p.a1[i] + AWFL_TV3_A2A2 * (p.a2[i] * p.a2[i]);
-  // coefs_to_tv<5> (TransformMatrices.h:871-876) grouped as h1 (h1 + .5 h3) + h2 (c2 h2 + 4.2 h4) + c3 h3^2 + c4 h4^2
-  tv[3] = p.h1 * (p.h1 + AWFL_TV5_A1A3 * p.h3) + p.h2 * (AWFL_TV5_A2A2 * p.h2 + AWFL_TV5_A2A4 * p.h4) +
-          (AWFL_TV5_A3A3 * p.h3) * p.h3 + (AWFL_TV5_A4A4 * p.h4) * p.h4;
-  double lo_avg = (tv[0] + tv[1] + tv[2]) * (1.0 / 3.0);
-  tv[3] = lo_avg + (tv[3] - lo_avg) * wc.sigma;
+  for (int i = 0; i < 3; i++) tv[i] = p.a1[i] * p.a1[i] + K2 * (p.a2[i] * p.a2[i]);
+  // coefs_to_tv<5> (TransformMatrices.h:871-876) grouped as h1 (h1 + .5 h3) + h2 (c2 h2 + 4.2 h4) + c3 h3^2 + c4 h4^2, with
+  // h3, h4 carried pre-scaled by sqrt(c3), sqrt(c4)
+  tv[3] = p.h1 * (p.h1 + K13 * p.h3) + p.h2 * (AWFL_TV5_A2A2 * p.h2 + K24 * p.h4) + p.h3 * p.h3 + p.h4 * p.h4;
+  // tv3 = lo_avg + (tv3 - lo_avg) sigma  (WenoLimiter.h:150-151)
+  tv[3] = wc.sigma * tv[3] + ((1.0 - AWFL_WENO_SIGMA) / 3.0) * ((tv[0] + tv[1]) + tv[2]);
   // w_i = idl_i/(tv_i^2+eps), then convexify: w_i /= (sum_k w_k + eps) (WenoLimiter.h:163-166).  One reciprocal,
   // through products of the denominators d_i.  The eps added to the SUM matters when the TVs are large (pressure
   // stencils: sum ~ 1e-17), so it is kept: numerator and denominator are both scaled by d0*d1*d2*d3.
@@ -144,7 +149,8 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double n2 = wc.idl[2] * (d3 * p01), n3 = wc.idl[3] * (d2 * p01);
   double rs = fast_rcp((((n0 + n1) + n2) + n3) + 1.0e-20 * (p01 * p23));
   double w[4] = {n0 * rs, n1 * rs, n2 * rs, n3 * rs};
-  // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal
+  // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal; the normalisation 1/sum(m) is applied
+  // to the two weighted sums instead of to the four weights
   double num[4], den[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -155,9 +161,11 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
   double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
   double rm = fast_rcp(((m0 + m1) + m2) + m3);
-  m0 *= rm; m1 *= rm; m2 *= rm; m3 *= rm;
-  double even = u2 + (m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2])));
-  double odd = 0.5 * (m3 * p.h1 + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]))) + 0.125 * (m3 * p.h3);
+  double se = m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2]));
+  // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
+  double so = m3 * (p.h1 + (0.25 / AWFL_TV5_SQRT_A3A3) * p.h3) + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]));
+  double even = u2 + rm * se;
+  double odd = (0.5 * rm) * so;
   left = even - odd;
   right = even + odd;
 }
@@ -165,7 +173,8 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
 // Difference-form coefficient tables.  Lower candidate i uses (d_{i+1}, d_{i+2}); the upper polynomial uses d_1..d_4.
 //   lo1[i][2], lo2[i][2]      x and x^2 coefficients of candidate i
 //   loE[i][2]                 (a0_i - u2) + a2_i/4
-//   hi[p-1][4]   p=1..4       bridged upper coefficients
+//   hi[p-1][4]   p=1..4       bridged upper coefficients; the x^3 and x^4 rows are scaled by sqrt(39.1125), sqrt(625.8)
+//                             (their weights in coefs_to_tv<5>), see weno5_blend
 //   hiE[4]                    (a0_h - u2) + a2_h/4 + a4_h/16
 // VZ_STRIDE = 38 doubles per level in this order.
 struct DTable { double lo1[3][2], lo2[3][2], loE[3][2], hi[4][4], hiE[4]; };
@@ -205,7 +214,8 @@ constexpr DTable make_dtable(const double lo[3][3][3], const double hi[5][5], co
       t.loE[i][q] = lod[i][0][i + q] + 0.25 * lod[i][2][i + q];
     }
   for (int pp = 1; pp <= 4; pp++)
-    for (int m = 0; m < 4; m++) t.hi[pp - 1][m] = hid[pp][m];
+    for (int m = 0; m < 4; m++)
+      t.hi[pp - 1][m] = hid[pp][m] * (pp == 3 ? AWFL_TV5_SQRT_A3A3 : (pp == 4 ? AWFL_TV5_SQRT_A4A4 : 1.0));
   for (int m = 0; m < 4; m++) t.hiE[m] = hid[0][m] + 0.25 * hid[2][m] + 0.0625 * hid[4][m];
   return t;
 }
@@ -224,10 +234,13 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   constexpr DTable T = make_const_dtable();
   const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
   WenoLin p;
+  // on the uniform grid every lower candidate has a2 = (d_{i+1} - d_i)/2 exactly (checked at compile time)
+  static_assert(T.lo2[0][0] == -0.5 && T.lo2[0][1] == 0.5 && T.lo2[1][0] == -0.5 && T.lo2[1][1] == 0.5 &&
+                T.lo2[2][0] == -0.5 && T.lo2[2][1] == 0.5, "uniform-grid x^2 coefficients are half second differences");
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     p.a1[i] = T.lo1[i][0] * d[i] + T.lo1[i][1] * d[i + 1];
-    p.a2[i] = T.lo2[i][0] * d[i] + T.lo2[i][1] * d[i + 1];
+    p.a2[i] = d[i + 1] - d[i];
     p.E[i] = T.loE[i][0] * d[i] + T.loE[i][1] * d[i + 1];
   }
   p.h1 = T.hi[0][0] * d[0] + (T.hi[0][1] * d[1] + (T.hi[0][2] * d[2] + T.hi[0][3] * d[3]));
@@ -235,7 +248,7 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   p.h3 = T.hi[2][0] * d[0] + (T.hi[2][1] * d[1] + (T.hi[2][2] * d[2] + T.hi[2][3] * d[3]));
   p.h4 = T.hi[3][0] * d[0] + (T.hi[3][1] * d[1] + (T.hi[3][2] * d[2] + T.hi[3][3] * d[3]));
   p.Eh = T.hiE[0] * d[0] + (T.hiE[1] * d[1] + (T.hiE[2] * d[2] + T.hiE[3] * d[3]));
-  weno5_blend(u[2], p, wc, left, right);
+  weno5_blend<true>(u[2], p, wc, left, right);
 }
 
 // Vertical direction: per-level difference-form table built at init from the cell-edge locations
@@ -256,7 +269,7 @@ PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, cons
   p.h3 = tab[26 * ts] * d[0] + (tab[27 * ts] * d[1] + (tab[28 * ts] * d[2] + tab[29 * ts] * d[3]));
   p.h4 = tab[30 * ts] * d[0] + (tab[31 * ts] * d[1] + (tab[32 * ts] * d[2] + tab[33 * ts] * d[3]));
   p.Eh = tab[34 * ts] * d[0] + (tab[35 * ts] * d[1] + (tab[36 * ts] * d[2] + tab[37 * ts] * d[3]));
-  weno5_blend(u[2], p, wc, left, right);
+  weno5_blend<false>(u[2], p, wc, left, right);
 }
 
 // ------------------------------------------------------------------------------------------------
