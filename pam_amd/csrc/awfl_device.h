@@ -86,6 +86,19 @@ PAMA_D double fast_rcp(double x) {
 #endif
 }
 
+// reciprocal for the two WENO weight normalisations: one Newton step (measured on gfx950, tools/probe/rcp_precision.hip:
+// v_rcp_f64 alone 4.6e-8, one step 2.2e-15, two steps exact).  A relative error e in a normalisation factor moves an edge
+// value by ~e x (spread of the candidate polynomials at the edge), far below one ulp of the value itself.
+PAMA_D double weno_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double r = fma(-x, y, 1.0);
+  return fma(y, r, y);
+#else
+  return 1.0 / x;
+#endif
+}
+
 // Convexified ideal weights (WenoLimiter.h:39-44 + :94), sigma, and derived constants.
 struct WenoConsts {
   double idl[4], sigma, ridl3;
@@ -147,7 +160,7 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double p01 = d0 * d1, p23 = d2 * d3;
   double n0 = wc.idl[0] * (d1 * p23), n1 = wc.idl[1] * (d0 * p23);
   double n2 = wc.idl[2] * (d3 * p01), n3 = wc.idl[3] * (d2 * p01);
-  double rs = fast_rcp((((n0 + n1) + n2) + n3) + 1.0e-20 * (p01 * p23));
+  double rs = weno_rcp((((n0 + n1) + n2) + n3) + 1.0e-20 * (p01 * p23));
   double w[4] = {n0 * rs, n1 * rs, n2 * rs, n3 * rs};
   // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal; the normalisation 1/sum(m) is applied
   // to the two weighted sums instead of to the four weights
@@ -160,7 +173,7 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double q01 = den[0] * den[1], q23 = den[2] * den[3];
   double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
   double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
-  double rm = fast_rcp(((m0 + m1) + m2) + m3);
+  double rm = weno_rcp(((m0 + m1) + m2) + m3);
   double se = m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2]));
   // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
   double so = m3 * (p.h1 + (0.25 / AWFL_TV5_SQRT_A3A3) * p.h3) + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]));
