@@ -40,9 +40,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec; 256 CU x 4 SIMD 
 
 CONFIGS = {
     # name: (nens per GPU, nx, ny, tracer set, constants, crm_dt, description)
-    "c2": (1024, 32, 32, "none", "default", 2.0, "AWFL supercell idealized, nens=1024/GPU, 32x32x60 L60, NT=1, fp64"),
-    "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=4096/GPU, 2-D 32x1x60 L60, fp64"),
-    "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=512/GPU, 2-D 32x1x60 L60, fp64"),
+    "c2": (1024, 32, 32, "none", "default", 2.0, "AWFL supercell idealized, nens=%d/GPU, 32x32x60 L60, NT=1, fp64"),
+    "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
+    "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
 }
 
 
@@ -258,7 +258,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": desc, "nens_per_gpu": nens_pg, "nens_total": nens_pg * world, "nx": nx, "ny": ny,
+               "config": {"workload": desc % nens_pg, "nens_per_gpu": nens_pg, "nens_total": nens_pg * world, "nx": nx, "ny": ny,
                           "nz": nz, "num_tracers": nt, "crm_dt": crm_dt, "substeps_per_step": substeps / args.steps,
                           "parallelism": "nens-shard x%d" % world},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}
