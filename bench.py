@@ -72,14 +72,25 @@ def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:   # a container's CPU quota (cgroup v2) is the real core count when it is below the affinity mask
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
-    nens = 16 if ny > 1 else 256
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except Exception:
+        pass
+    nens = 64 if ny > 1 else 1024      # ~10-30 s of host work on the GPU box's cores
     f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tracers, magnitude=0.1)
     if len(tracers) > 1:
         idz.add_tracer_blobs(f, tracers, xlen, ylen, zint)
     o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), pos, mass, idwv, consts=consts, lib=lib)
     o.declare_current_profile_as_hydrostatic(f)
-    dt = 1.0
+    dt = 2.0
     o.time_step(copy.deepcopy(f), 0.2)      # warm-up (thread pool, page faults)
     t0 = time.time()
     ncyc, _ = o.time_step(f, dt)
