@@ -267,8 +267,8 @@ def test_full_baseline_size_c2_properties():
     size-independent properties.  (i) dry mass and vapour mass of every member conserved to 1e-10 per timeStep (the
     reference's PAM_DEBUG invariant, Dycore.h:224-251); (ii) all fields finite, vapour non-negative; (iii) members that
     start identical stay bit-identical (the inputs are 16 distinct members tiled 64 times: any cross-member leakage or
-    chunk-boundary error would break this); (iv) the automatic 3-chunk overlapped schedule equals the single-chunk one
-    bit for bit."""
+    chunk-boundary error would break this); (iv) the automatic overlapped schedule (8 member ranges of 128 on prioritised
+    streams) equals the single-range one bit for bit (tools/soak_c2.py repeats this over hundreds of sub-steps)."""
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, ngen = 1024, 32, 32, 60, 16
@@ -302,7 +302,7 @@ def test_full_baseline_size_c2_properties():
             t = coupler.dm.get(k, readonly=True)
             assert torch.isfinite(t).all(), k
             assert torch.equal(t[..., :ngen], t[..., nens - ngen:]), k           # tile 0 == tile 63
-            assert torch.equal(t[..., :ngen], t[..., 384:384 + ngen]), k          # across the chunk boundary at 384
+            assert torch.equal(t[..., :ngen], t[..., 384:384 + ngen]), k          # across the range boundary at 384 = 3*128
         assert (coupler.dm.get("water_vapor", readonly=True) >= 0).all()
         results.append({k: coupler.dm.get(k, readonly=True)[..., ::37].clone() for k in ("density_dry", "wvel", "temp")})
         dycore.finalize(coupler)
