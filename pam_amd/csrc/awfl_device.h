@@ -174,7 +174,15 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
   double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
   double rm = weno_rcp(((m0 + m1) + m2) + m3);
-  double se = m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2]));
+  // even part.  On the uniform grid every candidate reproduces the average of the centre cell [-1/2,1/2]:
+  // a0 + a2/12 (+ a4/80) = u2, so its edge value minus u2 is (a0 - u2) + a2/4 (+ a4/16) = a2/6 (+ a4/20) and needs no
+  // coefficients of its own (p.a2 holds 2 a2 there); the vertical tables (off-centre coordinates) carry E.
+  double se;
+  if (UNIFORM)
+    se = m3 * (p.h2 * (1.0 / 6.0) + p.h4 * (0.05 / AWFL_TV5_SQRT_A4A4)) +
+         (1.0 / 12.0) * (m0 * p.a2[0] + (m1 * p.a2[1] + m2 * p.a2[2]));
+  else
+    se = m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2]));
   // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
   double so = m3 * (p.h1 + (0.25 / AWFL_TV5_SQRT_A3A3) * p.h3) + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]));
   double even = u2 + rm * se;
@@ -242,6 +250,20 @@ constexpr DTable make_const_dtable() {
   return make_dtable(W3, S5, idl);
 }
 
+constexpr double cabs_(double x) { return x < 0 ? -x : x; }
+// compile-time proof of the identity weno5_blend<true> relies on: E = a2/6 for the lower candidates and
+// Eh = h2/6 + h4/20 for the bridged upper polynomial (h4 is carried times sqrt(625.8))
+constexpr bool uniform_even_identity_holds() {
+  constexpr DTable T = make_const_dtable();
+  for (int i = 0; i < 3; i++)
+    for (int q = 0; q < 2; q++)
+      if (cabs_(T.loE[i][q] - T.lo2[i][q] / 6.0) > 1e-15) return false;
+  for (int m = 0; m < 4; m++)
+    if (cabs_(T.hiE[m] - (T.hi[1][m] / 6.0 + T.hi[3][m] * (0.05 / AWFL_TV5_SQRT_A4A4))) > 1e-15) return false;
+  return true;
+}
+static_assert(uniform_even_identity_holds(), "uniform-grid candidates must reproduce the centre cell average");
+
 // Horizontal directions: constant matrices (uniform grid).  All coefficients are compile-time literals.
 PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
   constexpr DTable T = make_const_dtable();
@@ -254,13 +276,13 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   for (int i = 0; i < 3; i++) {
     p.a1[i] = T.lo1[i][0] * d[i] + T.lo1[i][1] * d[i + 1];
     p.a2[i] = d[i + 1] - d[i];
-    p.E[i] = T.loE[i][0] * d[i] + T.loE[i][1] * d[i + 1];
+    p.E[i] = 0.0;   // unused on the uniform grid (weno5_blend<true>)
   }
   p.h1 = T.hi[0][0] * d[0] + (T.hi[0][1] * d[1] + (T.hi[0][2] * d[2] + T.hi[0][3] * d[3]));
   p.h2 = T.hi[1][0] * d[0] + (T.hi[1][1] * d[1] + (T.hi[1][2] * d[2] + T.hi[1][3] * d[3]));
   p.h3 = T.hi[2][0] * d[0] + (T.hi[2][1] * d[1] + (T.hi[2][2] * d[2] + T.hi[2][3] * d[3]));
   p.h4 = T.hi[3][0] * d[0] + (T.hi[3][1] * d[1] + (T.hi[3][2] * d[2] + T.hi[3][3] * d[3]));
-  p.Eh = T.hiE[0] * d[0] + (T.hiE[1] * d[1] + (T.hiE[2] * d[2] + T.hiE[3] * d[3]));
+  p.Eh = 0.0;
   weno5_blend<true>(u[2], p, wc, left, right);
 }
 
