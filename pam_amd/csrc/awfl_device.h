@@ -264,25 +264,36 @@ constexpr bool uniform_even_identity_holds() {
 }
 static_assert(uniform_even_identity_holds(), "uniform-grid candidates must reproduce the centre cell average");
 
-// Horizontal directions: constant matrices (uniform grid).  All coefficients are compile-time literals.
+// Horizontal directions: constant matrices (uniform grid).  All coefficients are compile-time literals, and the mirror
+// symmetry of the uniform stencil (checked below, exactly) lets the four upper-polynomial coefficients share the sums
+// and differences of the outer and inner first differences:
+//   h1 = a (d0+d3) + b (d1+d2)      h3 = g ((d0+d3) - (d1+d2))
+//   h2 = c (d0-d3) + e (d2-d1)      h4 = q ((d3-d0) - 3 (d2-d1))          (h3, h4 times sqrt of their TV weights)
 PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
   constexpr DTable T = make_const_dtable();
-  const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
-  WenoLin p;
-  // on the uniform grid every lower candidate has a2 = (d_{i+1} - d_i)/2 exactly (checked at compile time)
+  static_assert(T.hi[0][0] == T.hi[0][3] && T.hi[0][1] == T.hi[0][2], "x coefficient: symmetric");
+  static_assert(T.hi[1][0] == -T.hi[1][3] && T.hi[1][1] == -T.hi[1][2], "x^2 coefficient: antisymmetric");
+  static_assert(T.hi[2][0] == T.hi[2][3] && T.hi[2][1] == T.hi[2][2] && T.hi[2][0] == -T.hi[2][1], "x^3 coefficient");
+  static_assert(T.hi[3][0] == -T.hi[3][3] && T.hi[3][1] == -T.hi[3][2] && cabs_(T.hi[3][1] + 3.0 * T.hi[3][0]) < 1e-14,
+                "x^4 coefficient");
+  static_assert(T.lo1[1][0] == 0.5 && T.lo1[1][1] == 0.5, "centred candidate slope");
+  // on the uniform grid every lower candidate has a2 = (d_{i+1} - d_i)/2 exactly
   static_assert(T.lo2[0][0] == -0.5 && T.lo2[0][1] == 0.5 && T.lo2[1][0] == -0.5 && T.lo2[1][1] == 0.5 &&
                 T.lo2[2][0] == -0.5 && T.lo2[2][1] == 0.5, "uniform-grid x^2 coefficients are half second differences");
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    p.a1[i] = T.lo1[i][0] * d[i] + T.lo1[i][1] * d[i + 1];
-    p.a2[i] = d[i + 1] - d[i];
-    p.E[i] = 0.0;   // unused on the uniform grid (weno5_blend<true>)
-  }
-  p.h1 = T.hi[0][0] * d[0] + (T.hi[0][1] * d[1] + (T.hi[0][2] * d[2] + T.hi[0][3] * d[3]));
-  p.h2 = T.hi[1][0] * d[0] + (T.hi[1][1] * d[1] + (T.hi[1][2] * d[2] + T.hi[1][3] * d[3]));
-  p.h3 = T.hi[2][0] * d[0] + (T.hi[2][1] * d[1] + (T.hi[2][2] * d[2] + T.hi[2][3] * d[3]));
-  p.h4 = T.hi[3][0] * d[0] + (T.hi[3][1] * d[1] + (T.hi[3][2] * d[2] + T.hi[3][3] * d[3]));
-  p.Eh = 0.0;
+  const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
+  WenoLin p;
+  const double s03 = d[0] + d[3], s12 = d[1] + d[2], t03 = d[3] - d[0];
+  p.a2[0] = d[1] - d[0];
+  p.a2[1] = d[2] - d[1];
+  p.a2[2] = d[3] - d[2];
+  p.a1[0] = T.lo1[0][0] * d[0] + T.lo1[0][1] * d[1];
+  p.a1[1] = 0.5 * s12;
+  p.a1[2] = T.lo1[2][0] * d[2] + T.lo1[2][1] * d[3];
+  p.h1 = T.hi[0][0] * s03 + T.hi[0][1] * s12;
+  p.h2 = T.hi[1][2] * p.a2[1] - T.hi[1][0] * t03;
+  p.h3 = T.hi[2][0] * (s03 - s12);
+  p.h4 = T.hi[3][3] * (t03 - 3.0 * p.a2[1]);
+  p.E[0] = p.E[1] = p.E[2] = p.Eh = 0.0;   // unused on the uniform grid (weno5_blend<true>)
   weno5_blend<true>(u[2], p, wc, left, right);
 }
 
