@@ -452,31 +452,67 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       wm[4] = nm; wp[4] = np_; wn[4] = nn;
     }
   }
-  // ---------------- the other advected quantities, one field at a time (Dycore.h:367-385) -----------------------
-  for (int a = 0; a < nadv; a++) {
-    const int pf = P_U + a;                 // prim field
-    if (pf == ncomp) continue;
-    const double *q = prim + (long long)pf * P.prim_fs;
+  // ---------------- the other advected quantities (Dycore.h:367-385), two fields per sweep ---------------------
+  // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with two
+  // wavefronts per SIMD a single chain per iteration leaves issue slots empty, two independent chains fill them.
+  for (int a = 0; a < nadv;) {
+    if (P_U + a == ncomp) { a++; continue; }
+    int a2 = a + 1;
+    if (a2 < nadv && P_U + a2 == ncomp) a2++;
+    const bool pair = a2 < nadv;
+    const double *q = prim + (long long)(P_U + a) * P.prim_fs;
     double *fl = flux + (long long)(1 + a) * g.fs_flux + fbase;
-    double w[5];
-    int c = cstart;
+    if (pair) {
+      const double *q2 = prim + (long long)(P_U + a2) * P.prim_fs;
+      double *fl2 = flux + (long long)(1 + a2) * g.fs_flux + fbase;
+      double w[5], v[5];
+      int c = cstart;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
-    double prevR = 0.0;
-    for (; c < fend; c++) {
-      double nq = q[cell_off(c + 3)];
-      double L, R;
-      if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
-      else weno5_const(w, wc, L, R);
-      if (c >= f0) {
-        double ruf = ruf_slot[(c - f0) * nthr];
-        double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
-        fl[(long long)c * g.cs] = ruf * val;
+      for (int s = 0; s < 5; s++) {
+        const long long o = cell_off(c - 2 + s);
+        w[s] = q[o]; v[s] = q2[o];
       }
-      prevR = R;
+      double prevR = 0.0, prevR2 = 0.0;
+      for (; c < fend; c++) {
+        const long long on = cell_off(c + 3);
+        double nq = q[on], nq2 = q2[on];
+        double L, R, L2, R2;
+        if (DIR == 2) { weno5_table(w, vtab(c), vts, wc, L, R); weno5_table(v, vtab(c), vts, wc, L2, R2); }
+        else { weno5_const(w, wc, L, R); weno5_const(v, wc, L2, R2); }
+        if (c >= f0) {
+          double ruf = ruf_slot[(c - f0) * nthr];
+          const bool up = ruf > 0.0;                          // upwind (Dycore.h:368)
+          fl[(long long)c * g.cs] = ruf * (up ? prevR : L);
+          fl2[(long long)c * g.cs] = ruf * (up ? prevR2 : L2);
+        }
+        prevR = R; prevR2 = R2;
 #pragma unroll
-      for (int s = 0; s < 4; s++) w[s] = w[s + 1];
-      w[4] = nq;
+        for (int s = 0; s < 4; s++) { w[s] = w[s + 1]; v[s] = v[s + 1]; }
+        w[4] = nq; v[4] = nq2;
+      }
+      a = a2 + 1;
+    } else {
+      double w[5];
+      int c = cstart;
+#pragma unroll
+      for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
+      double prevR = 0.0;
+      for (; c < fend; c++) {
+        double nq = q[cell_off(c + 3)];
+        double L, R;
+        if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
+        else weno5_const(w, wc, L, R);
+        if (c >= f0) {
+          double ruf = ruf_slot[(c - f0) * nthr];
+          double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
+          fl[(long long)c * g.cs] = ruf * val;
+        }
+        prevR = R;
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[s] = w[s + 1];
+        w[4] = nq;
+      }
+      a = a2;
     }
   }
 }
