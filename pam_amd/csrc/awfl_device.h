@@ -29,6 +29,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 #include "awfl_constants.h"
 
 #if defined(__HIPCC__)
@@ -43,6 +44,10 @@ constexpr int HS = 3;          // ghost levels (Dycore.h:23)
 constexpr int MAXT = 50;       // pam_const.h:24 max_fields
 constexpr int FLUX_THREADS = 256;
 constexpr int FLUX_WAVES = FLUX_THREADS / 64;
+#ifndef PAMA_FLUX_NF
+#define PAMA_FLUX_NF 2
+#endif
+constexpr int FLUX_NF = PAMA_FLUX_NF;   // advected fields swept together (independent polynomial chains per iteration)
 constexpr int FLUX_MAX_SPAN = 32; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
 constexpr int VZ_STRIDE = 38;  // per-level vertical table in difference form (struct DTable)
 
@@ -452,69 +457,62 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       wm[4] = nm; wp[4] = np_; wn[4] = nn;
     }
   }
-  // ---------------- the other advected quantities (Dycore.h:367-385), two fields per sweep ---------------------
+  // ---------------- the other advected quantities (Dycore.h:367-385), FLUX_NF fields per sweep ------------------
   // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with two
-  // wavefronts per SIMD a single chain per iteration leaves issue slots empty, two independent chains fill them.
-  for (int a = 0; a < nadv;) {
-    if (P_U + a == ncomp) { a++; continue; }
-    int a2 = a + 1;
-    if (a2 < nadv && P_U + a2 == ncomp) a2++;
-    const bool pair = a2 < nadv;
-    const double *q = prim + (long long)(P_U + a) * P.prim_fs;
-    double *fl = flux + (long long)(1 + a) * g.fs_flux + fbase;
-    if (pair) {
-      const double *q2 = prim + (long long)(P_U + a2) * P.prim_fs;
-      double *fl2 = flux + (long long)(1 + a2) * g.fs_flux + fbase;
-      double w[5], v[5];
-      int c = cstart;
+  // wavefronts per SIMD a single chain per iteration leaves issue slots empty, several independent chains fill them.
+  auto sweep = [&](auto nf_tag, const int *fa) {
+    constexpr int NF = decltype(nf_tag)::value;
+    const double *q[NF];
+    double *fl[NF];
+    double w[NF][5], prevR[NF];
 #pragma unroll
-      for (int s = 0; s < 5; s++) {
-        const long long o = cell_off(c - 2 + s);
-        w[s] = q[o]; v[s] = q2[o];
-      }
-      double prevR = 0.0, prevR2 = 0.0;
-      for (; c < fend; c++) {
-        const long long on = cell_off(c + 3);
-        double nq = q[on], nq2 = q2[on];
-        double L, R, L2, R2;
-        if (DIR == 2) { weno5_table(w, vtab(c), vts, wc, L, R); weno5_table(v, vtab(c), vts, wc, L2, R2); }
-        else { weno5_const(w, wc, L, R); weno5_const(v, wc, L2, R2); }
-        if (c >= f0) {
-          double ruf = ruf_slot[(c - f0) * nthr];
-          const bool up = ruf > 0.0;                          // upwind (Dycore.h:368)
-          fl[(long long)c * g.cs] = ruf * (up ? prevR : L);
-          fl2[(long long)c * g.cs] = ruf * (up ? prevR2 : L2);
-        }
-        prevR = R; prevR2 = R2;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { w[s] = w[s + 1]; v[s] = v[s + 1]; }
-        w[4] = nq; v[4] = nq2;
-      }
-      a = a2 + 1;
-    } else {
-      double w[5];
-      int c = cstart;
-#pragma unroll
-      for (int s = 0; s < 5; s++) w[s] = q[cell_off(c - 2 + s)];
-      double prevR = 0.0;
-      for (; c < fend; c++) {
-        double nq = q[cell_off(c + 3)];
-        double L, R;
-        if (DIR == 2) weno5_table(w, vtab(c), vts, wc, L, R);
-        else weno5_const(w, wc, L, R);
-        if (c >= f0) {
-          double ruf = ruf_slot[(c - f0) * nthr];
-          double val = (ruf > 0.0) ? prevR : L;               // upwind (Dycore.h:368)
-          fl[(long long)c * g.cs] = ruf * val;
-        }
-        prevR = R;
-#pragma unroll
-        for (int s = 0; s < 4; s++) w[s] = w[s + 1];
-        w[4] = nq;
-      }
-      a = a2;
+    for (int n = 0; n < NF; n++) {
+      q[n] = prim + (long long)(P_U + fa[n]) * P.prim_fs;
+      fl[n] = flux + (long long)(1 + fa[n]) * g.fs_flux + fbase;
+      prevR[n] = 0.0;
     }
+    int c = cstart;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const long long o = cell_off(c - 2 + s);
+#pragma unroll
+      for (int n = 0; n < NF; n++) w[n][s] = q[n][o];
+    }
+    for (; c < fend; c++) {
+      const long long on = cell_off(c + 3);
+      double nq[NF], L[NF], R[NF];
+#pragma unroll
+      for (int n = 0; n < NF; n++) nq[n] = q[n][on];
+#pragma unroll
+      for (int n = 0; n < NF; n++) {
+        if (DIR == 2) weno5_table(w[n], vtab(c), vts, wc, L[n], R[n]);
+        else weno5_const(w[n], wc, L[n], R[n]);
+      }
+      if (c >= f0) {
+        const double ruf = ruf_slot[(c - f0) * nthr];
+        const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
+#pragma unroll
+        for (int n = 0; n < NF; n++) fl[n][(long long)c * g.cs] = ruf * (up ? prevR[n] : L[n]);
+      }
+#pragma unroll
+      for (int n = 0; n < NF; n++) {
+        prevR[n] = R[n];
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+        w[n][4] = nq[n];
+      }
+    }
+  };
+  int fa[FLUX_NF], nfa = 0;
+  for (int a = 0; a < nadv; a++) {
+    if (P_U + a == ncomp) continue;
+    fa[nfa++] = a;
+    if (nfa == FLUX_NF) { sweep(std::integral_constant<int, FLUX_NF>{}, fa); nfa = 0; }
   }
+  if (FLUX_NF >= 4 && nfa == 3) { sweep(std::integral_constant<int, 3>{}, fa); nfa = 0; }
+  if (FLUX_NF >= 3 && nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
+  if (nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
+  if (nfa == 1) sweep(std::integral_constant<int, 1>{}, fa);
 }
 
 // ------------------------------------------------------------------------------------------------
