@@ -449,7 +449,7 @@ int build_chunks(pam_amd_awfl *h) {
     const long long W = ux + (P.sim2d ? 0 : uy) + uz;
     // ~11.8 k wave-units of flux work per chunk (128 members of a 32x32x60 CRM) measured best on MI355X for 256..2048
     // members; smaller jobs run as one chunk
-    n = (int)((W + 5888) / 11776);
+    n = (int)((W + 8000) / 11776);
     if (n < 1) n = 1;
     if (n > 16) n = 16;
   }
