@@ -49,7 +49,7 @@ constexpr int FLUX_WAVES = FLUX_THREADS / 64;
 #endif
 constexpr int FLUX_NF = PAMA_FLUX_NF;   // advected fields swept together (independent polynomial chains per iteration)
 constexpr int FLUX_MAX_SPAN = 32; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
-constexpr int VZ_STRIDE = 38;  // per-level vertical table in difference form (struct DTable)
+constexpr int VZ_STRIDE = 30;  // per-level vertical table in difference form (struct DTable)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
 
@@ -139,7 +139,7 @@ PAMA_D WenoConsts weno_consts() {
 struct WenoLin {
   double a1[3], a2[3];   // lower candidates: x coefficient; x^2 coefficient (UNIFORM: the second difference d_{i+1}-d_i = 2 a2)
   double h1, h2, h3, h4; // bridged upper polynomial: x, x^2 coefficients; x^3, x^4 coefficients times sqrt of their TV weight
-  double E[3], Eh;       // even-part edge contributions minus u2
+  double k2, k4;         // vertical only: even-part factors of the level (see weno5_blend)
 };
 
 // Non-linear part (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum).
@@ -179,15 +179,16 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
   double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
   double rm = weno_rcp(((m0 + m1) + m2) + m3);
-  // even part.  On the uniform grid every candidate reproduces the average of the centre cell [-1/2,1/2]:
-  // a0 + a2/12 (+ a4/80) = u2, so its edge value minus u2 is (a0 - u2) + a2/4 (+ a4/16) = a2/6 (+ a4/20) and needs no
-  // coefficients of its own (p.a2 holds 2 a2 there); the vertical tables (off-centre coordinates) carry E.
+  // even part.  Every candidate reproduces the average of the centre cell, which in the candidates' coordinate is centred
+  // at 0 with width w (1 on the uniform grid; dz(k)/dz(k-1) in the vertical, whose matrices are normalised by the cell
+  // below): a0 + a2 w^2/12 (+ a4 w^4/80) = u2.  Its value at x = +-1/2 minus u2 is therefore
+  // a2 (1/4 - w^2/12) (+ a4 (1/16 - w^4/80)) and needs no coefficients of its own.  (UNIFORM: p.a2 holds 2 a2.)
   double se;
   if (UNIFORM)
     se = m3 * (p.h2 * (1.0 / 6.0) + p.h4 * (0.05 / AWFL_TV5_SQRT_A4A4)) +
          (1.0 / 12.0) * (m0 * p.a2[0] + (m1 * p.a2[1] + m2 * p.a2[2]));
   else
-    se = m3 * p.Eh + (m0 * p.E[0] + (m1 * p.E[1] + m2 * p.E[2]));
+    se = m3 * (p.h2 * p.k2 + p.h4 * p.k4) + p.k2 * (m0 * p.a2[0] + (m1 * p.a2[1] + m2 * p.a2[2]));
   // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
   double so = m3 * (p.h1 + (0.25 / AWFL_TV5_SQRT_A3A3) * p.h3) + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]));
   double even = u2 + rm * se;
@@ -198,12 +199,11 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
 
 // Difference-form coefficient tables.  Lower candidate i uses (d_{i+1}, d_{i+2}); the upper polynomial uses d_1..d_4.
 //   lo1[i][2], lo2[i][2]      x and x^2 coefficients of candidate i
-//   loE[i][2]                 (a0_i - u2) + a2_i/4
 //   hi[p-1][4]   p=1..4       bridged upper coefficients; the x^3 and x^4 rows are scaled by sqrt(39.1125), sqrt(625.8)
 //                             (their weights in coefs_to_tv<5>), see weno5_blend
-//   hiE[4]                    (a0_h - u2) + a2_h/4 + a4_h/16
-// VZ_STRIDE = 38 doubles per level in this order.
-struct DTable { double lo1[3][2], lo2[3][2], loE[3][2], hi[4][4], hiE[4]; };
+//   k2, k4                    even-part factors 1/4 - w^2/12 and (1/16 - w^4/80)/sqrt(625.8), w = width of the centre cell
+// VZ_STRIDE = 30 doubles per level in this order.
+struct DTable { double lo1[3][2], lo2[3][2], hi[4][4], k2, k4; };
 
 // conversion of a stencil-form linear functional  sum_s c_s u_{s0+s}  (cells s0..s0+n-1 of the 5-stencil, centre = 2)
 // to difference form: coefficient of d_m (m = 1..4), dropping (sum c_s) u2 (=0 or u2, handled by the caller).
@@ -214,7 +214,7 @@ constexpr double dcoef(const double c[5], int m) {
 
 // Build the difference-form table from the stencil-form matrices recon_lo[i][s][ii] (vert_weno_recon_lower /
 // TransformMatrices.h:1218) and recon_hi[s][ii] (vert_sten_to_coefs / TransformMatrices.h:970) and the ideal weights.
-constexpr DTable make_dtable(const double lo[3][3][3], const double hi[5][5], const double idl[4]) {
+constexpr DTable make_dtable(const double lo[3][3][3], const double hi[5][5], const double idl[4], double w) {
   DTable t{};
   double lod[3][3][4] = {};   // [i][ii][m-1] full-width difference form of the lower candidates
   for (int i = 0; i < 3; i++)
@@ -237,12 +237,12 @@ constexpr DTable make_dtable(const double lo[3][3][3], const double hi[5][5], co
     for (int q = 0; q < 2; q++) {
       t.lo1[i][q] = lod[i][1][i + q];
       t.lo2[i][q] = lod[i][2][i + q];
-      t.loE[i][q] = lod[i][0][i + q] + 0.25 * lod[i][2][i + q];
     }
   for (int pp = 1; pp <= 4; pp++)
     for (int m = 0; m < 4; m++)
       t.hi[pp - 1][m] = hid[pp][m] * (pp == 3 ? AWFL_TV5_SQRT_A3A3 : (pp == 4 ? AWFL_TV5_SQRT_A4A4 : 1.0));
-  for (int m = 0; m < 4; m++) t.hiE[m] = hid[0][m] + 0.25 * hid[2][m] + 0.0625 * hid[4][m];
+  t.k2 = 0.25 - w * w / 12.0;
+  t.k4 = (0.0625 - w * w * w * w / 80.0) / AWFL_TV5_SQRT_A4A4;
   return t;
 }
 
@@ -252,19 +252,24 @@ constexpr DTable make_const_dtable() {
   constexpr double raw[4] = AWFL_WENO_IDL_INIT;
   double sum = ((raw[0] + raw[1]) + raw[2]) + raw[3];
   double idl[4] = {raw[0] / (sum + 1.0e-20), raw[1] / (sum + 1.0e-20), raw[2] / (sum + 1.0e-20), raw[3] / (sum + 1.0e-20)};
-  return make_dtable(W3, S5, idl);
+  return make_dtable(W3, S5, idl, 1.0);
 }
 
 constexpr double cabs_(double x) { return x < 0 ? -x : x; }
-// compile-time proof of the identity weno5_blend<true> relies on: E = a2/6 for the lower candidates and
-// Eh = h2/6 + h4/20 for the bridged upper polynomial (h4 is carried times sqrt(625.8))
+// compile-time proof of the cell-average identity weno5_blend relies on, on the generated uniform-grid constants:
+// (a0 - u2) = -a2/12 for the lower candidates and -(a2/12 + a4/80) for the full quartic (stencil form, per stencil value)
 constexpr bool uniform_even_identity_holds() {
-  constexpr DTable T = make_const_dtable();
+  constexpr double S5[5][5] = AWFL_STEN_TO_COEFS_INIT;
+  constexpr double W3[3][3][3] = AWFL_WENO_LOWER_INIT;
   for (int i = 0; i < 3; i++)
-    for (int q = 0; q < 2; q++)
-      if (cabs_(T.loE[i][q] - T.lo2[i][q] / 6.0) > 1e-15) return false;
-  for (int m = 0; m < 4; m++)
-    if (cabs_(T.hiE[m] - (T.hi[1][m] / 6.0 + T.hi[3][m] * (0.05 / AWFL_TV5_SQRT_A4A4))) > 1e-15) return false;
+    for (int s_ = 0; s_ < 3; s_++) {
+      const double centre = (i + s_ == 2) ? 1.0 : 0.0;
+      if (cabs_(W3[i][s_][0] + W3[i][s_][2] / 12.0 - centre) > 1e-15) return false;
+    }
+  for (int s_ = 0; s_ < 5; s_++) {
+    const double centre = (s_ == 2) ? 1.0 : 0.0;
+    if (cabs_(S5[s_][0] + S5[s_][2] / 12.0 + S5[s_][4] / 80.0 - centre) > 1e-15) return false;
+  }
   return true;
 }
 static_assert(uniform_even_identity_holds(), "uniform-grid candidates must reproduce the centre cell average");
@@ -298,7 +303,7 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   p.h2 = T.hi[1][2] * p.a2[1] - T.hi[1][0] * t03;
   p.h3 = T.hi[2][0] * (s03 - s12);
   p.h4 = T.hi[3][3] * (t03 - 3.0 * p.a2[1]);
-  p.E[0] = p.E[1] = p.E[2] = p.Eh = 0.0;   // unused on the uniform grid (weno5_blend<true>)
+  p.k2 = p.k4 = 0.0;   // unused on the uniform grid (weno5_blend<true>)
   weno5_blend<true>(u[2], p, wc, left, right);
 }
 
@@ -313,13 +318,13 @@ PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, cons
   for (int i = 0; i < 3; i++) {
     p.a1[i] = tab[(0 + 2 * i) * ts] * d[i] + tab[(1 + 2 * i) * ts] * d[i + 1];
     p.a2[i] = tab[(6 + 2 * i) * ts] * d[i] + tab[(7 + 2 * i) * ts] * d[i + 1];
-    p.E[i] = tab[(12 + 2 * i) * ts] * d[i] + tab[(13 + 2 * i) * ts] * d[i + 1];
   }
-  p.h1 = tab[18 * ts] * d[0] + (tab[19 * ts] * d[1] + (tab[20 * ts] * d[2] + tab[21 * ts] * d[3]));
-  p.h2 = tab[22 * ts] * d[0] + (tab[23 * ts] * d[1] + (tab[24 * ts] * d[2] + tab[25 * ts] * d[3]));
-  p.h3 = tab[26 * ts] * d[0] + (tab[27 * ts] * d[1] + (tab[28 * ts] * d[2] + tab[29 * ts] * d[3]));
-  p.h4 = tab[30 * ts] * d[0] + (tab[31 * ts] * d[1] + (tab[32 * ts] * d[2] + tab[33 * ts] * d[3]));
-  p.Eh = tab[34 * ts] * d[0] + (tab[35 * ts] * d[1] + (tab[36 * ts] * d[2] + tab[37 * ts] * d[3]));
+  p.h1 = tab[12 * ts] * d[0] + (tab[13 * ts] * d[1] + (tab[14 * ts] * d[2] + tab[15 * ts] * d[3]));
+  p.h2 = tab[16 * ts] * d[0] + (tab[17 * ts] * d[1] + (tab[18 * ts] * d[2] + tab[19 * ts] * d[3]));
+  p.h3 = tab[20 * ts] * d[0] + (tab[21 * ts] * d[1] + (tab[22 * ts] * d[2] + tab[23 * ts] * d[3]));
+  p.h4 = tab[24 * ts] * d[0] + (tab[25 * ts] * d[1] + (tab[26 * ts] * d[2] + tab[27 * ts] * d[3]));
+  p.k2 = tab[28 * ts];
+  p.k4 = tab[29 * ts];
   weno5_blend<false>(u[2], p, wc, left, right);
 }
 

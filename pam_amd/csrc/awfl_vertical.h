@@ -6,7 +6,7 @@
 // The reference inverts with yakl::intrinsics::matinv_ge, a third-party routine absent from the tree (YAKL
 // submodule, version unpinned); here it is Gauss-Jordan elimination without pivoting, (col,row) order.
 //
-// Output per level (and per ensemble member): VZ_STRIDE = 38 doubles, the difference-form table `DTable` of
+// Output per level (and per ensemble member): VZ_STRIDE = 30 doubles, the difference-form table `DTable` of
 // awfl_device.h (make_dtable): lower-candidate x / x^2 / even-edge coefficients and the bridged upper polynomial
 // (WenoLimiter.h:128-136 folded in; linear in the stencil, so exact up to rounding).
 // The stencil-form vert_sten_to_coefs / vert_weno_recon_lower are also returned for the DataManager entries of
@@ -60,7 +60,7 @@ inline void sten_to_coefs_variable_host(int n, const double *locs, double *rslt)
 
 struct VerticalTables {
   bool per_ens;                 // false: all ensemble members share one dz column
-  std::vector<double> table;    // (nz+2,52) or (nz+2,52,nens)
+  std::vector<double> table;    // (nz+2,VZ_STRIDE) or (nz+2,VZ_STRIDE,nens)
   std::vector<double> s2c;      // vert_sten_to_coefs    (nz+2,5,5,nens)
   std::vector<double> wrl;      // vert_weno_recon_lower (nz+2,3,3,3,nens)
 };
@@ -93,7 +93,7 @@ inline void level_matrices(const double *dzcol /* stride nens */, long long stri
       for (int ii = 0; ii < 3; ii++) lo[i][s][ii] = wrl[(i * 3 + s) * 3 + ii];
   for (int s = 0; s < 5; s++)
     for (int ii = 0; ii < 5; ii++) hi[s][ii] = s2c[s * 5 + ii];
-  const DTable t = make_dtable(lo, hi, idl);
+  const DTable t = make_dtable(lo, hi, idl, locs[3] - locs[2]);   // width of the centre cell in the matrices' coordinate
   static_assert(sizeof(DTable) == VZ_STRIDE * sizeof(double), "DTable layout");
   std::memcpy(dform, &t, sizeof(t));
 }
