@@ -238,9 +238,9 @@ def main():
             achieved = alg_bytes / avg_s / 1e9
             ndir = 2 if ny == 1 else 3
             # polynomials per cell-stage: ndir x (2 acoustic + 4+NT advected), x(span+1)/span (whole-line spans: ~1.03);
-            # 119 (uniform-grid directions) / 135 (vertical) FP64 instructions per polynomial of which half are FMAs (ISA
-            # count of the inner loops) -> ~186 flop on average
-            flops = cells * ndir * (6 + nt) * 1.03 * 186.0
+            # 119 (uniform-grid directions) / 128 (vertical) FP64 instructions per polynomial of which half are FMAs (ISA
+            # count of the inner loops) -> ~183 flop on average
+            flops = cells * ndir * (6 + nt) * 1.03 * 183.0
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01_c2_flux_traffic.json")
             if args.config == "c2" and args.nens == 0 and os.path.exists(tpath):
@@ -254,7 +254,7 @@ def main():
                         "valu": {"bound": "fp64-valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                  "note": "the kernel is FP64-VALU-bound (SURVEY F5; counters: SQ_INSTS_VALU x 4 cycles "
-                                         "over GRBM_GUI_ACTIVE -> VALU issuing in ~79% of the cycles at the ~2.1 GHz clock "
+                                         "over GRBM_GUI_ACTIVE -> VALU issuing in ~75-79% of the cycles at the ~2.1 GHz clock "
                                          "held; profiles/r01_c2_pmc_summary.txt): this is the roofline that binds"}}
 
     cpu = None
