@@ -80,3 +80,27 @@ def test_weno_ideal_weights_and_scalar_constants_equal_the_reference():
     dev = open(os.path.join(ROOT, "pam_amd", "csrc", "awfl_device.h")).read()
     assert "const double cs = 350.0" in dev and "constexpr int HS = 3;" in dev
     assert re.search(r"static constexpr hs\s*=\s*\(ord\+1\)/2;", dy)      # ord = 5 -> 3 halo / ghost cells
+
+
+KESSLER_LITERALS = ["36.34", "0.1364", "3.8", "17.27", "2.2", "0.875", "4093.", "1.6", "124.9", "0.2046", "0.525",
+                    "2550000.", "540000.", "273.", "36.", "0.001", "0.8", "1.e-10"]
+
+
+def test_kessler_and_module_literals_appear_in_reference_oracle_and_kernels():
+    """Numeric literals of the Kessler scheme (physics/micro/kessler/Microphysics.h:346-457) and of the sponge layer
+    defaults: each must be present in the reference text, in the oracle restatement and in the HIP kernels (a typo guard;
+    the arithmetic itself is covered by the oracle-vs-HIP parity tests)."""
+    ref = open("/root/reference/physics/micro/kessler/Microphysics.h").read()
+    ora = open(os.path.join(ROOT, "oracle", "awfl_oracle.c")).read()
+    hip = open(os.path.join(ROOT, "pam_amd", "csrc", "modules_kernels.hip")).read()
+    for lit in KESSLER_LITERALS:
+        pat = re.escape(lit.rstrip(".")) + r"(?![\d])"
+        assert re.search(pat, ref), ("reference", lit)
+        assert re.search(pat, ora), ("oracle", lit)
+        assert re.search(pat, hip), ("kernels", lit)
+    for name in ("R_d", "cp_d", "cp_v", "R_v", "p0", "grav"):      # the scheme's constants, Microphysics.h:66-71
+        m = re.search(name + r"\s*=\s*([\d.e+]+)\s*;", ref)
+        from pam_amd.micro import Microphysics
+        assert float(m.group(1)) == getattr(Microphysics, name), name
+    sp = open("/root/reference/pam_core/modules/sponge_layer.h").read()
+    assert re.search(r"num_layers\s*=\s*5;", sp) and re.search(r"time_scale\s*=\s*60", sp)
