@@ -16,7 +16,10 @@
 #include <cstdio>
 #include <fstream>
 
-#include "dynamics/awfl_amd/Dycore.h"
+// The dycore is selected by the include path, as in PAM (dynamics/CMakeLists.txt:5-17: -DPAM_DYCORE=<dir> puts
+// dynamics/<dir> first): -Ipam_amd/csrc/host/dynamics/awfl_amd for the MI355X AWFL step, .../dynamics/spam_surface for
+// the SPAM-surface stub of BASELINE config C5 (built with -DPAMC_DYCORE, like the reference's SPAM builds).
+#include "Dycore.h"
 #include "modules/gcm_forcing.h"     // compiled here; exercised from Python (tests/test_modules.py)
 #include "modules/sponge_layer.h"
 #include "physics/micro/kessler_amd/Microphysics.h"
@@ -69,8 +72,13 @@ int main(int argc, char **argv) {
       if (!in) die("short input file");
       if (hipMemcpy(dm.get<real, 4>(n).data(), buf.data(), ncell * sizeof(real), hipMemcpyHostToDevice) != hipSuccess) die("memcpy");
     }
+#ifdef PAMC_DYCORE
+    (void)mode_a;
+    dycore.pre_time_loop(coupler);                                           // driver.cpp:225-227
+#else
     if (!mode_a) coupler.set_option<bool>("balance_hydrostasis_with_gravity", false);   // after init(), SURVEY 8c
     dycore.declare_current_profile_as_hydrostatic(coupler);                  // the host model does this once per GCM step
+#endif
     for (int s = 0; s < nsteps; s++) {
       coupler.run_module("dycore", [&](pam::PamCoupler &c) { dycore.timeStep(c); });    // driver.cpp:248
       if (with_sponge) coupler.run_module("sponge_layer", modules::sponge_layer);       // driver.cpp:250

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PAM_AMD_AWFL_ABI_VERSION 1
+#define PAM_AMD_AWFL_ABI_VERSION 2
 
 #define PAM_AMD_OK 0
 #define PAM_AMD_EINVAL (-1)   /* bad argument / inconsistent dimensions (reference: endrun) */
@@ -37,12 +37,16 @@ extern "C" {
 typedef struct pam_amd_awfl pam_amd_awfl_t; /* opaque dycore handle */
 
 /* Grid, tracer registry and physical constants the dycore reads from the coupler in Dycore::init
- * (dynamics/awfl/Dycore.h:835-984).  A constant given as NaN takes the default of Dycore.h:871-876. */
+ * (dynamics/awfl/Dycore.h:835-984).  A constant given as NaN is "option absent": the six primary constants then take
+ * the defaults of Dycore.h:871-876 and the five derived ones are derived as in Dycore.h:883-890 (each only if absent,
+ * from the values in force -- a host model that pre-set e.g. gamma_d or C0 gets exactly its value, as :942-950 reads
+ * them back from the coupler). */
 typedef struct pam_amd_awfl_config {
   int nens, nx, ny, nz;                 /* coupler.get_nens/nx/ny/nz (pam_coupler.h:70-91) */
   int num_tracers;                      /* coupler.get_num_tracers() (>=1: water_vapor) */
   double xlen, ylen;                    /* coupler.get_xlen/ylen (m) */
   double R_d, cp_d, R_v, cp_v, p0, grav;/* options of the same names (Dycore.h:871-876) */
+  double cv_d, gamma_d, kappa_d, cv_v, C0; /* options of the same names (Dycore.h:883-890); NaN = absent = derive */
   int idWV;                             /* index of tracer "water_vapor" (Dycore.h:969,974) */
   const unsigned char *tracer_positive; /* host, num_tracers flags (coupler.get_tracer_info, Dycore.h:963-970) */
   const unsigned char *tracer_adds_mass;/* host, num_tracers flags */
@@ -94,6 +98,11 @@ int pam_amd_awfl_set_balance_hydrostasis_with_gravity(pam_amd_awfl_t *h, int val
  * "hy_pressure_cells" (nz,nens); "vert_sten_to_coefs" (nz+2,5,5,nens); "vert_weno_recon_lower" (nz+2,3,3,3,nens).
  * Returns the DEVICE pointer and the dimensions so the host model can register them in its DataManager. */
 int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_ptr, int dims[5], int *ndims);
+/* The reference's DataManager OWNS those entries (dm.register_and_allocate, Dycore.h:868,897-898,983-984) and they
+ * outlive dycore.finalize().  bind_array makes the kernels read and write `device_ptr` (storage the host model's
+ * DataManager allocated with the dims get_array reports) instead of the handle's own buffer; the current contents
+ * are carried over.  Unbound arrays stay in handle-owned storage that pam_amd_awfl_finalize releases. */
+int pam_amd_awfl_bind_array(pam_amd_awfl_t *h, const char *name, double *device_ptr);
 
 /* Dycore::declare_current_profile_as_hydrostatic(coupler, use_gcm_data) (Dycore.h:1392).  gcm == NULL is
  * use_gcm_data=false. */

@@ -17,6 +17,8 @@ class Config(C.Structure):
                 ("xlen", C.c_double), ("ylen", C.c_double),
                 ("R_d", C.c_double), ("cp_d", C.c_double), ("R_v", C.c_double), ("cp_v", C.c_double),
                 ("p0", C.c_double), ("grav", C.c_double),
+                ("cv_d", C.c_double), ("gamma_d", C.c_double), ("kappa_d", C.c_double), ("cv_v", C.c_double),
+                ("C0", C.c_double),
                 ("idWV", C.c_int),
                 ("tracer_positive", C.c_char_p), ("tracer_adds_mass", C.c_char_p),
                 ("vertical_cell_dz", C.c_void_p), ("stream", C.c_void_p)]
@@ -44,6 +46,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_balance_hydrostasis_with_gravity": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_get_array": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]),
+    "pam_amd_awfl_bind_array": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "pam_amd_awfl_declare_current_profile_as_hydrostatic": (C.c_int, [C.c_void_p, C.POINTER(Fields),
                                                                      C.POINTER(GcmColumns)]),
     "pam_amd_awfl_compute_time_step": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_double, _DP]),

@@ -78,8 +78,10 @@ class DataManager:
             self._check_dims(tuple(tensor.shape), dim_names)
         self._e[name] = dict(data=tensor, desc=desc, dims=tuple(tensor.shape), dirty=False, owned=False)
 
-    def unregister(self, name):
-        self._e.pop(name, None)
+    def unregister_and_deallocate(self, name):
+        if name not in self._e:
+            endrun(f"ERROR: Could not find entry {name}")                                           # DataManager.h:230-234
+        del self._e[name]       # a managed entry's storage is released with its last reference; a borrowed one is not ours
 
     def entry_exists(self, name):
         return name in self._e

@@ -48,7 +48,10 @@ constexpr int FLUX_WAVES = FLUX_THREADS / 64;
 #define PAMA_FLUX_NF 2
 #endif
 constexpr int FLUX_NF = PAMA_FLUX_NF;   // advected fields swept together (independent polynomial chains per iteration)
-constexpr int FLUX_MAX_SPAN = 32; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
+#ifndef PAMA_FLUX_MAX_SPAN
+#define PAMA_FLUX_MAX_SPAN 32
+#endif
+constexpr int FLUX_MAX_SPAN = PAMA_FLUX_MAX_SPAN; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
 constexpr int VZ_STRIDE = 30;  // per-level vertical table in difference form (struct DTable)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
@@ -450,7 +453,9 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         double ruf = (w2 - w1) * rcs;
         if (wall) ruf = 0.0;
         fl0[(long long)c * g.cs] = ruf;                       // flux field 0
+#ifndef PAMA_RUF_GLOBAL
         ruf_slot[(c - f0) * nthr] = ruf;
+#endif
         double val = (ruf > 0.0) ? prevR_n : Ln;              // upwind (Dycore.h:368)
         double f = ruf * val;
         f += ppf;
@@ -476,6 +481,8 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       fl[n] = flux + (long long)(1 + fa[n]) * g.fs_flux + fbase;
       prevR[n] = 0.0;
     }
+    const double *flux0 = flux + fbase;   // mass flux of this line (field 0), written by pass 1 of this thread
+    (void)flux0;
     int c = cstart;
 #pragma unroll
     for (int s = 0; s < 5; s++) {
@@ -494,7 +501,11 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         else weno5_const(w[n], wc, L[n], R[n]);
       }
       if (c >= f0) {
+#ifdef PAMA_RUF_GLOBAL
+        const double ruf = flux0[(long long)c * g.cs];
+#else
         const double ruf = ruf_slot[(c - f0) * nthr];
+#endif
         const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
 #pragma unroll
         for (int n = 0; n < NF; n++) fl[n][(long long)c * g.cs] = ruf * (up ? prevR[n] : L[n]);

@@ -228,6 +228,10 @@ struct pam_amd_awfl {
   double *prim0 = nullptr, *prim1 = nullptr, *flux_x = nullptr, *flux_y = nullptr, *flux_z = nullptr;
   double *seed = nullptr, *mult = nullptr, *dz = nullptr, *grav_var = nullptr, *hy_dens = nullptr, *hy_pres = nullptr;
   double *vz = nullptr, *vert_s2c = nullptr, *vert_wrl = nullptr;
+  // storage the kernels actually use for the dycore's named arrays: the handle's own buffers until the host model binds
+  // DataManager-owned storage (pam_amd_awfl_bind_array; the reference's entries are register_and_allocate'd, Dycore.h:868,897-898,983-984)
+  double *act_grav_var = nullptr, *act_hy_dens = nullptr, *act_hy_pres = nullptr, *act_vert_s2c = nullptr, *act_vert_wrl = nullptr;
+  size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
@@ -364,6 +368,16 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) 
   int spmax = G.spx > G.spz ? G.spx : G.spz;
   if (!P.sim2d && G.spy > spmax) spmax = G.spy;
   size_t lds_bytes = (size_t)spmax * FLUX_THREADS * sizeof(double);
+#ifdef PAMA_RUF_GLOBAL
+  lds_bytes = 0;
+#endif
+  if (const char *m = getenv("PAMA_SWEEP_MASK")) {   // EXPERIMENT: time single sweeps (results are wrong)
+    int mask = atoi(m);
+    if (!(mask & 1)) { G.nbx = 0; G.nux = 0; }
+    if (!(mask & 2)) { G.nby = 0; G.nuy = 0; }
+    if (!(mask & 4)) { G.nbz = 0; G.nuz = 0; }
+    G.nbx_l = G.nby_l = 0;
+  }
   if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
   ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
@@ -532,11 +546,13 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->R_d = opt(cfg->R_d, 287.);   h->cp_d = opt(cfg->cp_d, 1003.);
   h->R_v = opt(cfg->R_v, 461.);   h->cp_v = opt(cfg->cp_v, 1859.);
   h->p0 = opt(cfg->p0, 1.e5);     h->grav = opt(cfg->grav, 9.81);
-  h->cv_d = h->cp_d - h->R_d;
-  h->gamma_d = h->cp_d / h->cv_d;
-  h->kappa_d = h->R_d / h->cp_d;
-  h->cv_v = h->R_v - h->cp_v;
-  h->C0 = std::pow(h->R_d * std::pow(h->p0, -h->kappa_d), h->gamma_d);
+  // Dycore.h:877-890: each derived constant is set only if the option is absent, then all are read back from the coupler
+  // (:942-950) -- a host model that pre-set one of them gets ITS value (NaN = absent = derive)
+  h->cv_d = opt(cfg->cv_d, h->cp_d - h->R_d);
+  h->gamma_d = opt(cfg->gamma_d, h->cp_d / h->cv_d);
+  h->kappa_d = opt(cfg->kappa_d, h->R_d / h->cp_d);
+  h->cv_v = opt(cfg->cv_v, h->R_v - h->cp_v);
+  h->C0 = opt(cfg->C0, std::pow(h->R_d * std::pow(h->p0, -h->kappa_d), h->gamma_d));
 
   Params &P = h->P;
   std::memset(&P, 0, sizeof(P));
@@ -600,6 +616,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMemset(h->hy_dens, 0xFF, nzn * 8));
   INIT_TRY(hipMemset(h->hy_pres, 0xFF, nzn * 8));
   P.dz = h->dz; P.grav_var = h->grav_var; P.hy_dens = h->hy_dens; P.hy_pres = h->hy_pres; P.vz = h->vz;
+  h->act_grav_var = h->grav_var; h->act_hy_dens = h->hy_dens; h->act_hy_pres = h->hy_pres;
+  h->act_vert_s2c = h->vert_s2c; h->act_vert_wrl = h->vert_wrl;
+  h->n_vert_s2c = vt.s2c.size(); h->n_vert_wrl = vt.wrl.size();
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -659,15 +678,36 @@ int pam_amd_awfl_get_array(pam_amd_awfl_t *h, const char *name, double **device_
   const std::string k(name);
   const Params &P = h->P;
   if (k == "variable_gravity" || k == "hy_dens_cells" || k == "hy_pressure_cells") {
-    *device_ptr = (k == "variable_gravity") ? h->grav_var : (k == "hy_dens_cells" ? h->hy_dens : h->hy_pres);
+    *device_ptr = (k == "variable_gravity") ? h->act_grav_var : (k == "hy_dens_cells" ? h->act_hy_dens : h->act_hy_pres);
     dims[0] = P.nz; dims[1] = P.nens; *ndims = 2;
   } else if (k == "vert_sten_to_coefs") {
-    *device_ptr = h->vert_s2c; dims[0] = P.nz + 2; dims[1] = 5; dims[2] = 5; dims[3] = P.nens; *ndims = 4;
+    *device_ptr = h->act_vert_s2c; dims[0] = P.nz + 2; dims[1] = 5; dims[2] = 5; dims[3] = P.nens; *ndims = 4;
   } else if (k == "vert_weno_recon_lower") {
-    *device_ptr = h->vert_wrl; dims[0] = P.nz + 2; dims[1] = 3; dims[2] = 3; dims[3] = 3; dims[4] = P.nens; *ndims = 5;
+    *device_ptr = h->act_vert_wrl; dims[0] = P.nz + 2; dims[1] = 3; dims[2] = 3; dims[3] = 3; dims[4] = P.nens; *ndims = 5;
   } else {
     return fail(PAM_AMD_EINVAL, "ERROR: array " + k + " is not owned by the dycore");
   }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_bind_array(pam_amd_awfl_t *h, const char *name, double *device_ptr) {
+  if (!h || !name || !device_ptr) return fail(PAM_AMD_EINVAL, "bind_array: null argument");
+  USE_DEVICE(h);
+  const std::string k(name);
+  const size_t nzn = (size_t)h->P.nz * h->P.nens;
+  double **act = nullptr;
+  size_t n = 0;
+  if (k == "variable_gravity") { act = &h->act_grav_var; n = nzn; }
+  else if (k == "hy_dens_cells") { act = &h->act_hy_dens; n = nzn; }
+  else if (k == "hy_pressure_cells") { act = &h->act_hy_pres; n = nzn; }
+  else if (k == "vert_sten_to_coefs") { act = &h->act_vert_s2c; n = h->n_vert_s2c; }
+  else if (k == "vert_weno_recon_lower") { act = &h->act_vert_wrl; n = h->n_vert_wrl; }
+  else return fail(PAM_AMD_EINVAL, "ERROR: array " + k + " is not owned by the dycore");
+  if (*act != device_ptr) {   // carry the current contents over, then switch
+    HIP_TRY(hipMemcpyAsync(device_ptr, *act, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    *act = device_ptr;
+  }
+  h->P.grav_var = h->act_grav_var; h->P.hy_dens = h->act_hy_dens; h->P.hy_pres = h->act_hy_pres;
   return PAM_AMD_OK;
 }
 
@@ -681,11 +721,11 @@ int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const
     ScopedTimer st(h, "hydro", h->stream);
     const long long n = (long long)h->P.nz * h->P.nens;
     if (h->P.vz_per_ens)
-      hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->grav_var,
-                         h->hy_dens, h->hy_pres);
+      hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0,
+                         h->act_grav_var, h->act_hy_dens, h->act_hy_pres);
     else
-      hipLaunchKernelGGL(awfl_hydro_kernel<false>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->grav_var,
-                         h->hy_dens, h->hy_pres);
+      hipLaunchKernelGGL(awfl_hydro_kernel<false>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0,
+                         h->act_grav_var, h->act_hy_dens, h->act_hy_pres);
     HIP_TRY(hipGetLastError());
   }
   h->hydro_declared = true;

@@ -1,10 +1,15 @@
 // dynamics/awfl_amd/Dycore.h -- the compile-time plug-in class PAM selects with -DPAM_DYCORE=awfl_amd
 // (dynamics/CMakeLists.txt:5-17), forwarding to the C ABI of libpam_amd_awfl.so (include/pam_amd_awfl.h).
 //
-// It uses only members that exist with the same names in PAM's own pam_core/pam_coupler.h / DataManager.h, so the same
-// file compiles against the real PAM headers (inside PAM) and against the minimal work-alike in ../../pam_coupler.h (here).
-// Members replace, one for one, those of dynamics/awfl/Dycore.h (line numbers in the comments).
+// It calls only members that exist, with these names and argument lists, in PAM's own pam_core/pam_coupler.h and
+// pam_core/DataManager.h (tests/test_boundary_surface.py scans this file against those headers where the reference tree
+// is mounted), so the same file compiles inside PAM and against the minimal work-alike in ../../pam_coupler.h (here).
+// Members replace, one for one and with the same signatures, those of dynamics/awfl/Dycore.h (line numbers in the
+// comments).  The only non-coupler calls are the C ABI and hipMemcpy (host -> DataManager array, where the reference
+// uses YAKL's deep_copy_to).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cmath>
 #include <string>
 #include <vector>
@@ -13,12 +18,15 @@
 #include "pam_amd_awfl.h"    // C ABI
 
 class Dycore {
-  pam_amd_awfl_t *h = nullptr;
-  std::vector<double *> trc;   // device pointers of the tracer arrays, coupler registration order
+  // the reference's finalize() and compute_time_step() are const members taking the coupler const (awfl/Dycore.h:65,1548);
+  // the handle and the pointer scratch are implementation state behind that interface
+  mutable pam_amd_awfl_t *h = nullptr;
+  mutable std::vector<double *> trc;   // device pointers of the tracer arrays, coupler registration order
 
   static void chk(int rc) { if (rc) endrun(pam_amd_awfl_last_error()); }          // pam_const.h:249-252
 
-  pam_amd_awfl_fields_t fields(pam::PamCoupler &coupler) {
+  // read-write views of the coupler fields (awfl/Dycore.h:1301-1310): marks the entries dirty like the reference
+  pam_amd_awfl_fields_t fields(pam::PamCoupler &coupler) const {
     auto &dm = coupler.get_data_manager_device_readwrite();                        // pam_coupler.h:65
     trc.clear();
     for (auto &name : coupler.get_tracer_names()) trc.push_back(dm.get<real, 4>(name).data());
@@ -32,32 +40,51 @@ class Dycore {
     return f;
   }
 
+  // read-only views (awfl/Dycore.h:74-83,1357-1366): the C ABI struct is shared with the read-write entry points, the
+  // entry points these are passed to only read
+  pam_amd_awfl_fields_t fields_readonly(pam::PamCoupler const &coupler) const {
+    auto &dm = coupler.get_data_manager_device_readonly();                         // pam_coupler.h:64
+    trc.clear();
+    for (auto &name : coupler.get_tracer_names()) trc.push_back(const_cast<double *>(dm.get<real const, 4>(name).data()));
+    pam_amd_awfl_fields_t f;
+    f.density_dry = const_cast<double *>(dm.get<real const, 4>("density_dry").data());
+    f.uvel = const_cast<double *>(dm.get<real const, 4>("uvel").data());
+    f.vvel = const_cast<double *>(dm.get<real const, 4>("vvel").data());
+    f.wvel = const_cast<double *>(dm.get<real const, 4>("wvel").data());
+    f.temp = const_cast<double *>(dm.get<real const, 4>("temp").data());
+    f.tracers = trc.data();
+    return f;
+  }
+
  public:
   // awfl/Dycore.h:835
   void init(pam::PamCoupler &coupler, bool verbose = false) {
     auto names = coupler.get_tracer_names();
-    std::vector<unsigned char> pos(names.size()), mass(names.size());
+    int num_tracers = coupler.get_num_tracers();
+    std::vector<unsigned char> pos(num_tracers), mass(num_tracers);
     int idWV = -1;
-    for (size_t t = 0; t < names.size(); t++) {
+    for (int t = 0; t < num_tracers; t++) {
       std::string desc;
       bool found, p, m;
       coupler.get_tracer_info(names[t], desc, found, p, m);                        // pam_coupler.h:229
       pos[t] = p; mass[t] = m;
-      if (names[t] == "water_vapor") idWV = (int)t;                                // awfl/Dycore.h:969
+      if (names[t] == "water_vapor") idWV = t;                                     // awfl/Dycore.h:969
     }
     auto opt = [&](char const *k) { return coupler.option_exists(k) ? coupler.get_option<real>(k) : (real)NAN; };
     pam_amd_awfl_config_t cfg;
     cfg.nens = coupler.get_nens(); cfg.nx = coupler.get_nx(); cfg.ny = coupler.get_ny(); cfg.nz = coupler.get_nz();
-    cfg.num_tracers = (int)names.size();
+    cfg.num_tracers = num_tracers;
     cfg.xlen = coupler.get_xlen(); cfg.ylen = coupler.get_ylen();
     cfg.R_d = opt("R_d"); cfg.cp_d = opt("cp_d"); cfg.R_v = opt("R_v"); cfg.cp_v = opt("cp_v");
-    cfg.p0 = opt("p0"); cfg.grav = opt("grav");
+    cfg.p0 = opt("p0"); cfg.grav = opt("grav");                                    // awfl/Dycore.h:871-876
+    cfg.cv_d = opt("cv_d"); cfg.gamma_d = opt("gamma_d"); cfg.kappa_d = opt("kappa_d");
+    cfg.cv_v = opt("cv_v"); cfg.C0 = opt("C0");                                    // awfl/Dycore.h:883-890
     cfg.idWV = idWV;
     cfg.tracer_positive = pos.data(); cfg.tracer_adds_mass = mass.data();
     cfg.vertical_cell_dz = coupler.get_data_manager_device_readonly().get<real const, 2>("vertical_cell_dz").data();
     cfg.stream = nullptr;                                                          // the default stream (what YAKL uses)
     chk(pam_amd_awfl_init(&cfg, &h));
-    // what the reference writes back into the coupler (awfl/Dycore.h:866-891,974-984)
+    // what the reference writes back into the coupler (awfl/Dycore.h:866-891,974)
     coupler.set_option<bool>("balance_hydrostasis_with_gravity", true);
     for (char const *k : {"R_d", "cp_d", "R_v", "cp_v", "p0", "grav", "cv_d", "gamma_d", "kappa_d", "cv_v", "C0"}) {
       double v;
@@ -65,35 +92,50 @@ class Dycore {
       if (!coupler.option_exists(k)) coupler.set_option<real>(k, v);
     }
     coupler.set_option<int>("idWV", idWV);
+    // the dycore's DataManager entries: allocated and owned by the DataManager exactly as in the reference
+    // (awfl/Dycore.h:868,897-898,983-984), so they outlive finalize(); the kernels are bound to that storage
     auto &dm = coupler.get_data_manager_device_readwrite();
     for (char const *name : {"variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs",
                              "vert_weno_recon_lower"}) {
       double *p;
       int dims[5], nd;
       chk(pam_amd_awfl_get_array(h, name, &p, dims, &nd));
-      dm.register_existing<real>(name, "", std::vector<int>(dims, dims + nd), p);   // DataManager.h:158
+      dm.register_and_allocate<real>(name, "", std::vector<int>(dims, dims + nd));   // DataManager.h:91
+      if (nd == 2) chk(pam_amd_awfl_bind_array(h, name, dm.get<real, 2>(name).data()));
+      if (nd == 4) chk(pam_amd_awfl_bind_array(h, name, dm.get<real, 4>(name).data()));
+      if (nd == 5) chk(pam_amd_awfl_bind_array(h, name, dm.get<real, 5>(name).data()));
     }
+    // awfl/Dycore.h:975-981 (bool entries; the reference fills them with deep_copy_to)
+    std::vector<char> pos_b(num_tracers), mass_b(num_tracers);
+    static_assert(sizeof(bool) == 1, "bool entries are copied bytewise");
+    for (int t = 0; t < num_tracers; t++) { pos_b[t] = pos[t] ? 1 : 0; mass_b[t] = mass[t] ? 1 : 0; }
+    dm.register_and_allocate<bool>("tracer_adds_mass", "", {num_tracers});
+    if (hipMemcpy(dm.get<bool, 1>("tracer_adds_mass").data(), mass_b.data(), num_tracers, hipMemcpyHostToDevice) != hipSuccess)
+      endrun("ERROR: copying tracer_adds_mass to the device failed");
+    dm.register_and_allocate<bool>("tracer_positive", "", {num_tracers});
+    if (hipMemcpy(dm.get<bool, 1>("tracer_positive").data(), pos_b.data(), num_tracers, hipMemcpyHostToDevice) != hipSuccess)
+      endrun("ERROR: copying tracer_positive to the device failed");
   }
 
   // awfl/Dycore.h:107
   void timeStep(pam::PamCoupler &coupler) {
-    chk(pam_amd_awfl_set_balance_hydrostasis_with_gravity_if_changed(coupler));
+    chk(sync_balance_option(coupler));
     auto f = fields(coupler);
     chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), /*dt_dyn_hint=*/0., nullptr, nullptr));
   }
 
   // awfl/Dycore.h:65
-  real compute_time_step(pam::PamCoupler &coupler, real cfl = 0.8) {
-    auto f = fields(coupler);
+  real compute_time_step(pam::PamCoupler const &coupler, real cfl = 0.8) const {
+    auto f = fields_readonly(coupler);
     double dt;
     chk(pam_amd_awfl_compute_time_step(h, &f, cfl, &dt));
     return dt;
   }
 
   // awfl/Dycore.h:1392
-  void declare_current_profile_as_hydrostatic(pam::PamCoupler &coupler, bool use_gcm_data = false) {
-    chk(pam_amd_awfl_set_balance_hydrostasis_with_gravity_if_changed(coupler));
-    auto f = fields(coupler);
+  void declare_current_profile_as_hydrostatic(pam::PamCoupler &coupler, bool use_gcm_data = false) const {
+    chk(sync_balance_option(coupler));
+    auto f = fields_readonly(coupler);
     if (!use_gcm_data) { chk(pam_amd_awfl_declare_current_profile_as_hydrostatic(h, &f, nullptr)); return; }
     auto &dm = coupler.get_data_manager_device_readonly();
     pam_amd_awfl_gcm_columns_t g;
@@ -105,25 +147,30 @@ class Dycore {
     chk(pam_amd_awfl_declare_current_profile_as_hydrostatic(h, &f, &g));
   }
 
-  // awfl/Dycore.h:1336 / :1281
-  void convert_coupler_to_dynamics(pam::PamCoupler &c) { auto f = fields(c); chk(pam_amd_awfl_convert_coupler_to_dynamics(h, &f)); }
-  void convert_dynamics_to_coupler(pam::PamCoupler &c) { auto f = fields(c); chk(pam_amd_awfl_convert_dynamics_to_coupler(h, &f)); }
+  // awfl/Dycore.h:1336 / :1281.  The reference passes its halo'd state/tracers arrays as further arguments; here the
+  // dynamics state is resident inside the handle, so the coupler is the only argument.
+  void convert_coupler_to_dynamics(pam::PamCoupler &coupler) const {
+    auto f = fields_readonly(coupler);
+    chk(pam_amd_awfl_convert_coupler_to_dynamics(h, &f));
+  }
+  void convert_dynamics_to_coupler(pam::PamCoupler &coupler) const {
+    auto f = fields(coupler);
+    chk(pam_amd_awfl_convert_dynamics_to_coupler(h, &f));
+  }
 
   char const *dycore_name() const { return pam_amd_awfl_dycore_name(h); }           // awfl/Dycore.h:1544
 
-  void finalize(pam::PamCoupler &coupler) {                                         // awfl/Dycore.h:1548
+  // awfl/Dycore.h:1548 (empty there).  The DataManager keeps the dycore's entries -- it owns them -- and frees them in
+  // its own finalize (DataManager.h:596-602); only the handle (scratch arrays, streams) is released here.
+  void finalize(pam::PamCoupler const &coupler) const {
     if (!h) return;
-    auto &dm = coupler.get_data_manager_device_readwrite();
-    for (char const *name : {"variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs",
-                             "vert_weno_recon_lower"})
-      dm.unregister(name);
     pam_amd_awfl_finalize(h);
     h = nullptr;
   }
 
  private:
   // the reference re-reads the option on every call (awfl/Dycore.h:284,624,1410)
-  int pam_amd_awfl_set_balance_hydrostasis_with_gravity_if_changed(pam::PamCoupler &coupler) {
+  int sync_balance_option(pam::PamCoupler const &coupler) const {
     double cur;
     int rc = pam_amd_awfl_get_option(h, "balance_hydrostasis_with_gravity", &cur);
     if (rc) return rc;

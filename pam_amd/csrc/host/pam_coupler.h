@@ -68,7 +68,8 @@ class DataManager {
   ~DataManager() { finalize(); }
 
   template <class T>
-  void register_and_allocate(std::string name, std::string desc, std::vector<int> dims, std::vector<std::string> dim_names = {}) {
+  void register_and_allocate(std::string name, std::string desc, std::vector<int> dims,
+                             std::vector<std::string> dim_names = std::vector<std::string>(), bool positive = false) {   // DataManager.h:91-95
     if (entries.count(name)) endrun("ERROR: Duplicate entry name " + name);
     for (size_t i = 0; i < dim_names.size(); i++) {
       auto it = dimensions.find(dim_names[i]);
@@ -84,14 +85,16 @@ class DataManager {
   }
 
   template <class T>
-  void register_existing(std::string name, std::string desc, std::vector<int> dims, T *ptr) {
+  void register_existing(std::string name, std::string desc, std::vector<int> dims, T *ptr,
+                         std::vector<std::string> dim_names = std::vector<std::string>(), bool positive = false) {       // DataManager.h:158-163
     if (entries.count(name)) endrun("ERROR: Duplicate entry name " + name);
     entries[name] = Entry{(void *)ptr, desc, dims, sizeof(T), false, false};
   }
 
-  void unregister(std::string name) {
+  // DataManager.h:230-234: frees a managed entry's storage, only forgets a borrowed (register_existing) one
+  void unregister_and_deallocate(std::string name) {
     auto it = entries.find(name);
-    if (it == entries.end()) return;
+    if (it == entries.end()) endrun("ERROR: Could not find entry " + name);
     if (it->second.owned) (void)hipFree(it->second.ptr);
     entries.erase(it);
   }

@@ -43,7 +43,8 @@ class Dycore:
         cfg = capi.Config()
         cfg.nens, cfg.nx, cfg.ny, cfg.nz, cfg.num_tracers = nens, nx, ny, nz, len(names)
         cfg.xlen, cfg.ylen = coupler.get_xlen(), coupler.get_ylen()
-        for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav"):       # Dycore.h:871-876: defaults if absent
+        for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav",        # Dycore.h:871-876: defaults if absent
+                  "cv_d", "gamma_d", "kappa_d", "cv_v", "C0"):       # Dycore.h:883-890: derived if absent
             setattr(cfg, k, float(coupler.get_option(k)) if coupler.option_exists(k) else math.nan)
         cfg.idWV = names.index("water_vapor")
         cfg.tracer_positive, cfg.tracer_adds_mass = pos, mass
@@ -61,12 +62,16 @@ class Dycore:
             if not coupler.option_exists(k):
                 coupler.set_option(k, self.get_option(k))
         coupler.set_option("idWV", cfg.idWV)
-        # dycore-owned DataManager entries (Dycore.h:868,897-898,975-984)
+        # the dycore's DataManager entries (Dycore.h:868,897-898,975-984): allocated and owned by the DataManager as in the
+        # reference (they outlive dycore.finalize); the kernels are bound to that storage
         dm = coupler.get_data_manager_device_readwrite()
         for name in ("variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs", "vert_weno_recon_lower"):
-            dm.register_existing(name, "", self._owned_array(name))
-        dm.register_existing("tracer_adds_mass", "", torch.tensor(list(mass), dtype=torch.bool, device=coupler.device))
-        dm.register_existing("tracer_positive", "", torch.tensor(list(pos), dtype=torch.bool, device=coupler.device))
+            t = dm.register_and_allocate(name, "", self._owned_array(name).shape)
+            check(lib.pam_amd_awfl_bind_array(self._h, name.encode(), t.data_ptr()))
+        dm.register_and_allocate("tracer_adds_mass", "", (len(names),), dtype=torch.bool).copy_(
+            torch.tensor(list(mass), dtype=torch.bool))
+        dm.register_and_allocate("tracer_positive", "", (len(names),), dtype=torch.bool).copy_(
+            torch.tensor(list(pos), dtype=torch.bool))
         # optional idealised initial data (Dycore.h:986-1090; the reference compiles this under PAM_STANDALONE and reads the
         # `initData` key of the YAML file named by option "standalone_input_file")
         if coupler.option_exists("standalone_input_file"):
@@ -178,12 +183,9 @@ class Dycore:
         return lib.pam_amd_awfl_dycore_name(self._h).decode()
 
     def finalize(self, coupler=None):
+        # Dycore.h:1548: the reference's finalize is empty and takes the coupler const -- the DataManager keeps the dycore's
+        # entries (it owns them); only the handle (scratch, streams) is released here
         if self._h is not None:
-            if coupler is not None:
-                dm = coupler.get_data_manager_device_readwrite()
-                for name in ("variable_gravity", "hy_dens_cells", "hy_pressure_cells", "vert_sten_to_coefs",
-                             "vert_weno_recon_lower", "tracer_adds_mass", "tracer_positive"):
-                    dm.unregister(name)
             check(self._lib.pam_amd_awfl_finalize(self._h))
             self._h = None
 
