@@ -1,39 +1,50 @@
 #!/usr/bin/env python3
 """bench.py -- cell-updates/s of the MI355X-native AWFL dycore step (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nens E] [--config c2|c3|c4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--scaling weak|strong] [--nens E]
 
 A "step" is one `Dycore::timeStep` (Dycore.h:107) over the whole resident ensemble: coupler->dycore conversion,
 CFL reduction, `ncycles` SSPRK3 sub-steps (3 tendency evaluations each) and dycore->coupler conversion, with the
 coupler fields already resident in HBM.  A "cell-update" is one grid cell advanced by one sub-step;
-value = nens*nz*ny*nx*sum(ncycles) / wall seconds of the K timed steps (max over ranks).
+value = sum over ranks of nens*nz*ny*nx*sum(ncycles) / wall seconds of the K timed steps (max over ranks).
 
 Workload (config c2 = BASELINE.json configs[1], the configuration the metric is quoted on): AWFL supercell,
 nens=1024 CRMs of 32x32x60 on the L60 stretched grid, NT=1 (water_vapor), crm_dt=2 s (ncycles ~ 9), synthetic
-supercell sounding + splitmix64 temperature perturbation (no datasets exist offline).  At N>1 each rank owns
-nens=1024 members (weak scaling by nens sharding); the only inter-rank exchange is the 8-byte
-all-reduce(MIN) of the CFL time step per timeStep.
+supercell sounding + splitmix64 temperature perturbation (no datasets exist offline).
+
+Ranks.  One process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks
+come from RANK/LOCAL_RANK/WORLD_SIZE (WORLD_SIZE must equal --gpus).  Without those variables `--gpus N` makes THIS
+process a launcher: it starts N fresh child processes (before anything touches a GPU: the parent never imports torch),
+one rank each, and prints rank 0's JSON line.  The ensemble shards by member index with no data-path collective; the one
+exchange is the 8-byte all-reduce(MIN) of the CFL time step per timeStep (RCCL; Dycore.h:141-145 semantics).
+`--scaling weak` (default): every rank holds the config's nens (1024 for c2).  `--scaling strong`: the config's nens is
+the TOTAL, split over the ranks (c2: 1024 -> 128 per GPU at N=8; c4's 512 is already the per-GPU shard of nens=4096).
+When the box has fewer GPUs than ranks (rehearsal on a 1-GPU box) the ranks share device 0 and reduce over gloo.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = awfl_flux_kernel (reconstruction + fluxes, ~90% of device time).  achieved =
-               algorithmic bytes per launch / mean launch duration; one launch = one tendency stage over all cells =
-               cells/3 cell-updates x 64*(5+NT) B.  Launch durations are measured live with HIP events on
-               the stream the kernels run on (inside libpam_amd_awfl.so: pam_amd_awfl_set_kernel_timing), in a separate
-               un-timed pass.  The kernel is FP64-VALU-bound, not HBM-bound: `valu` gives that roofline.
-  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/awfl_oracle.c, OpenMP over the flux loop)
-               timed on this host on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      the dominant kernel of the stage (by device time, nothing co-running): achieved = algorithmic bytes per
+                launch / mean launch duration; one launch = one tendency stage over all cells = cells/3 cell-updates x
+                64*(5+NT) B.  Launch durations are measured live with HIP events on the stream the kernels
+                run on (inside libpam_amd_awfl.so: pam_amd_awfl_set_kernel_timing), in a separate un-timed pass.
+                `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command, valid only for the build they
+                were taken from (content hash of pam_amd/csrc; null when the sources have changed since).
+                `kernels` lists every stage kernel with the bytes it must itself move and its FP64 work.
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, oracle/awfl_oracle.c, OpenMP over the flux loop)
+                timed on this host on a bounded sample of the same workload (rank 0, N=1 only).
+  other_configs C3 / C4 throughput on this GPU (N=1, default run only), measured the same way with fewer steps.
 """
 import argparse
 import copy
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec; 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
@@ -44,18 +55,49 @@ CONFIGS = {
     "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
     "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
 }
+STAGE_KERNELS = ("flux", "xupd", "fct_mult", "trupd", "update")
 
 
-def make_inputs(idz, nens, nx, ny, nz, zint, tracers, consts, xlen, ylen, nens_gen=16, id0=0):
-    """numpy coupler fields for nens_gen distinct members; the caller tiles them over nens on the GPU."""
-    f = idz.supercell_fields(nens_gen, nx, ny, nz, zint, consts=consts, tracers=tracers, magnitude=0.1, id0=id0)
-    if len(tracers) > 1:
-        idz.add_tracer_blobs(f, tracers, xlen, ylen, zint)
-    return f
+def csrc_hash():
+    """content hash of the kernel sources: ties a committed PMC profile to the build it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        p = os.path.join(d, f)
+        if os.path.isfile(p) and f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Parent of an N-rank run: fresh children, started before this process has imported torch or touched a GPU."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
 
 def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
     """Oracle timed on the host cores on a bounded sample (a few ensemble members of the same grid)."""
+    import numpy as np
     from oracle import awfl_oracle as ao
     nens_pg, nx, ny = CONFIGS[cfg_name][:3]
     names, pos, mass, idwv = idz.tracer_flags(tracers)
@@ -101,34 +143,195 @@ def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
                       "crm_dt=%.2g s = %d sub-steps, %.1f s wall" % (kind_note, threads, nens, nx, ny, nz, dt, ncyc, el)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--nens", type=int, default=0, help="members per GPU (default: the config's)")
-    ap.add_argument("--seg", type=int, default=0, help="flux-kernel chunk length (default: library default)")
-    ap.add_argument("--span", type=int, default=-1, help="flux-kernel faces per thread (default: automatic)")
-    ap.add_argument("--chunks", type=int, default=-1, help="internal ensemble chunks / HIP streams (default: automatic)")
-    ap.add_argument("--lds-floor", type=int, default=64 * 1024, help="flux-kernel LDS floor in bytes when chunks > 1")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+class Job:
+    """One config resident on this rank's GPU: coupler + dycore + synthetic inputs."""
 
+    def __init__(self, cfg_name, args, dev, rank, world, nens_override=0):
+        import numpy as np
+        import torch
+        from pam_amd import Dycore, PamCoupler, idealized as idz, parallel
+        self.torch, self.parallel, self.idz = torch, parallel, idz
+        nens_pg, nx, ny, trname, cname, crm_dt, desc = CONFIGS[cfg_name]
+        if nens_override > 0:
+            nens_pg = nens_override
+        self.nens_total = nens_pg * world
+        if args.scaling == "strong":
+            self.nens_total = nens_pg
+            lo, hi = parallel.shard_range(nens_pg, rank, world)
+            nens_pg = hi - lo
+            if nens_pg < 1:
+                raise SystemExit("bench.py: --scaling strong leaves rank %d without members" % rank)
+        self.cfg_name, self.desc, self.crm_dt = cfg_name, desc, crm_dt
+        self.nens, self.nx, self.ny, self.nz = nens_pg, nx, ny, 60
+        self.tracers = {"none": idz.TRACERS_NONE, "kessler_shoc": idz.TRACERS_KESSLER_SHOC, "p3_shoc": idz.TRACERS_P3_SHOC}[trname]
+        self.consts = {"default": idz.CONSTS_DEFAULT, "p3": idz.CONSTS_P3}[cname]
+        self.nt = len(self.tracers)
+        self.zint = idz.l60_interfaces()
+        self.xlen = nx * 1000.0
+        self.ylen = ny * 1000.0 if ny > 1 else self.xlen
+        self.world = world
+        # ---- coupler + dycore, inputs resident in HBM before anything is timed
+        coupler = PamCoupler(dev)
+        coupler.set_option("crm_dt", crm_dt)
+        for k, v in self.consts.items():
+            coupler.set_option(k, v)
+        coupler.allocate_coupler_state(self.nz, ny, nx, nens_pg)
+        coupler.set_grid(self.xlen, self.ylen, self.zint)
+        for n, p, m in self.tracers:
+            coupler.add_tracer(n, "", p, m)
+        dycore = Dycore()
+        dycore.init(coupler)
+        if args.seg > 0:
+            dycore.set_flux_segment(args.seg)
+        if args.span >= 0:
+            dycore.set_flux_span(args.span)
+        if args.fused >= 0:
+            dycore.set_fused_stage(args.fused)
+        self.chunks = args.chunks
+        self.lds_floor = args.lds_floor
+        if args.chunks >= 0:
+            dycore.set_ensemble_chunks(args.chunks, args.lds_floor)
+        nens_gen = min(16, nens_pg)
+        f = idz.supercell_fields(nens_gen, nx, ny, self.nz, self.zint, consts=self.consts, tracers=self.tracers,
+                                 magnitude=0.1, id0=rank * 1000)
+        if self.nt > 1:
+            idz.add_tracer_blobs(f, self.tracers, self.xlen, self.ylen, self.zint)
+        reps = (nens_pg + nens_gen - 1) // nens_gen
+        # members differ between tiles by a small smooth temperature offset so no two CRMs are identical
+        off = (torch.arange(nens_pg, device=dev, dtype=torch.float64) // nens_gen) * 1.0e-3
+
+        def tile(a):
+            return torch.from_numpy(a).to(dev).repeat(*([1] * (a.ndim - 1)), reps)[..., :nens_pg].contiguous()
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            coupler.dm.get(k).copy_(tile(f[k]))
+        coupler.dm.get("temp").add_(off)
+        for t, name in enumerate(coupler.get_tracer_names()):
+            coupler.dm.get(name).copy_(tile(f["tracers"][t]))
+        del f
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+        torch.cuda.synchronize()
+        self.coupler, self.dycore = coupler, dycore
+
+    def one_step(self):
+        if self.world > 1:
+            return self.parallel.sharded_time_step(self.dycore, self.coupler)
+        return self.dycore.timeStep(self.coupler)
+
+    def timed(self, steps, warmup, dist=None, backend="nccl", dev=None):
+        torch = self.torch
+        for _ in range(warmup):
+            self.one_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        substeps = 0
+        for _ in range(steps):
+            substeps += self.one_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        updates = float(self.nens * self.nz * self.ny * self.nx * substeps)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            u = torch.tensor([updates], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(u, op=dist.ReduceOp.SUM)
+            updates = float(u.item())
+        return updates, elapsed, substeps
+
+    def kernel_pass(self):
+        d = self.dycore
+        d.reset_kernel_timing()
+        self.one_step()
+        self.torch.cuda.synchronize()
+        out = {}
+        for name in STAGE_KERNELS + ("init_prim", "finalize", "cfl"):
+            ms, n = d.get_kernel_timing(name)
+            if n:
+                out[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
+        return out
+
+    def close(self):
+        self.dycore.finalize(self.coupler)
+        self.coupler.dm.finalize()
+        self.torch.cuda.empty_cache()
+
+
+def stage_rooflines(job, alone):
+    """Per-kernel accounting of one tendency stage (nothing co-running: chunks=1).  `own_bytes`: what the kernel must move
+    given the kernel split (every field it reads or writes, once); `flops`: FP64 operations of its WENO polynomials (183 per
+    polynomial on average: 119/128 FP64 instructions, half of them FMAs -- ISA count) plus ~60 per cell
+    and state variable for the update arithmetic and ~250 for a pow."""
+    cells = float(job.nens * job.nz * job.ny * job.nx)
+    nt, d3 = job.nt, job.ny > 1
+    fb = cells * 8.0                       # one interior-sized field
+    pb = fb * (job.nz + 6) / job.nz        # one prim field (3 ghost levels below and above)
+    fused = "xupd" in alone
+    poly = 183.0 * 1.03
+    acct = {}
+    if fused:
+        ndir = 2 if d3 else 1              # flux kernel sweeps y (3-D only) and z
+        acct["flux"] = (ndir * (6 + nt) * pb + ndir * (5 + nt) * fb, cells * ndir * (6 + nt) * poly)
+        nyz = 2 if d3 else 1
+        acct["xupd"] = ((6 + nt) * pb + 5 * pb + nyz * 2 * 5 * fb + 6 * pb + nt * fb,
+                        cells * ((6 + nt) * poly + 5 * 60.0))
+        acct["fct_mult"] = (nt * ((3 if d3 else 2) + 2) * fb, cells * nt * 20.0)
+        acct["trupd"] = (nt * ((3 if d3 else 2) + 1) * fb + (2 * nt + 6) * pb + nt * pb + pb + nt * fb, cells * (nt * 60.0 + 250.0))
+    else:
+        ndir = 3 if d3 else 2
+        acct["flux"] = (ndir * (6 + nt) * pb + ndir * (5 + nt) * fb, cells * ndir * (6 + nt) * poly)
+        acct["fct_mult"] = (nt * (ndir + 2) * fb, cells * nt * 20.0)
+        acct["update"] = (ndir * (5 + nt) * fb + 2 * (6 + nt) * pb + nt * fb + (6 + nt) * pb + nt * fb,
+                          cells * ((5 + nt) * 60.0 + 250.0))
+    out = []
+    for name, (nbytes, flops) in acct.items():
+        if name not in alone:
+            continue
+        s = alone[name]["avg_ms"] * 1e-3
+        out.append({"kernel": "awfl_%s_kernel" % name.replace("fct_mult", "fct"), "avg_launch_ms": alone[name]["avg_ms"],
+                    "own_bytes_per_launch": nbytes, "own_GBps": nbytes / s / 1e9, "hbm_frac": nbytes / s / 1e9 / HBM_PEAK_GBS,
+                    "fp64_flops_per_launch": flops, "fp64_TFLOPs": flops / s / 1e12,
+                    "valu_frac": flops / s / 1e12 / FP64_VALU_PEAK_TFLOPS})
+    return out
+
+
+def worker(args):
     import torch
     import torch.distributed as dist
-    from pam_amd import Dycore, PamCoupler, idealized as idz, parallel
+    from pam_amd import idealized as idz
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # PAM_AMD_DIST_BACKEND=gloo is a rehearsal switch: several ranks on ONE GPU (RCCL refuses that), collectives on CPU
-    backend = os.environ.get("PAM_AMD_DIST_BACKEND", "nccl")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node N bench.py --gpus N), or run `python bench.py --gpus N` without WORLD_SIZE set and "
+                         "let it start the ranks" % (args.gpus, world))
+    if os.environ.get("PAM_AMD_BENCH_DRYRUN") == "1":
+        # launcher rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous over gloo, count the ranks, no dycore
+        n = 1.0
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1, dtype=torch.float64)
+            dist.all_reduce(t)
+            n = float(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": n, "scaling": args.scaling}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()
-    dev = torch.device("cuda", dev_index)
+    ndev = torch.cuda.device_count()
+    # PAM_AMD_DIST_BACKEND=gloo is the rehearsal switch: several ranks on ONE GPU (RCCL refuses that), collectives on CPU.
+    # It is chosen automatically when the box has fewer GPUs than ranks.
+    backend = os.environ.get("PAM_AMD_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -137,146 +340,125 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    dd = dist if world > 1 else None
 
-    nens_pg, nx, ny, trname, cname, crm_dt, desc = CONFIGS[args.config]
-    if args.nens > 0:
-        nens_pg = args.nens
-    nz = 60
-    tracers = {"none": idz.TRACERS_NONE, "kessler_shoc": idz.TRACERS_KESSLER_SHOC, "p3_shoc": idz.TRACERS_P3_SHOC}[trname]
-    consts = {"default": idz.CONSTS_DEFAULT, "p3": idz.CONSTS_P3}[cname]
-    nt = len(tracers)
-    zint = idz.l60_interfaces()
-    xlen = nx * 1000.0
-    ylen = ny * 1000.0 if ny > 1 else xlen
-
-    # ---- coupler + dycore, inputs resident in HBM before anything is timed
-    coupler = PamCoupler(dev)
-    coupler.set_option("crm_dt", crm_dt)
-    for k, v in consts.items():
-        coupler.set_option(k, v)
-    coupler.allocate_coupler_state(nz, ny, nx, nens_pg)
-    coupler.set_grid(xlen, ylen, zint)
-    for n, p, m in tracers:
-        coupler.add_tracer(n, "", p, m)
-    dycore = Dycore()
-    dycore.init(coupler)
-    if args.seg > 0:
-        dycore.set_flux_segment(args.seg)
-    if args.span >= 0:
-        dycore.set_flux_span(args.span)
-    if args.chunks >= 0:
-        dycore.set_ensemble_chunks(args.chunks, args.lds_floor)
-    nens_gen = min(16, nens_pg)
-    f = make_inputs(idz, nens_pg, nx, ny, nz, zint, tracers, consts, xlen, ylen, nens_gen=nens_gen, id0=rank * 1000)
-    reps = (nens_pg + nens_gen - 1) // nens_gen
-    # members differ between tiles by a small smooth temperature offset so no two CRMs are identical
-    off = (torch.arange(nens_pg, device=dev, dtype=torch.float64) // nens_gen) * 1.0e-3
-
-    def tile(a):
-        return torch.from_numpy(a).to(dev).repeat(*([1] * (a.ndim - 1)), reps)[..., :nens_pg].contiguous()
-    for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
-        coupler.dm.get(k).copy_(tile(f[k]))
-    coupler.dm.get("temp").add_(off)
-    for t, name in enumerate(coupler.get_tracer_names()):
-        coupler.dm.get(name).copy_(tile(f["tracers"][t]))
-    del f
-    dycore.declare_current_profile_as_hydrostatic(coupler)
-    torch.cuda.synchronize()
-
-    def one_step():
-        if world > 1:
-            return parallel.sharded_time_step(dycore, coupler)
-        return dycore.timeStep(coupler)
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    substeps = 0
-    for _ in range(args.steps):
-        substeps += one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    cells = nens_pg * nz * ny * nx
-    total_updates = cells * substeps * world
-    value = total_updates / elapsed
+    job = Job(args.config, args, dev, rank, world, args.nens)
+    updates, elapsed, substeps = job.timed(args.steps, args.warmup, dd, backend, dev)
+    value = updates / elapsed
+    cells = job.nens * job.nz * job.ny * job.nx
+    nt = job.nt
 
     # ---- per-kernel durations (HIP events on the stream each kernel is launched on), separate un-timed passes
-    roofline = None
-    kernels = {}
+    roofline, kernels, kernel_rooflines = None, {}, []
     if not args.no_kernel_timing:
-        def timed_pass():
-            dycore.reset_kernel_timing()
-            one_step()
-            torch.cuda.synchronize()
-            out = {}
-            for name in ("flux", "fct_mult", "update", "init_prim", "finalize", "cfl"):
-                ms, n = dycore.get_kernel_timing(name)
-                if n:
-                    out[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
-            return out
-        dycore.set_kernel_timing(True)
-        kernels = timed_pass()                         # shipped configuration (chunks overlap: durations include contention)
-        # kernel-level roofline: the dominant kernel on its own (one chunk = whole ensemble per launch, nothing co-running)
-        dycore.set_ensemble_chunks(1)
-        alone = timed_pass()
-        dycore.set_ensemble_chunks(args.chunks if args.chunks >= 0 else 0, args.lds_floor)
-        dycore.set_kernel_timing(False)
-        if "flux" in alone:
-            avg_s = alone["flux"]["avg_ms"] * 1e-3
+        d = job.dycore
+        d.set_kernel_timing(True)
+        kernels = job.kernel_pass()                    # shipped configuration (chunks overlap: durations include contention)
+        d.set_ensemble_chunks(1)                       # every stage kernel on its own: whole ensemble per launch
+        alone = job.kernel_pass()
+        d.set_ensemble_chunks(args.chunks if args.chunks >= 0 else 0, args.lds_floor)
+        d.set_kernel_timing(False)
+        kernel_rooflines = stage_rooflines(job, alone)
+        stage = [k for k in STAGE_KERNELS if k in alone]
+        if stage:
+            dom = max(stage, key=lambda k: alone[k]["total_ms"])
+            avg_s = alone[dom]["avg_ms"] * 1e-3
             alg_bytes = cells / 3.0 * 64.0 * (5 + nt)            # 64*(5+NT) B per cell-update, 1/3 per stage
             achieved = alg_bytes / avg_s / 1e9
-            ndir = 2 if ny == 1 else 3
-            # polynomials per cell-stage: ndir x (2 acoustic + 4+NT advected), x(span+1)/span (whole-line spans: ~1.03);
-            # 119 (uniform-grid directions) / 128 (vertical) FP64 instructions per polynomial of which half are FMAs (ISA
-            # count of the inner loops) -> ~183 flop on average
-            flops = cells * ndir * (6 + nt) * 1.03 * 183.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_c2_flux_traffic.json")
-            if args.config == "c2" and args.nens == 0 and os.path.exists(tpath):
-                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]   # rocprofv3 PMC passes of this same command
-            roofline = {"bound": "hbm", "kernel": "awfl_flux_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "avg_launch_ms": alone["flux"]["avg_ms"], "alg_bytes_per_launch": alg_bytes,
-                        "note": "one launch = one tendency stage of the whole ensemble, measured with --chunks 1 "
-                                "(nothing co-running); in the shipped chunked configuration launches are per chunk and "
-                                "overlap the update kernels (see kernels)",
-                        "valu": {"bound": "fp64-valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                 "note": "the kernel is FP64-VALU-bound (SURVEY F5; counters: SQ_INSTS_VALU x 4 cycles "
-                                         "over GRBM_GUI_ACTIVE -> VALU issuing in ~75-79% of the cycles at the ~2.1 GHz clock "
-                                         "held; profiles/r01_c2_pmc_summary.txt): this is the roofline that binds"}}
+            kname = "awfl_%s_kernel" % dom.replace("fct_mult", "fct")
+            mine = [k for k in kernel_rooflines if k["kernel"] == kname]
+            traffic, tnote = None, "no PMC profile for this configuration"
+            tpath = os.path.join(ROOT, "profiles", "r02_c2_traffic.json")
+            if args.config == "c2" and args.nens == 0 and args.scaling == "weak" and os.path.exists(tpath):
+                prof = json.load(open(tpath))
+                if prof.get("csrc_hash") == csrc_hash() and kname in prof.get("kernels", {}):
+                    traffic = prof["kernels"][kname]["hbm_bytes_per_launch"]
+                    tnote = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, this build (%s)" % prof["csrc_hash"]
+                else:
+                    tnote = "profiles/r02_c2_traffic.json was measured on another build of pam_amd/csrc (or lacks this kernel): not reported"
+            stage_ms = sum(alone[k]["avg_ms"] for k in stage)
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,
+                        "avg_launch_ms": alone[dom]["avg_ms"], "alg_bytes_per_launch": alg_bytes,
+                        "binding_roofline": "fp64-valu",
+                        "note": "one launch = one tendency stage of the whole ensemble, measured with --chunks 1 (nothing "
+                                "co-running); achieved = SURVEY 8d algorithmic bytes of a whole stage / this kernel's "
+                                "duration.  The kernel is FP64-VALU-bound (SURVEY F5), see `valu`; all stage kernels "
+                                "back to back take %.2f ms" % stage_ms,
+                        "stage_ms_back_to_back": stage_ms,
+                        "stage_frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "valu": ({"bound": "fp64-valu", "achieved": mine[0]["fp64_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": mine[0]["valu_frac"]} if mine else None)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(idz, args.config, nz, zint, tracers, consts, xlen, ylen, crm_dt)
+            cpu = cpu_baseline(idz, args.config, job.nz, job.zint, job.tracers, job.consts, job.xlen, job.ylen, job.crm_dt)
         except Exception as e:   # the baseline is a reported extra; never fail the bench line for it
             cpu = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    desc, nens_pg, nens_total = job.desc % job.nens, job.nens, job.nens_total
+    ny, nx, nz, crm_dt = job.ny, job.nx, job.nz, job.crm_dt
+    job.close()
+    del job
+
+    # ---- the other single-GPU configurations, same procedure, fewer steps (default N=1 run only)
+    others = None
+    if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs:
+        others = {}
+        for c in ("c3", "c4"):
+            try:
+                j = Job(c, args, dev, 0, 1)
+                u, el, sub = j.timed(3, 1)
+                others[c] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / 3 * 1e3, "workload": j.desc % j.nens,
+                             "num_tracers": j.nt, "substeps_per_step": sub / 3.0,
+                             "hbm_frac": u / el * 64.0 * (5 + j.nt) / 1e9 / HBM_PEAK_GBS}
+                j.close()
+                del j
+            except Exception as e:
+                others[c] = {"value": None, "error": repr(e)}
 
     if rank == 0:
         out = {"metric": "cell-updates/sec (AWFL dycore step)", "value": value, "unit": "cell-updates/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": desc % nens_pg, "nens_per_gpu": nens_pg, "nens_total": nens_pg * world, "nx": nx, "ny": ny,
+               "config": {"workload": desc, "nens_per_gpu": nens_pg, "nens_total": nens_total, "nx": nx, "ny": ny,
                           "nz": nz, "num_tracers": nt, "crm_dt": crm_dt, "substeps_per_step": substeps / args.steps,
-                          "parallelism": "nens-shard x%d" % world},
-               "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}
+                          "parallelism": "nens-shard x%d" % world,
+                          "collective": None if world == 1 else "all-reduce(MIN) of dt, 8 B per timeStep, backend %s%s" % (
+                              backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev))},
+               "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
+               "other_configs": others}
         print(json.dumps(out))
-    dycore.finalize(coupler)
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--nens", type=int, default=0, help="members per GPU (weak) / in total (strong); default: the config's")
+    ap.add_argument("--seg", type=int, default=0, help="flux-kernel chunk length (default: library default)")
+    ap.add_argument("--span", type=int, default=-1, help="flux-kernel faces per thread (default: automatic)")
+    ap.add_argument("--chunks", type=int, default=-1, help="internal ensemble chunks / HIP streams (default: automatic)")
+    ap.add_argument("--fused", type=int, default=-1, help="1/0: fused x-sweep stage / three-kernel stage (default: library default)")
+    ap.add_argument("--lds-floor", type=int, default=64 * 1024, help="flux-kernel LDS floor in bytes when chunks > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -129,7 +129,7 @@ int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_aw
 /* Enable HIP-event timing of every kernel launch on the handle's stream (off by default: zero overhead). */
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
 /* Accumulated device time (ms) and launch count of kernel `name` ("flux","fct_mult","update","init_prim",
- * "finalize","cfl","hydro") since the last reset; synchronises the stream. */
+ * "finalize","cfl","hydro","xupd","trupd") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 /* flux-kernel tuning knobs; results do not depend on them.
@@ -145,9 +145,21 @@ int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
  * other range's blocks can co-reside; default 64 KiB = 2 workgroups per CU).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
 
+/* Stage structure.  1 (default where supported: nx <= 64): per stage  flux(y,z) -> fused x-sweep + state update -> FCT
+ * multiplier -> tracer update, the state's x fluxes never reach HBM.  0: flux(x,y,z) -> FCT multiplier ->
+ * update, every face flux stored.  Both produce the same bits (tests/test_fused_stage.py). */
+int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
+
 /* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
-/* name: "prim0","prim1","flux_x","flux_y","flux_z","seed","mult". */
+/* name: "prim0","prim1","prim2","flux_x","flux_y","flux_z","seed","mult". */
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem);
+/* The device WENO reconstruction on n stencils of 5 values (DEVICE, (n,5)): left[i]/right[i] = value at the left/right edge
+ * of the centre cell (Dycore.h:591-604 with ind = 0/1).  level < 0: the constant uniform-grid matrices (x, y sweeps);
+ * 0 <= level <= nz+1: this handle's vertical matrices of that index, member 0 (z sweep, Dycore.h:454-469). */
+int pam_amd_awfl_debug_weno(pam_amd_awfl_t *h, int level, const double *stencils, int n, double *left, double *right);
+/* ONE tendency stage (stage 1 of a sub-step of length dt_dyn: a forward-Euler step of the resident state, Dycore.h:156-176)
+ * with the selected stage structure; afterwards "prim0" holds the new density-divided state. */
+int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn);
 /* flux + FCT multiplier of stage input prim0 with stage time step dt (Dycore.h:334-550); no update. */
 int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt);
 

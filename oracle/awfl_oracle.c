@@ -522,6 +522,16 @@ static void load_vert(const awfl_oracle_t *o, int k, int e, double s2c[5][5], do
         wrl[i1][i2][i3] = o->vert_wrl[((((size_t)k * 3 + i1) * 3 + i2) * 3 + i3) * nens + e];
 }
 
+/* KAT entry point for the vertical direction: reconstruct with the per-level matrices of index k (member e), as the z sweep
+ * does (Dycore.h:454-469: the face-k "L" stencil uses vert_*(k), the "R" stencil vert_*(k+1)); ind as awfl_oracle_reconstruct */
+double awfl_oracle_reconstruct_level(const awfl_oracle_t *o, int k, int e, const double stencil[5], int ind) {
+  const double c2g[5][2] = AWFL_COEFS_TO_GLL_INIT;
+  double s2c[5][5], wrl[3][3][3], idl[4], sigma;
+  load_vert(o, k, e, s2c, wrl);
+  awfl_oracle_ideal_sigma(idl, &sigma);
+  return reconstruct(stencil, c2g, s2c, wrl, idl, sigma, ind);
+}
+
 /* Dycore.h:262-586 compute_tendencies.  state/tracers are halo'd and modified in place exactly as the
  * reference does (divide by rho, multiply back).  tracers_tend carries the FCT mass seed in, tendencies out. */
 void awfl_oracle_compute_tendencies(const awfl_oracle_t *o, double *state, double *state_tend, double *tracers,

@@ -50,6 +50,8 @@ def load(path=None):
     lib.awfl_oracle_reconstruct.restype = C.c_double
     lib.awfl_oracle_reconstruct.argtypes = [_DP, C.c_int]
     lib.awfl_oracle_weno_coefs.argtypes = [_DP, _DP]
+    lib.awfl_oracle_reconstruct_level.restype = C.c_double
+    lib.awfl_oracle_reconstruct_level.argtypes = [C.c_void_p, C.c_int, C.c_int, _DP, C.c_int]
     lib.awfl_oracle_ideal_sigma.argtypes = [_DP, _DP]
     lib.awfl_oracle_variable_matrices.argtypes = [_DP, _DP, _DP]
     lib.awfl_oracle_compute_time_step.restype = C.c_double
@@ -201,6 +203,11 @@ class OracleDycore:
             self.lib.awfl_oracle_init_supercell(self.h, _p(zm), _p(zi), *self._f(fields))
         elif init_data != "external":
             raise ValueError("ERROR: Invalid data_spec")
+
+    def reconstruct_level(self, k, e, stencil, ind):
+        """vertical reconstruction with the matrices of index k in [0, nz+1] (Dycore.h:454-469), member e"""
+        s = np.ascontiguousarray(stencil, dtype=np.float64)
+        return self.lib.awfl_oracle_reconstruct_level(self.h, int(k), int(e), _p(s), int(ind))
 
     # --- intermediates, for kernel-level parity tests -------------------------------------------
     def halo_shape(self):

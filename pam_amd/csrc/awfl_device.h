@@ -148,54 +148,61 @@ struct WenoLin {
 // Non-linear part (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum).
 // UNIFORM (constant-matrix directions): the x^2 coefficient of every lower candidate is half the second difference, so
 // p.a2 holds the second difference itself and the factor 1/4 moves into the TV constant.
+// Every multiply-add below has an explicit rounding point (fma = one rounding; nothing else is contracted): the same
+// source must give the same bits in every kernel it is inlined into (x/y/z sweeps, the fused x-sweep, the KAT hook), and the
+// backend's own contraction choices depend on the surrounding code (seen on gfx950: tv*tv + 1e-20 fused in one kernel and
+// not in another -- visible only where tv^2 ~ 1e-20, i.e. at the edges of tracer blobs).
 template <bool UNIFORM>
 PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, double &left, double &right) {
+#pragma clang fp contract(off)
   constexpr double K2 = UNIFORM ? 0.25 * AWFL_TV3_A2A2 : AWFL_TV3_A2A2;
   constexpr double K13 = AWFL_TV5_A1A3 / AWFL_TV5_SQRT_A3A3, K24 = AWFL_TV5_A2A4 / AWFL_TV5_SQRT_A4A4;
   double tv[4];
 #pragma unroll
-  for (int i = 0; i < 3; i++) tv[i] = p.a1[i] * p.a1[i] + K2 * (p.a2[i] * p.a2[i]);
+  for (int i = 0; i < 3; i++) tv[i] = fma(p.a1[i], p.a1[i], (p.a2[i] * p.a2[i]) * K2);
   // coefs_to_tv<5> (TransformMatrices.h:871-876) grouped as h1 (h1 + .5 h3) + h2 (c2 h2 + 4.2 h4) + c3 h3^2 + c4 h4^2, with
   // h3, h4 carried pre-scaled by sqrt(c3), sqrt(c4)
-  tv[3] = p.h1 * (p.h1 + K13 * p.h3) + p.h2 * (AWFL_TV5_A2A2 * p.h2 + K24 * p.h4) + p.h3 * p.h3 + p.h4 * p.h4;
+  {
+    const double t1 = fma(K13, p.h3, p.h1), t2 = fma(K24, p.h4, AWFL_TV5_A2A2 * p.h2);
+    tv[3] = fma(p.h4, p.h4, fma(p.h3, p.h3, fma(p.h2, t2, p.h1 * t1)));
+  }
   // tv3 = lo_avg + (tv3 - lo_avg) sigma  (WenoLimiter.h:150-151)
-  tv[3] = wc.sigma * tv[3] + ((1.0 - AWFL_WENO_SIGMA) / 3.0) * ((tv[0] + tv[1]) + tv[2]);
+  tv[3] = fma((1.0 - AWFL_WENO_SIGMA) / 3.0, (tv[0] + tv[1]) + tv[2], wc.sigma * tv[3]);
   // w_i = idl_i/(tv_i^2+eps), then convexify: w_i /= (sum_k w_k + eps) (WenoLimiter.h:163-166).  One reciprocal,
   // through products of the denominators d_i.  The eps added to the SUM matters when the TVs are large (pressure
   // stencils: sum ~ 1e-17), so it is kept: numerator and denominator are both scaled by d0*d1*d2*d3.
-  double d0 = tv[0] * tv[0] + 1.0e-20, d1 = tv[1] * tv[1] + 1.0e-20;
-  double d2 = tv[2] * tv[2] + 1.0e-20, d3 = tv[3] * tv[3] + 1.0e-20;
-  double p01 = d0 * d1, p23 = d2 * d3;
-  double n0 = wc.idl[0] * (d1 * p23), n1 = wc.idl[1] * (d0 * p23);
-  double n2 = wc.idl[2] * (d3 * p01), n3 = wc.idl[3] * (d2 * p01);
-  double rs = weno_rcp((((n0 + n1) + n2) + n3) + 1.0e-20 * (p01 * p23));
-  double w[4] = {n0 * rs, n1 * rs, n2 * rs, n3 * rs};
+  const double d0 = fma(tv[0], tv[0], 1.0e-20), d1 = fma(tv[1], tv[1], 1.0e-20);
+  const double d2 = fma(tv[2], tv[2], 1.0e-20), d3 = fma(tv[3], tv[3], 1.0e-20);
+  const double p01 = d0 * d1, p23 = d2 * d3;
+  const double x0 = d1 * p23, x1 = d0 * p23, x2 = d3 * p01, x3 = d2 * p01;
+  const double n0 = wc.idl[0] * x0, n1 = wc.idl[1] * x1, n2 = wc.idl[2] * x2, n3 = wc.idl[3] * x3;
+  const double rs = weno_rcp(fma(1.0e-20, p01 * p23, fma(wc.idl[3], x3, fma(wc.idl[2], x2, fma(wc.idl[0], x0, n1)))));
   // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal; the normalisation 1/sum(m) is applied
   // to the two weighted sums instead of to the four weights
+  const double nn[4] = {n0, n1, n2, n3};
   double num[4], den[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    num[i] = w[i] * (wc.c0[i] + w[i] * (w[i] - wc.idl3x[i]));
-    den[i] = wc.c2[i] + w[i] * wc.c1[i];
+    const double w = nn[i] * rs;
+    num[i] = w * fma(w, fma(nn[i], rs, -wc.idl3x[i]), wc.c0[i]);     // w (c0 + w (w - 3 idl))
+    den[i] = fma(wc.c1[i], w, wc.c2[i]);
   }
-  double q01 = den[0] * den[1], q23 = den[2] * den[3];
-  double m0 = num[0] * (den[1] * q23), m1 = num[1] * (den[0] * q23);
-  double m2 = num[2] * (den[3] * q01), m3 = num[3] * (den[2] * q01);
-  double rm = weno_rcp(((m0 + m1) + m2) + m3);
+  const double q01 = den[0] * den[1], q23 = den[2] * den[3];
+  const double y0 = den[1] * q23, y1 = den[0] * q23, y2 = den[3] * q01, y3 = den[2] * q01;
+  const double m0 = num[0] * y0, m1 = num[1] * y1, m2 = num[2] * y2, m3 = num[3] * y3;
+  const double rm = weno_rcp(fma(num[3], y3, fma(num[2], y2, fma(num[1], y1, m0))));
   // even part.  Every candidate reproduces the average of the centre cell, which in the candidates' coordinate is centred
   // at 0 with width w (1 on the uniform grid; dz(k)/dz(k-1) in the vertical, whose matrices are normalised by the cell
   // below): a0 + a2 w^2/12 (+ a4 w^4/80) = u2.  Its value at x = +-1/2 minus u2 is therefore
   // a2 (1/4 - w^2/12) (+ a4 (1/16 - w^4/80)) and needs no coefficients of its own.  (UNIFORM: p.a2 holds 2 a2.)
+  const double lo_e = fma(m0, p.a2[0], fma(m1, p.a2[1], m2 * p.a2[2]));
   double se;
-  if (UNIFORM)
-    se = m3 * (p.h2 * (1.0 / 6.0) + p.h4 * (0.05 / AWFL_TV5_SQRT_A4A4)) +
-         (1.0 / 12.0) * (m0 * p.a2[0] + (m1 * p.a2[1] + m2 * p.a2[2]));
-  else
-    se = m3 * (p.h2 * p.k2 + p.h4 * p.k4) + p.k2 * (m0 * p.a2[0] + (m1 * p.a2[1] + m2 * p.a2[2]));
+  if (UNIFORM) se = fma(1.0 / 12.0, lo_e, m3 * fma(p.h4, 0.05 / AWFL_TV5_SQRT_A4A4, p.h2 * (1.0 / 6.0)));
+  else se = fma(p.k2, lo_e, m3 * fma(p.h4, p.k4, p.h2 * p.k2));
   // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
-  double so = m3 * (p.h1 + (0.25 / AWFL_TV5_SQRT_A3A3) * p.h3) + (m0 * p.a1[0] + (m1 * p.a1[1] + m2 * p.a1[2]));
-  double even = u2 + rm * se;
-  double odd = (0.5 * rm) * so;
+  const double so = fma(m3, fma(0.25 / AWFL_TV5_SQRT_A3A3, p.h3, p.h1), fma(m0, p.a1[0], fma(m1, p.a1[1], m2 * p.a1[2])));
+  const double even = fma(rm, se, u2);
+  const double odd = (0.5 * rm) * so;
   left = even - odd;
   right = even + odd;
 }
@@ -283,6 +290,7 @@ static_assert(uniform_even_identity_holds(), "uniform-grid candidates must repro
 //   h1 = a (d0+d3) + b (d1+d2)      h3 = g ((d0+d3) - (d1+d2))
 //   h2 = c (d0-d3) + e (d2-d1)      h4 = q ((d3-d0) - 3 (d2-d1))          (h3, h4 times sqrt of their TV weights)
 PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, double &right) {
+#pragma clang fp contract(off)
   constexpr DTable T = make_const_dtable();
   static_assert(T.hi[0][0] == T.hi[0][3] && T.hi[0][1] == T.hi[0][2], "x coefficient: symmetric");
   static_assert(T.hi[1][0] == -T.hi[1][3] && T.hi[1][1] == -T.hi[1][2], "x^2 coefficient: antisymmetric");
@@ -299,13 +307,13 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   p.a2[0] = d[1] - d[0];
   p.a2[1] = d[2] - d[1];
   p.a2[2] = d[3] - d[2];
-  p.a1[0] = T.lo1[0][0] * d[0] + T.lo1[0][1] * d[1];
+  p.a1[0] = fma(T.lo1[0][1], d[1], T.lo1[0][0] * d[0]);
   p.a1[1] = 0.5 * s12;
-  p.a1[2] = T.lo1[2][0] * d[2] + T.lo1[2][1] * d[3];
-  p.h1 = T.hi[0][0] * s03 + T.hi[0][1] * s12;
-  p.h2 = T.hi[1][2] * p.a2[1] - T.hi[1][0] * t03;
+  p.a1[2] = fma(T.lo1[2][1], d[3], T.lo1[2][0] * d[2]);
+  p.h1 = fma(T.hi[0][1], s12, T.hi[0][0] * s03);
+  p.h2 = fma(-T.hi[1][0], t03, T.hi[1][2] * p.a2[1]);
   p.h3 = T.hi[2][0] * (s03 - s12);
-  p.h4 = T.hi[3][3] * (t03 - 3.0 * p.a2[1]);
+  p.h4 = T.hi[3][3] * fma(-3.0, p.a2[1], t03);
   p.k2 = p.k4 = 0.0;   // unused on the uniform grid (weno5_blend<true>)
   weno5_blend<true>(u[2], p, wc, left, right);
 }
@@ -315,20 +323,80 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
 // tab points at VZ_STRIDE doubles with element stride `ts` (1 for the ensemble-uniform table, nens otherwise).
 PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, const WenoConsts &wc, double &left,
                         double &right) {
+#pragma clang fp contract(off)
   const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
   WenoLin p;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    p.a1[i] = tab[(0 + 2 * i) * ts] * d[i] + tab[(1 + 2 * i) * ts] * d[i + 1];
-    p.a2[i] = tab[(6 + 2 * i) * ts] * d[i] + tab[(7 + 2 * i) * ts] * d[i + 1];
+    p.a1[i] = fma(tab[(1 + 2 * i) * ts], d[i + 1], tab[(0 + 2 * i) * ts] * d[i]);
+    p.a2[i] = fma(tab[(7 + 2 * i) * ts], d[i + 1], tab[(6 + 2 * i) * ts] * d[i]);
   }
-  p.h1 = tab[12 * ts] * d[0] + (tab[13 * ts] * d[1] + (tab[14 * ts] * d[2] + tab[15 * ts] * d[3]));
-  p.h2 = tab[16 * ts] * d[0] + (tab[17 * ts] * d[1] + (tab[18 * ts] * d[2] + tab[19 * ts] * d[3]));
-  p.h3 = tab[20 * ts] * d[0] + (tab[21 * ts] * d[1] + (tab[22 * ts] * d[2] + tab[23 * ts] * d[3]));
-  p.h4 = tab[24 * ts] * d[0] + (tab[25 * ts] * d[1] + (tab[26 * ts] * d[2] + tab[27 * ts] * d[3]));
+  p.h1 = fma(tab[12 * ts], d[0], fma(tab[13 * ts], d[1], fma(tab[14 * ts], d[2], tab[15 * ts] * d[3])));
+  p.h2 = fma(tab[16 * ts], d[0], fma(tab[17 * ts], d[1], fma(tab[18 * ts], d[2], tab[19 * ts] * d[3])));
+  p.h3 = fma(tab[20 * ts], d[0], fma(tab[21 * ts], d[1], fma(tab[22 * ts], d[2], tab[23 * ts] * d[3])));
+  p.h4 = fma(tab[24 * ts], d[0], fma(tab[25 * ts], d[1], fma(tab[26 * ts], d[2], tab[27 * ts] * d[3])));
   p.k2 = tab[28 * ts];
   p.k4 = tab[29 * ts];
   weno5_blend<false>(u[2], p, wc, left, right);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Arithmetic shared by the unfused stage (flux kernel + update kernel) and the fused x-sweep (flux_x_update_body).  The two
+// paths must produce the same bits, so every multiply-add here has an explicit rounding point: fma() where one rounding
+// is meant, and no implicit contraction of anything else (the compiler's own contraction choices depend on the
+// surrounding code, which differs between the two kernels).
+//
+// A product that is rounded on its own: never contracted into a neighbouring add/subtract (the AMDGPU backend fuses
+// aggressively, also when the product has other uses -- and differently in different kernels).
+PAMA_D double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
+// Acoustic characteristic flux at a face (Dycore.h:341-366, :477-496 for the vertical walls): face mass flux and pressure.
+PAMA_D void acoustic_face(double ru_L, double ru_R, double pp_L, double pp_R, bool wall, double &ruf, double &ppf) {
+#pragma clang fp contract(off)
+  const double cs = 350.0, rcs = 1.0 / 350.0;               // Dycore.h:335
+  if (wall) { ru_L = 0.0; ru_R = 0.0; }                       // Dycore.h:477,482
+  const double w1 = 0.5 * fma(-cs, ru_R, pp_R);
+  const double w2 = 0.5 * fma(cs, ru_L, pp_L);
+  ppf = w1 + w2;
+  ruf = (w2 - w1) * rcs;
+  if (wall) ruf = 0.0;                                        // Dycore.h:496
+}
+
+// -(dFx)/dx - (dFy)/dy - (dFz)/dz of one variable (Dycore.h:553-571), reciprocal multiplies (<= 1 ulp per term)
+PAMA_D double flux_divergence(const Params &P, double xlo, double xhi, double ylo, double yhi, double zlo, double zhi,
+                              double rdzk) {
+#pragma clang fp contract(off)
+  double tend = (xlo - xhi) * P.rdx;
+  if (!P.sim2d) tend = fma(ylo - yhi, P.rdy, tend);
+  return fma(zlo - zhi, rdzk, tend);
+}
+
+// gravity source of the vertical momentum (Dycore.h:562-566): mode A -variable_gravity*rho, mode B -grav*(rho - hy_dens)
+PAMA_D double add_gravity(const Params &P, double tend, double rho_in, long long ke) {
+#pragma clang fp contract(off)
+  if (P.grav_balance) return fma(-P.grav_var[ke], rho_in, tend);
+  return fma(-P.grav, rho_in - P.hy_dens[ke], tend);
+}
+
+// SSPRK3 combines (Dycore.h:162-221):
+//   STAGE 1: out = in' + dt T     STAGE 2: out = 3/4 q0' + 1/4 in' + 1/4 dt T     STAGE 3: out = 1/3 q0' + 2/3 in' + 2/3 dt T
+template <int STAGE>
+PAMA_D double rk_combine(double m_0, double m_in, double dt_dyn, double tend) {
+#pragma clang fp contract(off)
+  if (STAGE == 1) return fma(dt_dyn, tend, m_in);
+  if (STAGE == 2) return fma((1.0 / 4.0) * dt_dyn, tend, fma(1.0 / 4.0, m_in, (3.0 / 4.0) * m_0));
+  return fma((2.0 / 3.0) * dt_dyn, tend, fma(2.0 / 3.0, m_in, (1.0 / 3.0) * m_0));
+}
+// FCT seed of the next stage (Dycore.h:173-174,197-198); after stage 3 the exact conserved tracer mass
+template <int STAGE>
+PAMA_D double next_seed(double m_0, double m_in, double v) {
+#pragma clang fp contract(off)
+  if (STAGE == 1) return fma(1.0 / 4.0, v, (3.0 / 4.0) * m_in);
+  if (STAGE == 2) return fma(2.0 / 3.0, v, (1.0 / 3.0) * m_0);
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,7 +466,6 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     fbase = line * P.sx + e;
   }
   const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive
-  const double cs = 350.0, rcs = 1.0 / 350.0;                        // Dycore.h:335
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
 
   auto cell_off = [&](int c) -> long long {
@@ -426,13 +493,13 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     for (int s = 0; s < 5; s++) {
       long long o = cell_off(c - 2 + s);
       wn[s] = pn[o];
-      wm[s] = pr[o] * wn[s];
+      wm[s] = mul_rn(pr[o], wn[s]);
       wp[s] = pp[o];
     }
     double prevR_m = 0.0, prevR_p = 0.0, prevR_n = 0.0;
     for (; c < fend; c++) {
       long long on = cell_off(c + 3);                    // the next cell entering the window
-      double nn = pn[on], nm = pr[on] * nn, np_ = pp[on];
+      double nn = pn[on], nm = mul_rn(pr[on], nn), np_ = pp[on];
       double Lm, Rm, Lp, Rp, Ln, Rn;
       if (DIR == 2) {
         weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
@@ -444,22 +511,15 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         weno5_const(wn, wc, Ln, Rn);
       }
       if (c >= f0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
-        double ru_L = prevR_m, ru_R = Lm, pp_L = prevR_p, pp_R = Lp;
-        bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
-        if (wall) { ru_L = 0.0; ru_R = 0.0; }
-        double w1 = 0.5 * (pp_R - cs * ru_R);
-        double w2 = 0.5 * (pp_L + cs * ru_L);
-        double ppf = w1 + w2;
-        double ruf = (w2 - w1) * rcs;
-        if (wall) ruf = 0.0;
+        const bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
+        double ruf, ppf;
+        acoustic_face(prevR_m, Lm, prevR_p, Lp, wall, ruf, ppf);
         fl0[(long long)c * g.cs] = ruf;                       // flux field 0
 #ifndef PAMA_RUF_GLOBAL
         ruf_slot[(c - f0) * nthr] = ruf;
 #endif
-        double val = (ruf > 0.0) ? prevR_n : Ln;              // upwind (Dycore.h:368)
-        double f = ruf * val;
-        f += ppf;
-        fln[(long long)c * g.cs] = f;
+        const double val = (ruf > 0.0) ? prevR_n : Ln;        // upwind (Dycore.h:368)
+        fln[(long long)c * g.cs] = fma(ruf, val, ppf);
       }
       prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
 #pragma unroll
@@ -508,7 +568,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 #endif
         const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
 #pragma unroll
-        for (int n = 0; n < NF; n++) fl[n][(long long)c * g.cs] = ruf * (up ? prevR[n] : L[n]);
+        for (int n = 0; n < NF; n++) fl[n][(long long)c * g.cs] = mul_rn(ruf, up ? prevR[n] : L[n]);
       }
 #pragma unroll
       for (int n = 0; n < NF; n++) {
@@ -547,6 +607,7 @@ PAMA_D void store_adv(const Params &P, double *prim, int pf, int k, long long c2
 // density and pressure of the cell + their hydrostatically extrapolated ghosts (Dycore.h:682-709)
 PAMA_D void store_rho_pres(const Params &P, double *prim, int k, long long c2, int e, double rho, double th,
                            double rho_theta, bool subtract_hy) {
+#pragma clang fp contract(off)
   double *fr = prim + (long long)P_RHO * P.prim_fs, *fp = prim + (long long)P_PRES * P.prim_fs;
   const long long o = (long long)(k + HS) * P.sz + c2;
   double pres = P.C0 * pow(rho_theta, P.gamma);
@@ -710,9 +771,76 @@ PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const 
 // on the high side (mh) of the face.  `seam`: the face is the periodic duplicate pair (face 0 == face n), where the
 // reference reconciles the two copies with min() (Dycore.h:574-579): a negative flux stays unlimited there (quirk Q4).
 PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
-  if (F > 0.0) return F * ml;
-  if (F < 0.0) return seam ? F : F * mh;
+  if (F > 0.0) return mul_rn(F, ml);
+  if (F < 0.0) return seam ? F : mul_rn(F, mh);
   return F;
+}
+
+
+
+// Tracer part of the stage update of one cell (Dycore.h:553-584 with the FCT-limited fluxes, :162-221): shared by the
+// one-kernel update (update_body) and by the tracer-only update that follows the fused x-sweep (tracer_update_body), so
+// that both paths perform the same arithmetic.  rho_in / rho_0: density of the stage input / sub-step start; rrho:
+// reciprocal of the NEW density.  Loads of prim_in/prim0 for tracer t happen before the store of tracer t (alias-safe).
+template <int STAGE>
+PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
+                               const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                               const double *__restrict__ mult, double *__restrict__ seed, double dt_dyn, const CellId &c,
+                               double rho_in, double rho_0, double rrho, double rdzk) {
+  const int k = c.k, j = c.j, i = c.i, e = c.e;
+  const long long idx = c.idx;
+  const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+  const long long o = (long long)(k + HS) * P.sz + c2;
+  const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
+  const long long im1 = idx + ((i == 0) ? (long long)(P.nx - 1) * P.sx : -P.sx);
+  const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
+  const long long jm1 = idx + ((j == 0) ? (long long)(P.ny - 1) * P.sy : -P.sy);
+  for (int t = 0; t < P.nt; t++) {
+    const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
+    const double *tz = fz + (long long)(5 + t) * P.fz_fs;
+    const double *mt = mult + (long long)t * P.ncell;
+    const double m_c = mt[idx];
+    double f_x = limited_flux(tx[idx], mt[im1], m_c, i == 0);
+    double f_xp1 = limited_flux(tx[ip1], m_c, mt[ip1], i == P.nx - 1);
+    double f_y = 0.0, f_yp1 = 0.0;
+    if (!P.sim2d) {
+      f_y = limited_flux(ty[idx], mt[jm1], m_c, j == 0);
+      f_yp1 = limited_flux(ty[jp1], m_c, mt[jp1], j == P.ny - 1);
+    }
+    // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
+    const double f_z = limited_flux(tz[idx], (k > 0) ? mt[idx - P.sz] : 1.0, m_c, false);
+    const double f_zp1 = limited_flux(tz[idx + P.sz], m_c, (k < P.nz - 1) ? mt[idx + P.sz] : 1.0, false);
+    const double tend = flux_divergence(P, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, rdzk);
+    const int pf = P_TR0 + t;
+    const double m_in = mul_rn(prim_in[pf * P.prim_fs + o], rho_in);
+    double m_0 = 0.0;
+    if (STAGE > 1) m_0 = mul_rn(prim0[pf * P.prim_fs + o], rho_0);
+    double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+    if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
+    seed[(long long)t * P.ncell + idx] = next_seed<STAGE>(m_0, m_in, v);
+    store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
+  }
+}
+
+// Pointwise remainder of the fused stage: tracer update + next stage's pressure.  The state variables were advanced by the
+// fused x-sweep (flux_x_update_body), which left the new density, the new theta and -- in the pressure slot -- the new
+// rho*theta in prim_out.  rrho = fast_rcp(new density) is bitwise what update_body derives from its own qs[0].
+template <int STAGE>
+PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                               double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
+                               const double *__restrict__ fz, const double *__restrict__ mult, double *__restrict__ seed,
+                               double dt_dyn, const CellId &c) {
+  const long long c2 = (long long)c.j * P.sy + (long long)c.i * P.sx + c.e;
+  const long long o = (long long)(c.k + HS) * P.sz + c2;
+  const double rho_in = prim_in[P_RHO * P.prim_fs + o];
+  const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
+  const double rho_new = prim_out[P_RHO * P.prim_fs + o];
+  const double rrho = fast_rcp(rho_new);
+  const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
+  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
+  // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
+  store_rho_pres(P, prim_out, c.k, c2, c.e, rho_new, prim_out[P_THETA * P.prim_fs + o], prim_out[P_PRES * P.prim_fs + o],
+                 !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -722,13 +850,6 @@ PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
 //   STAGE 3: out = 1/3 q0' + 2/3 in' + 2/3 dt T    seed = out (exact conserved tracer mass for the next sub-step)
 // in' / q0' are the conserved values re-formed as (m/rho)*rho exactly as the reference's in-place round trip
 // (Dycore.h:316-320,527-532).  prim_in is the stage input, prim0 the sub-step start (STAGE>1).
-template <int STAGE>
-PAMA_D double rk_combine(double m_0, double m_in, double dt_dyn, double tend) {
-  if (STAGE == 1) return m_in + dt_dyn * tend;
-  if (STAGE == 2) return (3.0 / 4.0) * m_0 + (1.0 / 4.0) * m_in + (1.0 / 4.0) * dt_dyn * tend;
-  return (1.0 / 3.0) * m_0 + (2.0 / 3.0) * m_in + (2.0 / 3.0) * dt_dyn * tend;
-}
-
 // prim_out may alias prim_in (stage 2) or prim0 (stage 3): the update is pointwise (every input of the cell is read
 // before its outputs are written), so no __restrict__ on those.
 template <int STAGE>
@@ -754,63 +875,257 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 #pragma unroll
   for (int l = 0; l < 5; l++) {
     const double *sx_ = fx + (long long)l * P.ncell, *sy_ = fy + (long long)l * P.ncell, *sz_ = fz + (long long)l * P.fz_fs;
-    // reciprocal multiplies instead of the reference's divisions (<= 1 ulp per term): the kernel co-runs with the
-    // FP64-bound flux kernel of another ensemble chunk, so its VALU work is not free
-    double tend = -(sx_[ip1] - sx_[idx]) * P.rdx;
-    if (!P.sim2d) tend = tend - (sy_[jp1] - sy_[idx]) * P.rdy;
-    tend = tend - (sz_[idx + P.sz] - sz_[idx]) * rdzk;
-    if (l == 3) {
-      if (P.grav_balance) tend += -P.grav_var[ke] * rho_in;
-      else tend += -P.grav * (rho_in - P.hy_dens[ke]);
-    }
+    const double ylo = P.sim2d ? 0.0 : sy_[idx], yhi = P.sim2d ? 0.0 : sy_[jp1];   // no y-flux array in 2-D
+    double tend = flux_divergence(P, sx_[idx], sx_[ip1], ylo, yhi, sz_[idx], sz_[idx + P.sz], rdzk);
+    if (l == 3) tend = add_gravity(P, tend, rho_in, ke);
     if (l == 2 && P.sim2d) tend = 0.0;
     const int pf = (l == 0) ? P_RHO : P_U + (l - 1);
     double m_in = prim_in[pf * P.prim_fs + o];
-    if (l > 0) m_in *= rho_in;
+    if (l > 0) m_in = mul_rn(m_in, rho_in);
     double m_0 = 0.0;
     if (STAGE > 1) {
       m_0 = prim0[pf * P.prim_fs + o];
-      if (l > 0) m_0 *= rho_0;
+      if (l > 0) m_0 = mul_rn(m_0, rho_0);
     }
     qs[l] = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
   }
   const double rrho = fast_rcp(qs[0]);
   const double th = qs[4] * rrho;
-  // tracers (loads of prim_in/prim0 for tracer t happen before the store of tracer t: pointwise, alias-safe)
-  for (int t = 0; t < P.nt; t++) {
-    const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
-    const double *tz = fz + (long long)(5 + t) * P.fz_fs;
-    const double *mt = mult + (long long)t * P.ncell;
-    const double m_c = mt[idx];
-    double f_x = limited_flux(tx[idx], mt[im1], m_c, i == 0);
-    double f_xp1 = limited_flux(tx[ip1], m_c, mt[ip1], i == P.nx - 1);
-    double tend = -(f_xp1 - f_x) * P.rdx;
-    if (!P.sim2d) {
-      double f_y = limited_flux(ty[idx], mt[jm1], m_c, j == 0);
-      double f_yp1 = limited_flux(ty[jp1], m_c, mt[jp1], j == P.ny - 1);
-      tend = tend - (f_yp1 - f_y) * P.rdy;
-    }
-    // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
-    double f_z = limited_flux(tz[idx], (k > 0) ? mt[idx - P.sz] : 1.0, m_c, false);
-    double f_zp1 = limited_flux(tz[idx + P.sz], m_c, (k < P.nz - 1) ? mt[idx + P.sz] : 1.0, false);
-    tend = tend - (f_zp1 - f_z) * rdzk;
-    const int pf = P_TR0 + t;
-    const double m_in = prim_in[pf * P.prim_fs + o] * rho_in;
-    double m_0 = 0.0;
-    if (STAGE > 1) m_0 = prim0[pf * P.prim_fs + o] * rho_0;
-    double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
-    if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
-    double s = v;                                                   // stage 3: exact conserved mass
-    if (STAGE == 1) s = (3.0 / 4.0) * m_in + (1.0 / 4.0) * v;       // Dycore.h:173-174
-    if (STAGE == 2) s = (1.0 / 3.0) * m_0 + (2.0 / 3.0) * v;        // Dycore.h:197-198
-    seed[(long long)t * P.ncell + idx] = s;
-    store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
-  }
+  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
   store_rho_pres(P, prim_out, k, c2, e, qs[0], th, qs[4], !P.grav_balance);
   store_adv(P, prim_out, P_U, k, c2, qs[1] * rrho, qs[1] * rrho);
   store_adv(P, prim_out, P_V, k, c2, qs[2] * rrho, qs[2] * rrho);
   store_adv(P, prim_out, P_W, k, c2, qs[3] * rrho, 0.0);
   store_adv(P, prim_out, P_THETA, k, c2, th, th);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FUSED x-sweep: reconstruction + fluxes in x (as flux_line_body<0>) AND, in the same pass, the stage update of the five
+// state variables of every cell of the line (as update_body), with the y and z face fluxes read from the flux arrays the
+// y/z sweeps wrote earlier.  Reference: Dycore.h:334-386 (x fluxes), :553-571 (divergence, gravity), :162-221 (SSPRK3
+// combine), next stage's :310-321 (pressure, divide by rho) and :662-710 (vertical ghosts).
+//
+// Why: in the three-kernel stage every x face flux of the state makes a round trip through HBM (written by the flux
+// kernel, read back by the update kernel) and the update kernel re-reads the stage input the x-sweep has just had in
+// registers.  Here a thread owns a whole periodic x line of one member: when faces c-1 and c of a variable are known,
+// cell c-1 is complete -- its x flux difference never leaves the registers, its stage-input value is the window element
+// the polynomial was built from, and only the y/z flux differences and the sub-step-start value are loaded.  The x
+// fluxes of the state are never stored; tracer x fluxes still are (the FCT limiter needs all six faces of a cell before
+// any tracer update: fct_mult_body, then tracer_update_body).
+//
+// Passes over the line (5-cell sliding windows, one polynomial per cell, as flux_line_body):
+//   pass 1   rho*u, p, u: face mass flux ruf (kept in the thread's LDS slots for the later passes) and face pressure;
+//            finishes rho and rho*u of each cell: new density -> prim_out[P_RHO], its reciprocal is parked in
+//            prim_out[P_PRES] (this thread's own cells; overwritten by the pressure in the theta pass)
+//   pass 2.. FLUX_NF advected fields at a time (v, w, theta, tracers): state variables are finished per cell and written
+//            density-divided to prim_out (+ vertical ghosts when k is a boundary level); theta -- always the last state
+//            variable of the sweep order -- leaves the new rho*theta in prim_out[P_PRES] for the pointwise kernel that
+//            follows (tracer_update_body: next stage's pressure and density/pressure ghosts); tracers only store their x flux.
+// The loads a cell's completion needs (y/z faces, sub-step-start values, densities) are issued one iteration ahead.
+// prim_in, prim0 and prim_out must be three different buffers: the line is periodic (cells 0..2 are read again at the
+// end of the sweep) and later passes re-read the stage-input density, so nothing may be updated in place.
+// Bit-for-bit the arithmetic of flux_line_body<0> + update_body (shared helpers above; tests/test_fused_stage.py).
+template <int STAGE>
+PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                               double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
+                               const double *__restrict__ fz, long long item, double dt_dyn, double *lds, int nthr,
+                               int tid) {
+  const WenoConsts wc = weno_consts();
+  const int nx = P.nx;
+  const int e = (int)(item % P.nens);
+  const long long line = item / P.nens;
+  const int k = (int)(line / P.ny), j = (int)(line % P.ny);
+  const long long c2_0 = (long long)j * P.sy + e;                      // (j, i=0, e) inside a level
+  const long long pbase = (long long)(k + HS) * P.sz + c2_0;           // cell i=0 inside a prim field
+  const long long fbase = (long long)k * P.sz + c2_0;                  // cell / face i=0 inside an interior-sized field
+  const long long jp1 = (j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy;   // offset of the (j+1) neighbour
+  const long long ke = (long long)k * P.nens + e;
+  const double rdzk = fast_rcp(P.dz[ke]);
+  const bool have_y = !P.sim2d;
+  double *ruf_slot = lds + tid;
+  auto cell_off = [&](int c) -> long long { return pbase + (long long)wrap(c, nx) * P.sx; };
+
+  // ---------------- pass 1: acoustic pair, mass and x-momentum (Dycore.h:341-366,:368-385) + their update -------------
+  {
+    const double *pr = prim_in + (long long)P_RHO * P.prim_fs;
+    const double *pn = prim_in + (long long)P_U * P.prim_fs;
+    const double *pp = prim_in + (long long)P_PRES * P.prim_fs;
+    const double *r0 = prim0 + (long long)P_RHO * P.prim_fs, *u0 = prim0 + (long long)P_U * P.prim_fs;
+    double *out_rho = prim_out + (long long)P_RHO * P.prim_fs, *out_rr = prim_out + (long long)P_PRES * P.prim_fs;
+    const double *fy0 = fy, *fy1 = fy + P.ncell, *fz0 = fz, *fz1 = fz + P.fz_fs;
+    double wm[5], wp[5], wn[5];
+    int c = -1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const long long o = cell_off(c - 2 + s);
+      wn[s] = pn[o];
+      wm[s] = mul_rn(pr[o], wn[s]);
+      wp[s] = pp[o];
+    }
+    double prevR_m = 0.0, prevR_p = 0.0, prevR_n = 0.0;
+    double F0_prev = 0.0, F1_prev = 0.0, F0_first = 0.0, F1_first = 0.0;
+    // pending loads of the cell that completes in the next iteration
+    double p_rho_in = 0.0, p_rho_0 = 0.0, p_u_0 = 0.0, p_y0l = 0.0, p_y0h = 0.0, p_y1l = 0.0, p_y1h = 0.0, p_z0l = 0.0,
+           p_z0h = 0.0, p_z1l = 0.0, p_z1h = 0.0;
+    auto finish = [&](int cc, double F0lo, double F0hi, double F1lo, double F1hi, double m_in_u) {
+      const long long o = pbase + (long long)cc * P.sx;
+      const double q0 = rk_combine<STAGE>(p_rho_0, p_rho_in, dt_dyn,
+                                          flux_divergence(P, F0lo, F0hi, p_y0l, p_y0h, p_z0l, p_z0h, rdzk));
+      const double rrho = fast_rcp(q0);
+      out_rho[o] = q0;
+      out_rr[o] = rrho;
+      const double m_0 = (STAGE > 1) ? mul_rn(p_u_0, p_rho_0) : 0.0;
+      const double q1 = rk_combine<STAGE>(m_0, m_in_u, dt_dyn,
+                                          flux_divergence(P, F1lo, F1hi, p_y1l, p_y1h, p_z1l, p_z1h, rdzk));
+      store_adv(P, prim_out, P_U, k, c2_0 + (long long)cc * P.sx, q1 * rrho, q1 * rrho);
+    };
+    for (; c < nx; c++) {
+      const long long on = cell_off(c + 3);
+      const double nn = pn[on], nm = mul_rn(pr[on], nn), np_ = pp[on];
+      // loads for cell c (completed in iteration c+1, or after the loop for the last cell)
+      double n_rho_in = 0.0, n_rho_0 = 0.0, n_u_0 = 0.0, n_y0l = 0.0, n_y0h = 0.0, n_y1l = 0.0, n_y1h = 0.0, n_z0l = 0.0,
+             n_z0h = 0.0, n_z1l = 0.0, n_z1h = 0.0;
+      if (c >= 0) {
+        const long long o = pbase + (long long)c * P.sx, ix = fbase + (long long)c * P.sx;
+        n_rho_in = pr[o];
+        if (STAGE > 1) { n_rho_0 = r0[o]; n_u_0 = u0[o]; }
+        if (have_y) { n_y0l = fy0[ix]; n_y0h = fy0[ix + jp1]; n_y1l = fy1[ix]; n_y1h = fy1[ix + jp1]; }
+        n_z0l = fz0[ix]; n_z0h = fz0[ix + P.sz]; n_z1l = fz1[ix]; n_z1h = fz1[ix + P.sz];
+      }
+      double Lm, Rm, Lp, Rp, Ln, Rn;
+      weno5_const(wm, wc, Lm, Rm);
+      weno5_const(wp, wc, Lp, Rp);
+      weno5_const(wn, wc, Ln, Rn);
+      if (c >= 0) {
+        double ruf, ppf;
+        acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
+        ruf_slot[c * nthr] = ruf;
+        const double val = (ruf > 0.0) ? prevR_n : Ln;        // upwind (Dycore.h:368)
+        const double f = fma(ruf, val, ppf);
+        if (c == 0) { F0_first = ruf; F1_first = f; }
+        else finish(c - 1, F0_prev, ruf, F1_prev, f, wm[1]);  // window = cells c-2..c+2: element 1 is cell c-1
+        F0_prev = ruf; F1_prev = f;
+      }
+      p_rho_in = n_rho_in; p_rho_0 = n_rho_0; p_u_0 = n_u_0; p_y0l = n_y0l; p_y0h = n_y0h; p_y1l = n_y1l; p_y1h = n_y1h;
+      p_z0l = n_z0l; p_z0h = n_z0h; p_z1l = n_z1l; p_z1h = n_z1h;
+      prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
+#pragma unroll
+      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
+      wm[4] = nm; wp[4] = np_; wn[4] = nn;
+    }
+    // the periodic face nx is face 0; the window now holds cells nx-2..nx+2, element 1 is cell nx-1
+    finish(nx - 1, F0_prev, F0_first, F1_prev, F1_first, wm[1]);
+  }
+
+  // ---------------- the other advected quantities, FLUX_NF per sweep; state variables are finished per cell -----------
+  auto sweep = [&](auto nf_tag, const int *fa) {
+    constexpr int NF = decltype(nf_tag)::value;
+    const double *q[NF], *q0p[NF], *fyl[NF], *fzl[NF];
+    double *fl[NF];
+    bool st[NF];                                  // state variable (finished here) or tracer (x flux stored)
+    int pfld[NF];
+    double w[NF][5], prevR[NF], Fprev[NF], Ffirst[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+      pfld[n] = P_U + fa[n];
+      st[n] = fa[n] < 4;
+      q[n] = prim_in + (long long)pfld[n] * P.prim_fs;
+      q0p[n] = prim0 + (long long)pfld[n] * P.prim_fs;
+      fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
+      fyl[n] = fy + (long long)(1 + fa[n]) * P.ncell;
+      fzl[n] = fz + (long long)(1 + fa[n]) * P.fz_fs;
+      prevR[n] = 0.0; Fprev[n] = 0.0; Ffirst[n] = 0.0;
+    }
+    const double *pr = prim_in + (long long)P_RHO * P.prim_fs, *r0 = prim0 + (long long)P_RHO * P.prim_fs;
+    double *out_rr = prim_out + (long long)P_PRES * P.prim_fs;
+    double p_rho_in = 0.0, p_rho_0 = 0.0, p_rr = 0.0, p_q0[NF], p_yl[NF], p_yh[NF], p_zl[NF], p_zh[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) { p_q0[n] = 0.0; p_yl[n] = 0.0; p_yh[n] = 0.0; p_zl[n] = 0.0; p_zh[n] = 0.0; }
+    auto finish = [&](int n, int cc, double Flo, double Fhi, double q_in) {
+      const long long c2 = c2_0 + (long long)cc * P.sx;
+      const int l = 1 + fa[n];                                 // 2 rho v, 3 rho w, 4 rho theta
+      double tend = flux_divergence(P, Flo, Fhi, p_yl[n], p_yh[n], p_zl[n], p_zh[n], rdzk);
+      if (l == 3) tend = add_gravity(P, tend, p_rho_in, ke);
+      if (l == 2 && P.sim2d) tend = 0.0;
+      const double m_in = mul_rn(q_in, p_rho_in);
+      const double m_0 = (STAGE > 1) ? mul_rn(p_q0[n], p_rho_0) : 0.0;
+      const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+      store_adv(P, prim_out, pfld[n], k, c2, v * p_rr, (l == 3) ? 0.0 : v * p_rr);
+      // theta: the conserved rho*theta replaces the parked reciprocal density; pressure_body turns it into the next
+      // stage's pressure (a pow per cell, kept out of this register-critical loop)
+      if (l == 4) out_rr[pbase + (long long)cc * P.sx] = v;
+    };
+    int c = -1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const long long o = cell_off(c - 2 + s);
+#pragma unroll
+      for (int n = 0; n < NF; n++) w[n][s] = q[n][o];
+    }
+    for (; c < nx; c++) {
+      const long long on = cell_off(c + 3);
+      double nq[NF], L[NF], R[NF];
+#pragma unroll
+      for (int n = 0; n < NF; n++) nq[n] = q[n][on];
+      double n_rho_in = 0.0, n_rho_0 = 0.0, n_rr = 0.0, n_q0[NF], n_yl[NF], n_yh[NF], n_zl[NF], n_zh[NF];
+#pragma unroll
+      for (int n = 0; n < NF; n++) { n_q0[n] = 0.0; n_yl[n] = 0.0; n_yh[n] = 0.0; n_zl[n] = 0.0; n_zh[n] = 0.0; }
+      if (c >= 0) {
+        const long long o = pbase + (long long)c * P.sx, ix = fbase + (long long)c * P.sx;
+        bool any = false;
+#pragma unroll
+        for (int n = 0; n < NF; n++) {
+          if (!st[n]) continue;
+          any = true;
+          if (STAGE > 1) n_q0[n] = q0p[n][o];
+          if (have_y) { n_yl[n] = fyl[n][ix]; n_yh[n] = fyl[n][ix + jp1]; }
+          n_zl[n] = fzl[n][ix]; n_zh[n] = fzl[n][ix + P.sz];
+        }
+        if (any) {
+          n_rho_in = pr[o];
+          if (STAGE > 1) n_rho_0 = r0[o];
+          n_rr = out_rr[o];
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
+      if (c >= 0) {
+        const double ruf = ruf_slot[c * nthr];
+        const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
+#pragma unroll
+        for (int n = 0; n < NF; n++) {
+          const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
+          if (!st[n]) { fl[n][(long long)c * P.sx] = F; continue; }
+          if (c == 0) Ffirst[n] = F;
+          else finish(n, c - 1, Fprev[n], F, w[n][1]);
+          Fprev[n] = F;
+        }
+      }
+      p_rho_in = n_rho_in; p_rho_0 = n_rho_0; p_rr = n_rr;
+#pragma unroll
+      for (int n = 0; n < NF; n++) {
+        p_q0[n] = n_q0[n]; p_yl[n] = n_yl[n]; p_yh[n] = n_yh[n]; p_zl[n] = n_zl[n]; p_zh[n] = n_zh[n];
+        prevR[n] = R[n];
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+        w[n][4] = nq[n];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NF; n++)
+      if (st[n]) finish(n, nx - 1, Fprev[n], Ffirst[n], w[n][1]);
+  };
+  // sweep order: v, w, theta, tracers (theta is the last state variable: it overwrites the parked reciprocal density)
+  const int nadv = 4 + P.nt;
+  int fa[FLUX_NF], nfa = 0;
+  for (int a = 1; a < nadv; a++) {
+    fa[nfa++] = a;
+    if (nfa == FLUX_NF) { sweep(std::integral_constant<int, FLUX_NF>{}, fa); nfa = 0; }
+  }
+  if (FLUX_NF >= 4 && nfa == 3) { sweep(std::integral_constant<int, 3>{}, fa); nfa = 0; }
+  if (FLUX_NF >= 3 && nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
+  if (nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
+  if (nfa == 1) sweep(std::integral_constant<int, 1>{}, fa);
 }
 
 // ------------------------------------------------------------------------------------------------

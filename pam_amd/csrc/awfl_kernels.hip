@@ -116,6 +116,47 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
   CellId c;
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
+// Fused x-sweep + state update (flux_x_update_body): every wavefront owns 64 consecutive (x line, member) items.
+template <int STAGE>
+__global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                                  const double *__restrict__ prim0,
+                                                                  double *__restrict__ prim_out, double *__restrict__ fx,
+                                                                  const double *__restrict__ fy,
+                                                                  const double *__restrict__ fz, double dt_dyn) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const long long item = (long long)blockIdx.x * FLUX_THREADS + tid;     // wave w of the block: items 64 w .. 64 w + 63
+  if (item < (long long)P.nz * P.ny * R.ne)
+    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, to_global(item, P.nens, R), dt_dyn, lds, FLUX_THREADS,
+                              tid);
+}
+// Tracer-only update after the fused x-sweep and the FCT multiplier (tracer_update_body).
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_trupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                         const double *__restrict__ prim0, double *prim_out,
+                                                         const double *__restrict__ fx, const double *__restrict__ fy,
+                                                         const double *__restrict__ fz, const double *__restrict__ mult,
+                                                         double *__restrict__ seed, double dt_dyn) {
+  CellId c;
+  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
+}
+// Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
+// level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
+// (weno5_table, the z sweep; level = vertical matrix index 0..nz+1 as in Dycore.h:454-469).
+__global__ void __launch_bounds__(256) awfl_weno_kat_kernel(Params P, int level, const double *__restrict__ stencils, int n,
+                                                            double *__restrict__ left, double *__restrict__ right) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const WenoConsts wc = weno_consts();
+  double u[5], L, R;
+  for (int s = 0; s < 5; s++) u[s] = stencils[(long long)t * 5 + s];
+  if (level < 0) weno5_const(u, wc, L, R);
+  else if (P.vz_per_ens) weno5_table(u, P.vz + ((long long)level * VZ_STRIDE) * P.nens, P.nens, wc, L, R);
+  else weno5_table(u, P.vz + (long long)level * VZ_STRIDE, 1, wc, L, R);
+  left[t] = L;
+  right[t] = R;
+}
+
 __global__ void __launch_bounds__(256) awfl_init_thermal_kernel(Params P, EnsRange R, double xlen, double ylen, double cp_d,
                                                                 double p0, const double *__restrict__ zmid,
                                                                 double *__restrict__ rho_d, double *__restrict__ u,
@@ -225,7 +266,7 @@ struct pam_amd_awfl {
   // options (Dycore.h:871-891)
   double R_d, cp_d, R_v, cp_v, p0, grav, cv_d, gamma_d, kappa_d, cv_v, C0;
   // device buffers
-  double *prim0 = nullptr, *prim1 = nullptr, *flux_x = nullptr, *flux_y = nullptr, *flux_z = nullptr;
+  double *prim0 = nullptr, *prim1 = nullptr, *prim2 = nullptr, *flux_x = nullptr, *flux_y = nullptr, *flux_z = nullptr;
   double *seed = nullptr, *mult = nullptr, *dz = nullptr, *grav_var = nullptr, *hy_dens = nullptr, *hy_pres = nullptr;
   double *vz = nullptr, *vert_s2c = nullptr, *vert_wrl = nullptr;
   // storage the kernels actually use for the dycore's named arrays: the handle's own buffers until the host model binds
@@ -239,6 +280,8 @@ struct pam_amd_awfl {
   int chunks_requested = 0;    // 0: automatic
   bool use_priorities = true;  // flux streams get the device's highest stream priority (see Chunk)
   bool interleave_xy = true;
+  bool fused = false;          // fused x-sweep + state update (needs prim2 and nx LDS slots per thread)
+  bool fused_supported = false;
   size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
@@ -347,38 +390,34 @@ static void choose_span(int nfaces, long long nitems, int min_span, int span_ove
   nunits = nib * nspan;
 }
 
-int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s) {
+// sweeps: bit 0 x, bit 1 y, bit 2 z (the fused stage runs y and z here and x in awfl_xupd_kernel)
+int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, int sweeps = 7) {
   const Params &P = h->P;
   FluxGrid G;
   // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
   choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, G.spx, G.nsx, G.nux);
   choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, G.spy, G.nsy, G.nuy);
   choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, G.spz, G.nsz, G.nuz);
-  G.nux = (((long long)P.nz * P.ny * r.ne + 63) / 64) * G.nsx;
-  G.nuy = P.sim2d ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
-  G.nuz = (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz;
+  G.nux = (sweeps & 1) ? (((long long)P.nz * P.ny * r.ne + 63) / 64) * G.nsx : 0;
+  G.nuy = (P.sim2d || !(sweeps & 2)) ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
+  G.nuz = (sweeps & 4) ? (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz : 0;
   G.nbx = (int)((G.nux + FLUX_WAVES - 1) / FLUX_WAVES); G.nby = (int)((G.nuy + FLUX_WAVES - 1) / FLUX_WAVES);
   G.nbz = (int)((G.nuz + FLUX_WAVES - 1) / FLUX_WAVES);
   G.nbx_l = G.nby_l = 0;
-  if (h->interleave_xy && !P.sim2d && G.nux % ((long long)FLUX_WAVES * P.nz) == 0 && G.nuy % ((long long)FLUX_WAVES * P.nz) == 0) {
+  if (h->interleave_xy && !P.sim2d && G.nux > 0 && G.nuy > 0 && G.nux % ((long long)FLUX_WAVES * P.nz) == 0 && G.nuy % ((long long)FLUX_WAVES * P.nz) == 0) {
     G.nbx_l = G.nbx / P.nz;
     G.nby_l = G.nby / P.nz;
   }
   // per-thread LDS: one mass-flux slot per face of the span
-  int spmax = G.spx > G.spz ? G.spx : G.spz;
-  if (!P.sim2d && G.spy > spmax) spmax = G.spy;
+  int spmax = 1;
+  if (G.nux > 0 && G.spx > spmax) spmax = G.spx;
+  if (G.nuy > 0 && G.spy > spmax) spmax = G.spy;
+  if (G.nuz > 0 && G.spz > spmax) spmax = G.spz;
+  if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
   size_t lds_bytes = (size_t)spmax * FLUX_THREADS * sizeof(double);
 #ifdef PAMA_RUF_GLOBAL
   lds_bytes = 0;
 #endif
-  if (const char *m = getenv("PAMA_SWEEP_MASK")) {   // EXPERIMENT: time single sweeps (results are wrong)
-    int mask = atoi(m);
-    if (!(mask & 1)) { G.nbx = 0; G.nux = 0; }
-    if (!(mask & 2)) { G.nby = 0; G.nuy = 0; }
-    if (!(mask & 4)) { G.nbz = 0; G.nuz = 0; }
-    G.nbx_l = G.nby_l = 0;
-  }
-  if (h->chunks.size() > 1 && lds_bytes < h->flux_lds_floor) lds_bytes = h->flux_lds_floor;
   ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
     hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
@@ -404,6 +443,29 @@ int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, d
   ScopedTimer st(h, "update", s);
   hipLaunchKernelGGL(awfl_update_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in,
                      prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+template <int STAGE>
+int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
+                hipStream_t s) {
+  const Params &P = h->P;
+  const long long nitems = (long long)P.nz * P.ny * r.ne;
+  const size_t lds_bytes = (size_t)P.nx * FLUX_THREADS * sizeof(double);      // one mass-flux slot per face of the line
+  ScopedTimer st(h, "xupd", s);
+  hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nitems, FLUX_THREADS)), dim3(FLUX_THREADS), lds_bytes, s, P, r,
+                     prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+template <int STAGE>
+int launch_trupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
+                 hipStream_t s) {
+  ScopedTimer st(h, "trupd", s);
+  hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+                     h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -495,7 +557,7 @@ void free_all(pam_amd_awfl *h) {
   destroy_chunks(h);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   h->ev_fork = nullptr;
-  double **bufs[] = {&h->prim0, &h->prim1, &h->flux_x, &h->flux_y, &h->flux_z, &h->seed, &h->mult, &h->dz,
+  double **bufs[] = {&h->prim0, &h->prim1, &h->prim2, &h->flux_x, &h->flux_y, &h->flux_z, &h->seed, &h->mult, &h->dz,
                      &h->grav_var, &h->hy_dens, &h->hy_pres, &h->vz, &h->vert_s2c, &h->vert_wrl};
   for (auto b : bufs) {
     if (*b) (void)hipFree(*b);
@@ -593,6 +655,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->n_seed = (size_t)P.nt * P.ncell;
   INIT_TRY(hipMalloc(&h->prim0, h->n_prim * 8));
   INIT_TRY(hipMalloc(&h->prim1, h->n_prim * 8));
+  // the fused x-sweep keeps a whole x line's face mass fluxes in the thread's LDS slots and writes into a third buffer
+  h->fused_supported = (size_t)P.nx * FLUX_THREADS * sizeof(double) <= 128 * 1024;
+  h->fused = h->fused_supported;
+  if (h->fused_supported) INIT_TRY(hipMalloc(&h->prim2, h->n_prim * 8));
   INIT_TRY(hipMalloc(&h->flux_x, h->n_flux_xy * 8));
   INIT_TRY(hipMalloc(&h->flux_y, (P.sim2d ? 8 : h->n_flux_xy) * 8));
   INIT_TRY(hipMalloc(&h->flux_z, h->n_flux_z * 8));
@@ -623,6 +689,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 64 * 1024;   // with >1 chunk: at most 2 flux workgroups per CU, leaving wave slots for update blocks
   if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }
@@ -788,33 +857,73 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   //    (A1 -> B1 -> C1 -> A2 ...): two VALU-bound flux kernels never share the chip;
   //  * a chunk's HBM-bound FCT/update kernels run on its normal-priority stream beside the NEXT chunk's flux kernel.
   hipEvent_t prev_flux = nullptr;
-  auto stage = [&](Chunk &c, int st, const double *pin, double *pout, double dt_stage) -> int {
+  // One tendency stage of one chunk.  Unfused: flux (x,y,z) -> FCT -> update.  Fused: flux (y,z) -> x-sweep + state update
+  // -> FCT -> tracer update + pressure (pout differs from pin and p0).
+  auto stage = [&](Chunk &c, int st, const double *pin, const double *p0, double *pout, double dt_stage) -> int {
     int r2;
+    if (h->fused) {
+      // Fused stage.  The two polynomial kernels (flux y,z and the fused x-sweep) of ALL chunks run back to back on ONE
+      // high-priority compute stream, chunk after chunk; a chunk's HBM-bound tail (FCT multiplier, tracer update + pressure)
+      // runs on the chunk's own stream beside the NEXT chunk's flux kernel.  The x-sweep is both VALU- and HBM-heavy and
+      // gets the chip to itself.
+      hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
+      if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
+      if ((r2 = launch_flux(h, pin, c.r, cs, 6))) return r2;
+      if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, c.r, cs);
+      else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, c.r, cs);
+      else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, c.r, cs);
+      if (r2) return r2;
+      if (forked) {
+        HIP_TRY(hipEventRecord(c.flux_done, cs));
+        HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
+      }
+      if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
+      if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      if (r2) return r2;
+      if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+      return PAM_AMD_OK;
+    }
     if (forked) {
       HIP_TRY(hipStreamWaitEvent(c.fstream, c.upd_done, 0));               // this chunk's previous update / init
       if (prev_flux) HIP_TRY(hipStreamWaitEvent(c.fstream, prev_flux, 0));  // the flux kernel launched just before
     }
-    if ((r2 = launch_flux(h, pin, c.r, c.fstream))) return r2;
+    if ((r2 = launch_flux(h, pin, c.r, c.fstream, 7))) return r2;
     if (forked) {
       HIP_TRY(hipEventRecord(c.flux_done, c.fstream));
       prev_flux = c.flux_done;
       HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
     }
     if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
-    if (st == 1) r2 = launch_update<1>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
-    else if (st == 2) r2 = launch_update<2>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
-    else r2 = launch_update<3>(h, pin, h->prim0, pout, dt_dyn, c.r, c.stream);
+    if (st == 1) r2 = launch_update<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+    else if (st == 2) r2 = launch_update<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+    else r2 = launch_update<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
     if (r2) return r2;
     if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
     return PAM_AMD_OK;
   };
   for (int ic = 0; ic < ncycles; ic++) {
-    for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
-      if ((rc = stage(c, 1, h->prim0, h->prim1, dt_dyn))) return rc;
-    for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
-      if ((rc = stage(c, 2, h->prim1, h->prim1, (1.0 / 4.0) * dt_dyn))) return rc;
-    for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
-      if ((rc = stage(c, 3, h->prim1, h->prim0, (2.0 / 3.0) * dt_dyn))) return rc;
+    double *A = h->prim0, *B = h->prim1, *C = h->prim2;
+    if (h->fused) {
+      // three rotating buffers: A (sub-step start) -> B -> C -> B; the new state B becomes prim0
+      for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
+        if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+      for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
+        if ((rc = stage(c, 2, B, A, C, (1.0 / 4.0) * dt_dyn))) return rc;
+      for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
+        if ((rc = stage(c, 3, C, A, B, (2.0 / 3.0) * dt_dyn))) return rc;
+      h->prim0 = B;
+      h->prim1 = A;
+    } else {
+      // pointwise update kernel: stage 2 and 3 update in place
+      for (auto &c : h->chunks)
+        if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+      for (auto &c : h->chunks)
+        if ((rc = stage(c, 2, B, A, B, (1.0 / 4.0) * dt_dyn))) return rc;
+      for (auto &c : h->chunks)
+        if ((rc = stage(c, 3, B, A, A, (2.0 / 3.0) * dt_dyn))) return rc;
+    }
   }
   // Dycore.h:254 (per chunk), then join: the caller's stream continues after every chunk has finished
   for (auto &c : h->chunks)
@@ -922,17 +1031,54 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
   return build_chunks(h);
 }
 
+int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (enable && !h->fused_supported)
+    return fail(PAM_AMD_EINVAL, "set_fused_stage: the fused x-sweep needs nx <= 64 (one LDS slot per face of the line)");
+  h->fused = enable != 0;
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem) {
   if (!h || !name || !device_ptr || !nelem) return fail(PAM_AMD_EINVAL, "debug_get_buffer: null argument");
   const std::string k(name);
   if (k == "prim0") { *device_ptr = h->prim0; *nelem = h->n_prim; }
   else if (k == "prim1") { *device_ptr = h->prim1; *nelem = h->n_prim; }
+  else if (k == "prim2") { *device_ptr = h->prim2; *nelem = h->prim2 ? h->n_prim : 0; }
   else if (k == "flux_x") { *device_ptr = h->flux_x; *nelem = h->n_flux_xy; }
   else if (k == "flux_y") { *device_ptr = h->flux_y; *nelem = h->P.sim2d ? 0 : h->n_flux_xy; }
   else if (k == "flux_z") { *device_ptr = h->flux_z; *nelem = h->n_flux_z; }
   else if (k == "seed") { *device_ptr = h->seed; *nelem = h->n_seed; }
   else if (k == "mult") { *device_ptr = h->mult; *nelem = h->n_seed; }
   else return fail(PAM_AMD_EINVAL, "debug_get_buffer: unknown buffer " + k);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_debug_weno(pam_amd_awfl_t *h, int level, const double *stencils, int n, double *left, double *right) {
+  if (!h || !stencils || !left || !right || n < 0) return fail(PAM_AMD_EINVAL, "debug_weno: bad argument");
+  if (level > h->P.nz + 1) return fail(PAM_AMD_EINVAL, "debug_weno: level must be < nz+2 (negative = uniform-grid constants)");
+  USE_DEVICE(h);
+  if (n == 0) return PAM_AMD_OK;
+  hipLaunchKernelGGL(awfl_weno_kat_kernel, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->P, level, stencils, n, left, right);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+// One tendency stage on its own: stage 1 of a sub-step of length dt_dyn from the resident state (a forward-Euler step
+// prim0 -> new prim0; the FCT seed is left as stage 1 leaves it), with whichever stage structure is selected.
+int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (!h->hydro_declared) return fail(PAM_AMD_ESTATE, "debug_stage: declare_current_profile_as_hydrostatic first");
+  USE_DEVICE(h);
+  const EnsRange r = full_range(h->P);
+  int rc;
+  if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7))) return rc;
+  if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream))) return rc;
+  if ((rc = launch_fct(h, dt_dyn, r, h->stream))) return rc;
+  if (h->fused) rc = launch_trupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
+  else rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
+  if (rc) return rc;
+  std::swap(h->prim0, h->prim1);
   return PAM_AMD_OK;
 }
 

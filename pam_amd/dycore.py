@@ -216,10 +216,24 @@ class Dycore:
     def set_ensemble_chunks(self, chunks, flux_lds_floor_bytes=64 * 1024):
         check(self._lib.pam_amd_awfl_set_ensemble_chunks(self._h, int(chunks), int(flux_lds_floor_bytes)))
 
+    def set_fused_stage(self, enable):
+        check(self._lib.pam_amd_awfl_set_fused_stage(self._h, int(bool(enable))))
+
     def debug_buffer(self, name):
         ptr, n = C.c_void_p(), C.c_size_t()
         check(self._lib.pam_amd_awfl_debug_get_buffer(self._h, name.encode(), C.byref(ptr), C.byref(n)))
         return _device_view(ptr.value, (n.value,), self._device)
+
+    def debug_weno(self, stencils, level=-1):
+        """stencils: (n,5) float64 CUDA tensor -> (left, right) edge values (test hook)"""
+        st = stencils.contiguous()
+        left, right = torch.empty(st.shape[0], dtype=torch.float64, device=st.device), torch.empty(
+            st.shape[0], dtype=torch.float64, device=st.device)
+        check(self._lib.pam_amd_awfl_debug_weno(self._h, int(level), st.data_ptr(), st.shape[0], left.data_ptr(), right.data_ptr()))
+        return left, right
+
+    def debug_stage(self, dt_dyn):
+        check(self._lib.pam_amd_awfl_debug_stage(self._h, float(dt_dyn)))
 
     def debug_flux_stage(self, dt):
         check(self._lib.pam_amd_awfl_debug_flux_stage(self._h, float(dt)))

@@ -18,16 +18,18 @@ using namespace pama;
 
 struct Emu {
   Params P;
-  std::vector<double> prim0, prim1, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
+  std::vector<double> prim0, prim1, prim2, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
   VerticalTables vt;
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
+  int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
 };
 
-static void flux_launch(Emu *h, const double *prim) {
+static void flux_launch(Emu *h, const double *prim, int sweeps = 7) {
   const Params &P = h->P;
   std::vector<double> lds((size_t)FLUX_MAX_SPAN * FLUX_THREADS);
   for (int dir = 0; dir < 3; dir++) {
     if (dir == 1 && P.sim2d) continue;
+    if (!((sweeps >> dir) & 1)) continue;
     const int nfaces = dir == 0 ? P.nx : (dir == 1 ? P.ny : P.nz + 1);
     const long long nitems = dir == 0 ? (long long)P.nz * P.ny * P.nens
                                       : (dir == 1 ? (long long)P.nz * P.nx * P.nens : (long long)P.ny * P.nx * P.nens);
@@ -71,6 +73,23 @@ static void update_launch(Emu *h, const double *in, const double *p0, double *ou
                        cell_of(h->P, idx));
 }
 
+// launch geometry of awfl_xupd_kernel: 256-thread blocks, thread t of block b owns item b*256 + t
+template <int STAGE>
+static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
+  const Params &P = h->P;
+  std::vector<double> lds((size_t)P.nx * FLUX_THREADS);
+  const long long nitems = (long long)P.nz * P.ny * P.nens;
+  for (long long item = 0; item < nitems; item++)
+    flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), item, dt, lds.data(), FLUX_THREADS,
+                              (int)(item % FLUX_THREADS));
+}
+template <int STAGE>
+static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
+  for (long long idx = 0; idx < h->P.ncell; idx++)
+    tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt,
+                              cell_of(h->P, idx));
+}
+
 static TracerPtrs tptrs(const Emu *h, double *tracers) {
   TracerPtrs tp;
   for (int t = 0; t < MAXT; t++) tp.p[t] = nullptr;
@@ -104,6 +123,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->vz = h->vt.table;
   const double nan = NAN;
   h->prim0.assign((size_t)(6 + nt) * P.prim_fs, nan); h->prim1.assign((size_t)(6 + nt) * P.prim_fs, nan);
+  h->prim2.assign((size_t)(6 + nt) * P.prim_fs, nan);
   h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
   h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
   h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
@@ -117,6 +137,7 @@ void emu_destroy(Emu *h) { delete h; }
 void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
 void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
 void emu_set_span(Emu *h, int span) { h->span = span; }
+void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
 int emu_vz_per_ens(Emu *h) { return h->P.vz_per_ens; }
 double *emu_buffer(Emu *h, const char *name) {
   std::string k(name);
@@ -176,10 +197,24 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
   dt = crm_dt / ncycles;
   if (dt_out) *dt_out = dt;
   double *p0 = h->prim0.data(), *p1 = h->prim1.data();
-  for (int ic = 0; ic < ncycles; ic++) {
-    flux_launch(h, p0); fct_launch(h, dt); update_launch<1>(h, p0, p0, p1, dt);
-    flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt); update_launch<2>(h, p1, p0, p1, dt);
-    flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
+  if (h->fused) {   // as pam_amd_awfl_time_step: three rotating buffers A -> B -> C -> B, then B is the state
+    double *A = h->prim0.data(), *B = h->prim1.data(), *C = h->prim2.data();
+    // poison the x fluxes of the state: the fused stage must not read them
+    for (int ic = 0; ic < ncycles; ic++) {
+      std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);
+      flux_launch(h, A, 6); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt); trupd_launch<1>(h, A, A, B, dt);
+      flux_launch(h, B, 6); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt); trupd_launch<2>(h, B, A, C, dt);
+      flux_launch(h, C, 6); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt); trupd_launch<3>(h, C, A, B, dt);
+      std::swap(A, B);
+    }
+    if (A != h->prim0.data()) h->prim0.swap(h->prim1);   // an odd number of sub-steps: the state sits in prim1
+    p0 = h->prim0.data();
+  } else {
+    for (int ic = 0; ic < ncycles; ic++) {
+      flux_launch(h, p0); fct_launch(h, dt); update_launch<1>(h, p0, p0, p1, dt);
+      flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt); update_launch<2>(h, p1, p0, p1, dt);
+      flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
+    }
   }
   TracerPtrs tp = tptrs(h, tracers);
   for (long long idx = 0; idx < h->P.ncell; idx++) finalize_body(h->P, p0, h->seed.data(), rho_d, u, v, w, T, tp, cell_of(h->P, idx));

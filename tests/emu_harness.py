@@ -31,6 +31,7 @@ def load():
         lib.emu_set_grav_balance.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_seg.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_span.argtypes = [C.c_void_p, C.c_int]
+        lib.emu_set_fused.argtypes = [C.c_void_p, C.c_int]
         lib.emu_vz_per_ens.argtypes = [C.c_void_p]
         lib.emu_buffer.restype = _DP
         lib.emu_buffer.argtypes = [C.c_void_p, C.c_char_p]
@@ -79,6 +80,9 @@ class EmuDycore:
 
     def set_span(self, s):
         self.lib.emu_set_span(self.h, int(s))
+
+    def set_fused(self, on):
+        self.lib.emu_set_fused(self.h, int(bool(on)))
 
     @property
     def vz_per_ens(self):

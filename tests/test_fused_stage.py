@@ -1,0 +1,93 @@
+"""GPU: the fused stage (flux(y,z) -> x-sweep + state update in one kernel -> FCT -> tracer update + pressure; the default)
+against the three-kernel stage (flux(x,y,z) -> FCT -> update) of the same library: bit for bit, because both are built from
+the same helpers with explicit rounding points (awfl_device.h).  Parity of either against the oracle is
+tests/test_gpu_parity.py (which runs the default, i.e. the fused stage)."""
+import copy
+
+import numpy as np
+import pytest
+
+from pam_amd import idealized as idz
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (nens, nx, ny, nz, tracers, zint, per_ens, mode_a, consts)
+    "3d_nt1_L60grid": (66, 32, 4, 60, idz.TRACERS_NONE, idz.l60_interfaces(), False, True, idz.CONSTS_DEFAULT),
+    "3d_nt4_stretched_B": (3, 6, 6, 8, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(8, 12000.0), False, False, idz.CONSTS_DEFAULT),
+    "2d_nt10_perens_p3": (70, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), True, True, idz.CONSTS_P3),
+    "3d_minimal_3x3x3": (1, 3, 3, 3, idz.TRACERS_NONE, idz.uniform_interfaces(3, 3000.0), False, True, idz.CONSTS_DEFAULT),
+    "3d_nx64_widest_fused_line": (2, 64, 3, 5, idz.TRACERS_NONE, idz.uniform_interfaces(5, 5000.0), False, True, idz.CONSTS_DEFAULT),
+}
+
+
+def _run(case, fused, chunks=0):
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts = CASES[case]
+    xlen = nx * 500.0
+    ylen = ny * 500.0 if ny > 1 else xlen
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    zi = np.asarray(zint)[:, None] * np.ones((1, nens))
+    if per_ens:
+        zi = zi * (1 + 0.01 * np.arange(nens))[None, :]
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 2.0)
+    for k, v in consts.items():
+        coupler.set_option(k, v)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(xlen, ylen, zi)
+    for n, p, m in tr:
+        coupler.add_tracer(n, "", p, m)
+    dycore = Dycore()
+    dycore.init(coupler)
+    dycore.set_fused_stage(fused)
+    if chunks:
+        dycore.set_ensemble_chunks(chunks)
+    coupler.load_fields(f)
+    if not mode_a:
+        coupler.set_option("balance_hydrostasis_with_gravity", False)
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    ncyc = []
+    for crm_dt in (2.0, 0.7, 2.0):        # odd and even sub-step counts: both parities of the three-buffer rotation
+        coupler.set_option("crm_dt", crm_dt)
+        ncyc.append(dycore.timeStep(coupler))
+    torch.cuda.synchronize()
+    out = coupler.dump_fields()
+    dycore.finalize(coupler)
+    return ncyc, out
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
+    n0, a = _run(case, fused=False)
+    n1, b = _run(case, fused=True)
+    assert n0 == n1
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
+def test_fused_stage_is_chunking_invariant():
+    """two member ranges on internal streams (fork/join, buffer rotation per range) == one range"""
+    _, a = _run("3d_nt1_L60grid", fused=True, chunks=1)
+    _, b = _run("3d_nt1_L60grid", fused=True, chunks=2)
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_fused_stage_refuses_lines_longer_than_its_lds_slots():
+    from pam_amd import Dycore, PamCoupler
+    from pam_amd.capi import PamAmdError
+    nens, nx, ny, nz = 2, 80, 1, 5
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 1.0)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(nx * 500.0, nx * 500.0, idz.uniform_interfaces(nz, 5000.0))
+    coupler.add_tracer("water_vapor", "", True, True)
+    dycore = Dycore()
+    dycore.init(coupler)                       # falls back to the three-kernel stage on its own
+    with pytest.raises(PamAmdError):
+        dycore.set_fused_stage(True)
+    dycore.finalize(coupler)

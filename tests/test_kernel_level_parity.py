@@ -1,0 +1,246 @@
+"""GPU, kernel level: the places where the HIP arithmetic differs from the oracle's by construction, each compared on its
+own so that a chaotic multi-step run is not needed to see them ("closable parity gaps"):
+
+  * the device WENO reconstruction alone (v_rcp_f64 + Newton, FMA, difference form, fused bridge) on adversarial stencils,
+    uniform-grid constants and per-level vertical tables, against oracle.reconstruct / reconstruct_level;
+  * every face flux of one stage -- all 5+NT fields, AFTER the FCT limiter, including the periodic-seam min() quirk -- on a
+    case with blobs, exact zeros, active limiting and a negative seam flux; plus the FCT seed the stage leaves;
+  * ONE tendency stage and ONE SSPRK3 sub-step with EVERY prognostic field (rho_d, u, v, w, T, every tracer) gated at
+    1e-12 * max|field| -- the north_star tolerance; looser gates are used only for multi-step runs (test_gpu_parity.py)."""
+import copy
+
+import numpy as np
+import pytest
+
+from pam_amd import idealized as idz
+from test_gpu_parity import _setup
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def _stencils(rng):
+    st = [[0, 0, 0.85, 1, 1], [1, 1, 0.85, 0, 0], [0, 0, 0, 1, 1], [1, 0, 0, 0, 0], [0, 0, 0, 0, 1], [0, 1, 0, 1, 0],
+          [1, 1, 1, 1, 1], [0, 0, 0, 0, 0], [-3.5, -3.5, -3.5, -3.5, -3.5], [1e5, 1e5, 1e5, 1e5, 1e5]]
+    st += [list(1e5 - 1200.0 * np.arange(5) + s) for s in (0.0, 0.37)]                       # hydrostatic-like pressure column
+    st += [list(np.sin(0.3 * np.arange(5) + 0.1)), list(300.0 + 2 * np.cos(0.7 * np.arange(5)))]
+    st = [np.array(s, dtype=np.float64) for s in st]
+    for _ in range(200):
+        st.append(rng.uniform(-1, 1, 5))                                                     # random O(1)
+        st.append(1e5 + rng.uniform(-3e3, 3e3, 5))                                           # 1e5 Pa scale
+        st.append(1e-300 * rng.uniform(0.1, 1, 5))                                           # tiny: the eps terms dominate
+        st.append(300.0 + 1e-13 * rng.integers(-3, 4, 5))                                    # constant + few-ulp noise (TV ~ 0)
+        st.append(rng.uniform(0, 1, 1) * np.array([0, 0, 1, 1, 1.0]) + 1e-3 * rng.uniform(-1, 1, 5))   # noisy steps
+        st.append(np.cumsum(rng.uniform(0, 1, 5)) * 10.0 ** rng.integers(-6, 7))             # monotone, any magnitude
+    return np.array(st)
+
+
+@pytest.mark.parametrize("grid", ["uniform_constants", "vertical_tables"])
+def test_device_weno_known_answers(grid):
+    """>= 1000 stencils through awfl_weno_kat_kernel vs the oracle's reconstruct (WenoLimiter.h:98-181 + Dycore.h:591-604 in
+    the reference's own operation order).  Gate: 8 units in the last place of the largest stencil value on the uniform grid
+    (the result is a convex-ish combination of polynomials of the stencil: its rounding unit is that of the data, not of the
+    result, which can be arbitrarily close to zero), 16 with the vertical tables (the matrices of a stretched grid, and of
+    the clamped boundary levels 0 and nz+1 in particular, have entries of magnitude ~3-10 that amplify the rounding of the
+    stencil differences; measured worst: 9, on a deliberately rough 1e5 +- 3e3 stencil).  Measured maxima are printed."""
+    import torch
+    from oracle import awfl_oracle as ao
+    nz = 12
+    zint = idz.stretched_interfaces(nz, 12000.0, ratio=1.25)
+    coupler, dycore, oracle, fo, names = _setup(2, 6, 1, nz, idz.TRACERS_NONE, zint)
+    st = _stencils(np.random.default_rng(20260104))
+    assert len(st) >= 1000
+    dev = torch.from_numpy(st).to("cuda:0")
+    levels = [-1] if grid == "uniform_constants" else [0, 1, 2, 5, nz - 1, nz, nz + 1]
+    worst = 0.0
+    for lev in levels:
+        L, R = dycore.debug_weno(dev, lev)
+        torch.cuda.synchronize()
+        L, R = L.cpu().numpy(), R.cpu().numpy()
+        for i, s in enumerate(st):
+            if lev < 0:
+                eL, eR = ao.reconstruct(s, 0), ao.reconstruct(s, 1)
+            else:
+                eL, eR = oracle.reconstruct_level(lev, 0, s, 0), oracle.reconstruct_level(lev, 0, s, 1)
+            unit = np.spacing(max(np.abs(s).max(), 1e-290))
+            e = max(abs(L[i] - eL), abs(R[i] - eR)) / unit
+            worst = max(worst, e)
+            assert e <= (8.0 if lev < 0 else 16.0), (lev, i, s.tolist(), (L[i], eL), (R[i], eR), e)
+    print("device WENO vs oracle, %s: worst %.2f units in the last place of max|stencil| over %d stencils x %d levels"
+          % (grid, worst, len(st), len(levels)))
+    dycore.finalize(coupler)
+
+
+def _fct_case():
+    """3-D, Kessler+SHOC tracer set (3 positive mass-carrying tracers + tke), blobs with exact zeros around them, a mean wind
+    against x so that the periodic-seam flux is negative, and a stage time step long enough for the limiter to act."""
+    nens, nx, ny, nz = 3, 8, 5, 9
+    tr = idz.TRACERS_KESSLER_SHOC
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, zint, mag=1.0)
+    for f in (fo,):
+        f["uvel"] -= 25.0
+        f["vvel"] += 7.0
+        for t in (1, 2, 3):
+            f["tracers"][t] *= 50.0          # thin blobs of large amplitude: outflow exceeds the mass available at their edges
+    coupler.load_fields(fo)
+    return coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, len(tr))
+
+
+def test_fct_limited_fluxes_of_all_fields_and_seed_match_oracle():
+    import torch
+    coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, nt) = _fct_case()
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    oracle.declare_current_profile_as_hydrostatic(fo)
+    dt = 6.0 * oracle.compute_time_step(fo)
+    st, trc = oracle.convert_coupler_to_dynamics(fo)
+    seed0 = trc[:, 3:-3, 3:-3, 3:-3, :].copy()
+    stend, ttend, fl = oracle.compute_tendencies(st, trc, seed0, dt, want_fluxes=True)       # post-FCT (Dycore.h:525-550)
+    dycore.set_fused_stage(False)                     # this structure stores every face flux, x fluxes of the state included
+    dycore.convert_coupler_to_dynamics(coupler)
+    dycore.debug_flux_stage(dt)
+    torch.cuda.synchronize()
+    gx = dycore.debug_buffer("flux_x").cpu().numpy().reshape(5 + nt, nz, ny, nx, nens)
+    gy = dycore.debug_buffer("flux_y").cpu().numpy().reshape(5 + nt, nz, ny, nx, nens)
+    gz = dycore.debug_buffer("flux_z").cpu().numpy().reshape(5 + nt, nz + 1, ny, nx, nens)
+    mult = dycore.debug_buffer("mult").cpu().numpy().reshape(nt, nz, ny, nx, nens)
+    pos = np.array([p for _, p, _ in idz.TRACERS_KESSLER_SHOC])
+    assert (mult[pos] < 1.0).any() and (mult[pos] == 1.0).any(), "the case must exercise the limiter"
+    assert (seed0 == 0.0).any(), "the case must contain exact zeros"
+    assert (gx[5:, :, :, 0] < 0).any(), "the case must have a negative flux at the periodic seam"
+
+    def cmp(g, o, what):
+        scale = max(np.abs(o).max(), 1.0 if what < 5 else 1e-300)
+        assert np.abs(g - o).max() <= TOL * scale, (what, np.abs(g - o).max() / scale)
+    for l in range(5):                                # state fluxes: untouched by FCT
+        cmp(gx[l], fl[0][l][:, :, :nx], l); cmp(gy[l], fl[1][l][:, :ny], l); cmp(gz[l], fl[2][l], l)
+    # tracer fluxes: the HIP path keeps the raw flux and a per-cell multiplier; limited flux through a face = F * mult(donor)
+    # (awfl_device.h limited_flux).  The reference limits its two copies of the periodic face separately and reconciles them
+    # with min() in the divergence kernel (Dycore.h:574-579): expected seam value = min(copy 0, copy n).
+    for t in range(nt):
+        F, m = gx[5 + t], mult[t]
+        lim = np.where(F > 0, F * np.roll(m, 1, axis=2), np.where(F < 0, F * m, F))
+        lim[:, :, 0] = np.where(F[:, :, 0] < 0, F[:, :, 0], lim[:, :, 0])                    # negative seam flux stays unlimited
+        o = fl[0][5 + t]
+        exp = o[:, :, :nx].copy()
+        exp[:, :, 0] = np.minimum(o[:, :, 0], o[:, :, nx])
+        cmp(lim, exp, 5 + t)
+        F = gy[5 + t]
+        lim = np.where(F > 0, F * np.roll(m, 1, axis=1), np.where(F < 0, F * m, F))
+        lim[:, 0] = np.where(F[:, 0] < 0, F[:, 0], lim[:, 0])
+        o = fl[1][5 + t]
+        exp = o[:, :ny].copy()
+        exp[:, 0] = np.minimum(o[:, 0], o[:, ny])
+        cmp(lim, exp, 5 + t)
+        F = gz[5 + t]
+        mlo = np.concatenate([np.ones_like(m[:1]), m], axis=0)                               # donor below face k: cell k-1
+        mhi = np.concatenate([m, np.ones_like(m[:1])], axis=0)                               # donor above: cell k
+        lim = np.where(F > 0, F * mlo, np.where(F < 0, F * mhi, F))
+        cmp(lim, fl[2][5 + t], 5 + t)
+    dycore.finalize(coupler)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_x_stage", "three_kernel_stage"])
+@pytest.mark.parametrize("mode_a", [True, False], ids=["modeA", "modeB"])
+def test_single_stage_every_prognostic_field_1e12(fused, mode_a):
+    """ONE compute_tendencies + forward-Euler combine (Dycore.h:156-176) from identical inputs: rho, u, v, w, theta, every
+    tracer mixing ratio, the next stage's pressure and the FCT seed, each within 1e-12 * max|field| of the oracle."""
+    import torch
+    coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, nt) = _fct_case()
+    if not mode_a:
+        coupler.set_option("balance_hydrostasis_with_gravity", False)
+        oracle.set_grav_balance(False)
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    oracle.declare_current_profile_as_hydrostatic(fo)
+    dt = 0.9 * oracle.compute_time_step(fo)
+    st, trc = oracle.convert_coupler_to_dynamics(fo)
+    seed0 = trc[:, 3:-3, 3:-3, 3:-3, :].copy()
+    stend, ttend = oracle.compute_tendencies(st, trc, seed0, dt)                              # st, trc now hold q' (Q5)
+    q = st[:, 3:-3, 3:-3, 3:-3, :] + dt * stend
+    pos = np.array([p for _, p, _ in idz.TRACERS_KESSLER_SHOC])
+    tin = trc[:, 3:-3, 3:-3, 3:-3, :]
+    t1 = tin + dt * ttend
+    t1[pos] = np.maximum(0.0, t1[pos])                                                        # Dycore.h:168-171
+    seed1 = 0.75 * tin + 0.25 * t1                                                            # Dycore.h:173-174
+    gam, C0 = oracle.option("gamma_d"), oracle.option("C0")
+    pres = C0 * np.power(q[4], gam) - (0.0 if mode_a else oracle.hy_pressure_cells[:, None, None, :])
+    exp = [q[0], pres, q[1] / q[0], q[2] / q[0], q[3] / q[0], q[4] / q[0]] + [t1[t] / q[0] for t in range(nt)]
+    dycore.set_fused_stage(fused)
+    dycore.convert_coupler_to_dynamics(coupler)
+    dycore.debug_stage(dt)
+    torch.cuda.synchronize()
+    got = dycore.debug_buffer("prim0").cpu().numpy().reshape(6 + nt, nz + 6, ny, nx, nens)[:, 3:-3]
+    gseed = dycore.debug_buffer("seed").cpu().numpy().reshape(nt, nz, ny, nx, nens)
+    label = ["rho", "pressure", "u", "v", "w", "theta"] + ["q_" + n for n in names]
+    errs = {}
+    for i, e in enumerate(exp):
+        errs[label[i]] = np.abs(got[i] - e).max() / max(np.abs(e).max(), 1e-300)
+    for t in range(nt):
+        errs["seed_" + names[t]] = np.abs(gseed[t] - seed1[t]).max() / max(np.abs(seed1[t]).max(), 1e-300)
+    print("single stage, relative to max|field|:", {k: "%.1e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= TOL, (k, v, errs)
+    dycore.finalize(coupler)
+
+
+@pytest.mark.parametrize("case", ["3d_nt4_fct", "2d_nt10_p3"])
+def test_single_substep_every_prognostic_field_1e12(case):
+    """ONE SSPRK3 sub-step (crm_dt just below the CFL step -> ncycles = 1) through Dycore::timeStep: every coupler field,
+    every tracer, gated at the north_star tolerance.  Multi-step runs amplify last-bit differences of the small, noisy
+    fields (v, w) through the flow's own sensitivity -- the growth is printed by test_error_growth_is_the_flows_own."""
+    import torch
+    if case == "3d_nt4_fct":
+        coupler, dycore, oracle, fo, names, dims = _fct_case()
+    else:
+        coupler, dycore, oracle, fo, names = _setup(5, 16, 1, 20, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(20, 14000.0),
+                                                     consts=idz.CONSTS_P3)
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    oracle.declare_current_profile_as_hydrostatic(fo)
+    crm_dt = 0.95 * oracle.compute_time_step(fo)
+    coupler.set_option("crm_dt", crm_dt)
+    n = dycore.timeStep(coupler)
+    n2, _ = oracle.time_step(fo, crm_dt)
+    assert n == n2 == 1
+    torch.cuda.synchronize()
+    got = coupler.dump_fields()
+    errs = {k: np.abs(got[k] - fo[k]).max() / max(np.abs(fo[k]).max(), 1e-300) for k in ("density_dry", "uvel", "vvel", "wvel", "temp")}
+    for t, nme in enumerate(names):
+        errs[nme] = np.abs(got["tracers"][t] - fo["tracers"][t]).max() / max(np.abs(fo["tracers"][t]).max(), 1e-300)
+    print("single sub-step, relative to max|field|:", {k: "%.1e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= TOL, (k, v, errs)
+    dycore.finalize(coupler)
+
+
+def test_error_growth_is_the_flows_own():
+    """Why multi-step gates on u, v, w are looser than 1e-12: the oracle run twice, once from inputs perturbed by one unit in
+    the last place, diverges from itself at the same rate as the HIP path diverges from the oracle.  Prints both series."""
+    import torch
+    nens, nx, ny, nz = 2, 8, 6, 10
+    tr = idz.TRACERS_NONE
+    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, idz.stretched_interfaces(nz, 12000.0), mag=1.0)
+    from oracle import awfl_oracle as ao
+    names_, pos, mass, idwv = idz.tracer_flags(tr)
+    o2 = ao.OracleDycore(nens, nx, ny, nz, nx * 500.0, ny * 500.0, np.diff(idz.stretched_interfaces(nz, 12000.0)), pos, mass, idwv)
+    f2 = copy.deepcopy(fo)
+    f2["temp"] = np.nextafter(f2["temp"], np.inf)
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    oracle.declare_current_profile_as_hydrostatic(fo)
+    o2.declare_current_profile_as_hydrostatic(f2)
+    rows = []
+    for step in range(6):
+        dycore.timeStep(coupler)
+        oracle.time_step(fo, 2.0)
+        o2.time_step(f2, 2.0)
+        torch.cuda.synchronize()
+        got = coupler.dump_fields()
+        rows.append((step + 1,) + tuple(np.abs(got[k] - fo[k]).max() / np.abs(fo[k]).max() for k in ("density_dry", "temp", "uvel", "wvel", "vvel"))
+                    + tuple(np.abs(f2[k] - fo[k]).max() / np.abs(fo[k]).max() for k in ("density_dry", "temp", "uvel", "wvel", "vvel")))
+    print("timeStep | HIP vs oracle: rho_d T u w v | oracle vs oracle(+1ulp T): rho_d T u w v")
+    for r in rows:
+        print("%8d | %s | %s" % (r[0], " ".join("%.1e" % x for x in r[1:6]), " ".join("%.1e" % x for x in r[6:])))
+    last = rows[-1]
+    for i in range(5):      # the HIP path stays within 20x of the oracle's own 1-ulp sensitivity (and within the multi-step gates)
+        assert last[1 + i] <= max(20.0 * last[6 + i], 1e-13), (i, last)
+    dycore.finalize(coupler)
