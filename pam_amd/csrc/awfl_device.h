@@ -48,10 +48,7 @@ constexpr int FLUX_WAVES = FLUX_THREADS / 64;
 #define PAMA_FLUX_NF 2
 #endif
 constexpr int FLUX_NF = PAMA_FLUX_NF;   // advected fields swept together (independent polynomial chains per iteration)
-#ifndef PAMA_FLUX_MAX_SPAN
-#define PAMA_FLUX_MAX_SPAN 32
-#endif
-constexpr int FLUX_MAX_SPAN = PAMA_FLUX_MAX_SPAN; // faces per thread: 32 LDS slots x 256 threads x 8 B = 64 KiB -> two workgroups per CU
+constexpr int FLUX_MAX_SPAN = 64; // longest span one wavefront sweeps without a cut (a 61-face column, a 64-cell line)
 constexpr int VZ_STRIDE = 30;  // per-level vertical table in difference form (struct DTable)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
@@ -321,7 +318,8 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
 // Vertical direction: per-level difference-form table built at init from the cell-edge locations
 // (Dycore.h:904-937 + TransformMatrices_variable.h -> awfl_vertical.h), used as Dycore.h:454-469.
 // tab points at VZ_STRIDE doubles with element stride `ts` (1 for the ensemble-uniform table, nens otherwise).
-PAMA_D void weno5_table(const double u[5], const double *tab, long long ts, const WenoConsts &wc, double &left,
+template <class TabPtr>
+PAMA_D void weno5_table(const double u[5], TabPtr tab, long long ts, const WenoConsts &wc, double &left,
                         double &right) {
 #pragma clang fp contract(off)
   const double d[4] = {u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3]};
@@ -400,6 +398,57 @@ PAMA_D double next_seed(double m_0, double m_in, double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-uniform addressing.  In the fused x-sweep every lane of a wavefront works on the SAME x line (k, j) and differs only
+// in the ensemble member, so every address is  (uniform base)  +  member * 8 bytes.  uni()/uniw() tell the compiler that a
+// pointer is wave-uniform (readfirstlane of an already-uniform value costs nothing): the base then lives in scalar
+// registers, is advanced by the scalar unit, and the access becomes `global_load v, v_member_offset, s[base]` -- one VGPR of
+// address for ALL streams instead of a 64-bit per-lane pointer (two VGPRs + vector adds) per stream.  ONLY for pointers
+// that really are identical across the wavefront.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(1))) double *gc_ptr;
+typedef __attribute__((address_space(1))) double *g_ptr;
+PAMA_D gc_ptr uni(const double *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gc_ptr)(((unsigned long long)hi << 32) | lo);
+}
+PAMA_D g_ptr uniw(double *p) { return (g_ptr)uni(p); }
+// a wave-uniform integer computed on the vector unit (e.g. a division) moved to a scalar register for good: the empty asm
+// keeps the compiler from folding the readfirstlane away and continuing on the vector unit
+// The ensemble-uniform vertical tables are written once in init and never by a kernel: read them through the constant
+// address space so that they are fetched with scalar loads whatever stores the kernel makes through other pointers.
+typedef const __attribute__((address_space(4))) double *const_ptr;
+PAMA_D const_ptr as_constant(const double *p) { return (const_ptr)(unsigned long long)p; }
+PAMA_D int uni_int(int v) {
+  int r = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(r));
+  return r;
+}
+#else
+typedef const double *gc_ptr;
+typedef double *g_ptr;
+PAMA_D gc_ptr uni(const double *p) { return p; }
+PAMA_D g_ptr uniw(double *p) { return p; }
+typedef const double *const_ptr;
+PAMA_D const_ptr as_constant(const double *p) { return p; }
+PAMA_D int uni_int(int v) { return v; }
+#endif
+// The member index of a lane as the compiler must see it for `scalar base + 32-bit lane offset` addressing: an unsigned
+// value whose top bits are KNOWN to be zero (nens < 2^28), so that 8*e cannot wrap in 32 bits.
+PAMA_D unsigned member_offset(int e) { return (unsigned)e & 0x0fffffffu; }
+
+// store_adv / store_rho_pres-style ghost handling with wave-uniform addressing: `cu` = offset of (j, i, member 0) inside a
+// level (uniform), `e` = member (per lane).
+PAMA_D void store_adv_u(const Params &P, double *prim, int pf, int k, long long cu, unsigned e, double val, double ghost_val) {
+  double *f = prim + (long long)pf * P.prim_fs + cu;
+  uniw(f + (long long)(k + HS) * P.sz)[e] = val;
+  if (k == 0)
+    for (int kk = 0; kk < HS; kk++) uniw(f + (long long)(HS - 1 - kk) * P.sz)[e] = ghost_val;     // Dycore.h:670,675
+  if (k == P.nz - 1)
+    for (int kk = 0; kk < HS; kk++) uniw(f + (long long)(HS + P.nz + kk) * P.sz)[e] = ghost_val;  // Dycore.h:671,676
+}
+
+// ------------------------------------------------------------------------------------------------
 // Flux kernel geometry.  One "line" = the cells along the sweep direction for fixed other indices and
 // ensemble member; an "item" = (line, iens) flattened with iens fastest so that a wavefront's 64 lanes read
 // 64 consecutive doubles (512 B, fully coalesced) for nens >= 64.  A thread sweeps a span of faces of its line
@@ -427,100 +476,102 @@ PAMA_D int wrap(int c, int n) {
   return c < 0 ? c + n : c;
 }
 
-// Body of the reconstruction + flux kernel for one thread.
-//   DIR      sweep direction; item = flattened (line, iens)
-//   f0,span  this thread sweeps the faces f0 .. min(f0+span, nfaces)-1 of its line (span <= FLUX_MAX_SPAN: a whole 32-cell
-//            line, or half of a 60-level column)
-//   lds      per-thread private slots (stride nthr doubles, conflict-free ds_read/write_b64):
-//              lds[s*nthr + tid] = mass flux of face f0+s   (s < span)
+// Body of the reconstruction + flux kernel for one lane.
+//   DIR      sweep direction
+//   line     wave-uniform index of the line: x: k*ny + j, y: k*nx + i, z: j*nx + i        e   ensemble member of this lane
+//   f0,span  the wavefront sweeps the faces f0 .. min(f0+span, nfaces)-1 of its line (normally the whole line)
+// All 64 lanes of a wavefront work on the same line and differ in the member only, so every address is a wave-uniform
+// base + member (uni()/uniw(): scalar addressing, one VGPR of address for all streams).
 // The span is swept once per quantity with a 5-cell sliding window in registers, so every state value is loaded once
 // per sweep (plus the 5-cell overlap at the start of a span):
 //   pass 1   rho*u_n, p and u_n together: the acoustic pair gives the face mass flux ruf and face pressure ppf
-//            (Dycore.h:341-366); ruf goes to flux field 0 and to the thread's LDS slots; the normal-momentum flux
-//            ruf*upwind(u_n) + ppf is finished in the same pass, so ppf never needs storing;
-//   pass 2.. one advected field at a time (the other velocity components, theta, tracers), upwinded by the ruf read back
-//            from LDS (Dycore.h:367-385).
+//            (Dycore.h:341-366); ruf goes to flux field 0; the normal-momentum flux ruf*upwind(u_n) + ppf is finished in the
+//            same pass, so ppf never needs storing;
+//   pass 2.. FLUX_NF advected fields at a time (the other velocity components, theta, tracers), upwinded by the ruf read
+//            back from flux field 0 (the lane's own store: L2-resident; no LDS, so residency is bounded by registers only)
+//            (Dycore.h:367-385).
 // Every cell polynomial is computed once and evaluated at both edges; the only redundant polynomial is the one of cell
-// f0-1 at the start of the span ((span+1)/span work).
+// f0-1 at the start of the span.
 // Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
 // with vertical ghosts already filled (Dycore.h:662-710).
 template <int DIR, bool VZ_PER_ENS>
-PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux,
-                           long long item, int f0, int span, double *lds, int nthr, int tid) {
+PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
+                           int f0, int span) {
+  const unsigned eu = member_offset(e);
   const LineGeom g = line_geom(P, DIR);
   const WenoConsts wc = weno_consts();
-  const int e = (int)(item % P.nens);
-  const long long line = item / P.nens;
-  // base offset of the line's cell 0 inside a prim field, and of its face 0 inside a flux field
+  // base offset of the line's cell 0 inside a prim field, and of its face 0 inside a flux field (wave-uniform)
   long long pbase, fbase;
   if (DIR == 0) {  // line = k*ny + j
-    long long k = line / P.ny, j = line % P.ny;
-    pbase = (k + HS) * P.sz + j * P.sy + e;
-    fbase = k * P.sz + j * P.sy + e;
+    const int k = uni_int(line / P.ny), j = line - k * P.ny;
+    pbase = (long long)(k + HS) * P.sz + (long long)j * P.sy;
+    fbase = (long long)k * P.sz + (long long)j * P.sy;
   } else if (DIR == 1) {  // line = k*nx + i
-    long long k = line / P.nx, i = line % P.nx;
-    pbase = (k + HS) * P.sz + i * P.sx + e;
-    fbase = k * P.sz + i * P.sx + e;
+    const int k = uni_int(line / P.nx), i = line - k * P.nx;
+    pbase = (long long)(k + HS) * P.sz + (long long)i * P.sx;
+    fbase = (long long)k * P.sz + (long long)i * P.sx;
   } else {  // line = j*nx + i ; cell c lives at kz = c + HS
-    pbase = (long long)HS * P.sz + line * P.sx + e;
-    fbase = line * P.sx + e;
+    pbase = (long long)HS * P.sz + (long long)line * P.sx;
+    fbase = (long long)line * P.sx;
   }
   const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
 
   auto cell_off = [&](int c) -> long long {
     if (DIR == 2) return pbase + (long long)(c > P.nz + 2 ? P.nz + 2 : c) * g.cs;   // ghosts exist for c in [-3, nz+2]
-    return pbase + (long long)wrap(c, g.n) * g.cs;                     // periodic (Dycore.h:629-657)
+    // periodic (Dycore.h:629-657); c in [-3, n+2] and n >= 3: no division, stays on the scalar unit
+    return pbase + (long long)(c < 0 ? c + g.n : (c >= g.n ? c - g.n : c)) * g.cs;
   };
-  auto vtab = [&](int c) -> const double * {                           // table of cell c: level index c+1
-    return VZ_PER_ENS ? P.vz + ((long long)(c + 1) * VZ_STRIDE) * P.nens + e : P.vz + (long long)(c + 1) * VZ_STRIDE;
+  // vertical table of cell c (level index c+1): tab[m] for the ensemble-uniform table, tab[m*nens + e] per member
+  auto weno = [&](const double u[5], int c, double &L, double &R) {
+    if (DIR != 2) { weno5_const(u, wc, L, R); return; }
+    const double *tab = P.vz + (long long)(c + 1) * VZ_STRIDE * (VZ_PER_ENS ? (long long)P.nens : 1);
+    if (VZ_PER_ENS) weno5_table(u, tab + e, (long long)P.nens, wc, L, R);
+    else weno5_table(u, as_constant(tab), 1, wc, L, R);
   };
-  const long long vts = VZ_PER_ENS ? (long long)P.nens : 1;
   const int nadv = 4 + P.nt;
-  const int cstart = f0 - 1;                                           // the sweep also builds cell f0-1
-  double *ruf_slot = lds + tid;
+  double *fl0 = flux + fbase;                                          // flux field 0 of this line: the mass flux
 
   // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
   {
     const double *pr = prim + (long long)P_RHO * P.prim_fs;
     const double *pn = prim + (long long)ncomp * P.prim_fs;
     const double *pp = prim + (long long)P_PRES * P.prim_fs;
-    double *fl0 = flux + fbase;
     double *fln = flux + (long long)(1 + ncomp - P_U) * g.fs_flux + fbase;
-    double wm[5], wp[5], wn[5];   // windows: rho*u_n product, pressure, u_n; cells c-2..c+2
-    int c = cstart;
+    double wm[5], wp[5], wn[5];   // windows: rho*u_n product, pressure, u_n
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      long long o = cell_off(c - 2 + s);
-      wn[s] = pn[o];
-      wm[s] = mul_rn(pr[o], wn[s]);
-      wp[s] = pp[o];
+    for (int s = 0; s < 5; s++) {                          // cells f0-3..f0+1: the window of cell f0-1
+      const long long o = cell_off(f0 - 3 + s);
+      wn[s] = uni(pn + o)[eu];
+      wm[s] = mul_rn(uni(pr + o)[eu], wn[s]);
+      wp[s] = uni(pp + o)[eu];
     }
-    double prevR_m = 0.0, prevR_p = 0.0, prevR_n = 0.0;
-    for (; c < fend; c++) {
-      long long on = cell_off(c + 3);                    // the next cell entering the window
-      double nn = pn[on], nm = mul_rn(pr[on], nn), np_ = pp[on];
+    double prevR_m, prevR_p, prevR_n;
+    {                                                      // cell f0-1: only its right-edge values are needed (face f0)
+      double Lm, Lp, Ln;
+      weno(wm, f0 - 1, Lm, prevR_m);
+      weno(wp, f0 - 1, Lp, prevR_p);
+      weno(wn, f0 - 1, Ln, prevR_n);
+      const long long on = cell_off(f0 + 2);
+      const double nn = uni(pn + on)[eu];
+#pragma unroll
+      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
+      wn[4] = nn; wm[4] = mul_rn(uni(pr + on)[eu], nn); wp[4] = uni(pp + on)[eu];
+    }
+#pragma clang loop unroll(disable)
+    for (int c = f0; c < fend; c++) {                      // window = cells c-2..c+2; face c lies between cells c-1 and c
+      const long long on = cell_off(c + 3);                // the next cell entering the window
+      const double nn = uni(pn + on)[eu], nm = mul_rn(uni(pr + on)[eu], nn), np_ = uni(pp + on)[eu];
       double Lm, Rm, Lp, Rp, Ln, Rn;
-      if (DIR == 2) {
-        weno5_table(wm, vtab(c), vts, wc, Lm, Rm);
-        weno5_table(wp, vtab(c), vts, wc, Lp, Rp);
-        weno5_table(wn, vtab(c), vts, wc, Ln, Rn);
-      } else {
-        weno5_const(wm, wc, Lm, Rm);
-        weno5_const(wp, wc, Lp, Rp);
-        weno5_const(wn, wc, Ln, Rn);
-      }
-      if (c >= f0) {  // face c lies between cells c-1 (left state = its right edge) and c (right state = left edge)
-        const bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
-        double ruf, ppf;
-        acoustic_face(prevR_m, Lm, prevR_p, Lp, wall, ruf, ppf);
-        fl0[(long long)c * g.cs] = ruf;                       // flux field 0
-#ifndef PAMA_RUF_GLOBAL
-        ruf_slot[(c - f0) * nthr] = ruf;
-#endif
-        const double val = (ruf > 0.0) ? prevR_n : Ln;        // upwind (Dycore.h:368)
-        fln[(long long)c * g.cs] = fma(ruf, val, ppf);
-      }
+      weno(wm, c, Lm, Rm);
+      weno(wp, c, Lp, Rp);
+      weno(wn, c, Ln, Rn);
+      const bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
+      double ruf, ppf;
+      acoustic_face(prevR_m, Lm, prevR_p, Lp, wall, ruf, ppf);
+      uniw(fl0 + (long long)c * g.cs)[eu] = ruf;                 // flux field 0
+      const double val = (ruf > 0.0) ? prevR_n : Ln;            // upwind (Dycore.h:368)
+      uniw(fln + (long long)c * g.cs)[eu] = fma(ruf, val, ppf);
       prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
 #pragma unroll
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
@@ -528,7 +579,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     }
   }
   // ---------------- the other advected quantities (Dycore.h:367-385), FLUX_NF fields per sweep ------------------
-  // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with two
+  // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with few
   // wavefronts per SIMD a single chain per iteration leaves issue slots empty, several independent chains fill them.
   auto sweep = [&](auto nf_tag, const int *fa) {
     constexpr int NF = decltype(nf_tag)::value;
@@ -539,39 +590,37 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     for (int n = 0; n < NF; n++) {
       q[n] = prim + (long long)(P_U + fa[n]) * P.prim_fs;
       fl[n] = flux + (long long)(1 + fa[n]) * g.fs_flux + fbase;
-      prevR[n] = 0.0;
     }
-    const double *flux0 = flux + fbase;   // mass flux of this line (field 0), written by pass 1 of this thread
-    (void)flux0;
-    int c = cstart;
 #pragma unroll
     for (int s = 0; s < 5; s++) {
-      const long long o = cell_off(c - 2 + s);
+      const long long o = cell_off(f0 - 3 + s);
 #pragma unroll
-      for (int n = 0; n < NF; n++) w[n][s] = q[n][o];
+      for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
     }
-    for (; c < fend; c++) {
+    {
+      const long long on = cell_off(f0 + 2);
+#pragma unroll
+      for (int n = 0; n < NF; n++) {
+        double L;
+        weno(w[n], f0 - 1, L, prevR[n]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+        w[n][4] = uni(q[n] + on)[eu];
+      }
+    }
+#pragma clang loop unroll(disable)
+    for (int c = f0; c < fend; c++) {
       const long long on = cell_off(c + 3);
       double nq[NF], L[NF], R[NF];
 #pragma unroll
-      for (int n = 0; n < NF; n++) nq[n] = q[n][on];
+      for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
+      const double ruf = uni(fl0 + (long long)c * g.cs)[eu];  // this lane's own store of pass 1
+#pragma unroll
+      for (int n = 0; n < NF; n++) weno(w[n], c, L[n], R[n]);
+      const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
 #pragma unroll
       for (int n = 0; n < NF; n++) {
-        if (DIR == 2) weno5_table(w[n], vtab(c), vts, wc, L[n], R[n]);
-        else weno5_const(w[n], wc, L[n], R[n]);
-      }
-      if (c >= f0) {
-#ifdef PAMA_RUF_GLOBAL
-        const double ruf = flux0[(long long)c * g.cs];
-#else
-        const double ruf = ruf_slot[(c - f0) * nthr];
-#endif
-        const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
-#pragma unroll
-        for (int n = 0; n < NF; n++) fl[n][(long long)c * g.cs] = mul_rn(ruf, up ? prevR[n] : L[n]);
-      }
-#pragma unroll
-      for (int n = 0; n < NF; n++) {
+        uniw(fl[n] + (long long)c * g.cs)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
         prevR[n] = R[n];
 #pragma unroll
         for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
@@ -903,222 +952,232 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 // FUSED x-sweep: reconstruction + fluxes in x (as flux_line_body<0>) AND, in the same pass, the stage update of the five
 // state variables of every cell of the line (as update_body), with the y and z face fluxes read from the flux arrays the
 // y/z sweeps wrote earlier.  Reference: Dycore.h:334-386 (x fluxes), :553-571 (divergence, gravity), :162-221 (SSPRK3
-// combine), next stage's :310-321 (pressure, divide by rho) and :662-710 (vertical ghosts).
+// combine), next stage's :310-321 (divide by rho) and :662-710 (vertical ghosts of the advected variables).
 //
 // Why: in the three-kernel stage every x face flux of the state makes a round trip through HBM (written by the flux
 // kernel, read back by the update kernel) and the update kernel re-reads the stage input the x-sweep has just had in
-// registers.  Here a thread owns a whole periodic x line of one member: when faces c-1 and c of a variable are known,
-// cell c-1 is complete -- its x flux difference never leaves the registers, its stage-input value is the window element
-// the polynomial was built from, and only the y/z flux differences and the sub-step-start value are loaded.  The x
-// fluxes of the state are never stored; tracer x fluxes still are (the FCT limiter needs all six faces of a cell before
-// any tracer update: fct_mult_body, then tracer_update_body).
+// registers.  Here a wavefront owns a whole periodic x line (k, j) of 64 members: when faces c-1 and c of a variable are
+// known, cell c-1 is complete -- its x flux difference never leaves the registers, its stage-input value is the window
+// element the polynomial was built from, and only the y/z flux differences and the sub-step-start value are loaded.  The
+// x fluxes of the state are never stored (except the mass flux, the thread's own scratch for the later passes); tracer x
+// fluxes still are (the FCT limiter needs all six faces of a cell before any tracer update: fct_mult_body, then
+// tracer_update_body).
 //
 // Passes over the line (5-cell sliding windows, one polynomial per cell, as flux_line_body):
-//   pass 1   rho*u, p, u: face mass flux ruf (kept in the thread's LDS slots for the later passes) and face pressure;
-//            finishes rho and rho*u of each cell: new density -> prim_out[P_RHO], its reciprocal is parked in
-//            prim_out[P_PRES] (this thread's own cells; overwritten by the pressure in the theta pass)
-//   pass 2.. FLUX_NF advected fields at a time (v, w, theta, tracers): state variables are finished per cell and written
-//            density-divided to prim_out (+ vertical ghosts when k is a boundary level); theta -- always the last state
-//            variable of the sweep order -- leaves the new rho*theta in prim_out[P_PRES] for the pointwise kernel that
-//            follows (tracer_update_body: next stage's pressure and density/pressure ghosts); tracers only store their x flux.
-// The loads a cell's completion needs (y/z faces, sub-step-start values, densities) are issued one iteration ahead.
+//   state    rho*u, p, u, v, w, theta together (six independent polynomial chains per cell): face mass flux ruf and face
+//            pressure, the x fluxes of all five state variables, and the complete update of every cell: new density, u, v, w,
+//            theta density-divided to prim_out (+ vertical ghosts when k is a boundary level); the new rho*theta goes to
+//            prim_out[P_PRES] for the pointwise kernel that follows (tracer_update_body: next stage's pressure and
+//            density/pressure ghosts).  ruf is also written to flux_x field 0 for the tracer sweeps (the lane's own line,
+//            L2-resident; no LDS, so residency is bounded by registers only).  Each input is read exactly once.
+//   tracers  FLUX_NF at a time, upwinded by the ruf read back: only their x flux is stored.
 // prim_in, prim0 and prim_out must be three different buffers: the line is periodic (cells 0..2 are read again at the
 // end of the sweep) and later passes re-read the stage-input density, so nothing may be updated in place.
 // Bit-for-bit the arithmetic of flux_line_body<0> + update_body (shared helpers above; tests/test_fused_stage.py).
+//   line   wave-uniform index of the x line: k * ny + j          e   ensemble member of this lane
 template <int STAGE>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, long long item, double dt_dyn, double *lds, int nthr,
-                               int tid) {
+                               const double *__restrict__ fz, int line, int e, double dt_dyn) {
+  const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
   const int nx = P.nx;
-  const int e = (int)(item % P.nens);
-  const long long line = item / P.nens;
-  const int k = (int)(line / P.ny), j = (int)(line % P.ny);
-  const long long c2_0 = (long long)j * P.sy + e;                      // (j, i=0, e) inside a level
-  const long long pbase = (long long)(k + HS) * P.sz + c2_0;           // cell i=0 inside a prim field
-  const long long fbase = (long long)k * P.sz + c2_0;                  // cell / face i=0 inside an interior-sized field
+  const int k = uni_int(line / P.ny), j = line - k * P.ny;   // (integer division runs on the vector unit: re-assert uniformity)
+  const long long cu0 = (long long)j * P.sy;                          // (j, i=0, member 0) inside a level
+  const long long pbase = (long long)(k + HS) * P.sz + cu0;            // cell i=0 inside a prim field (uniform)
+  const long long fbase = (long long)k * P.sz + cu0;                   // cell / face i=0 inside an interior-sized field
   const long long jp1 = (j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy;   // offset of the (j+1) neighbour
   const long long ke = (long long)k * P.nens + e;
   const double rdzk = fast_rcp(P.dz[ke]);
   const bool have_y = !P.sim2d;
-  double *ruf_slot = lds + tid;
-  auto cell_off = [&](int c) -> long long { return pbase + (long long)wrap(c, nx) * P.sx; };
+  double *ruf_line = fx + fbase;                                       // flux_x field 0 of this line: the mass flux
+  // periodic wrap of c in [-3, nx+2] without a division (nx >= 3): stays on the scalar unit
+  auto cell_off = [&](int c) -> long long { return pbase + (long long)(c < 0 ? c + nx : (c >= nx ? c - nx : c)) * P.sx; };
 
-  // ---------------- pass 1: acoustic pair, mass and x-momentum (Dycore.h:341-366,:368-385) + their update -------------
+  // ---------------- state pass: rho*u, p, u, v, w, theta in ONE sweep + the update of all five state variables --------
+  // (Dycore.h:341-386; :553-571; :162-221).  Six windows, six independent polynomial chains per cell; the stage-input
+  // density, the sub-step-start values and the y/z face fluxes of a cell are loaded once, at the top of the iteration
+  // that completes the cell, and are consumed ~700 vector instructions later.
   {
+    constexpr int NQ = 4;                                  // advected state variables: u (the normal velocity), v, w, theta
     const double *pr = prim_in + (long long)P_RHO * P.prim_fs;
-    const double *pn = prim_in + (long long)P_U * P.prim_fs;
     const double *pp = prim_in + (long long)P_PRES * P.prim_fs;
-    const double *r0 = prim0 + (long long)P_RHO * P.prim_fs, *u0 = prim0 + (long long)P_U * P.prim_fs;
-    double *out_rho = prim_out + (long long)P_RHO * P.prim_fs, *out_rr = prim_out + (long long)P_PRES * P.prim_fs;
-    const double *fy0 = fy, *fy1 = fy + P.ncell, *fz0 = fz, *fz1 = fz + P.fz_fs;
-    double wm[5], wp[5], wn[5];
-    int c = -1;
+    const double *r0 = prim0 + (long long)P_RHO * P.prim_fs;
+    double *out_rho = prim_out + (long long)P_RHO * P.prim_fs, *out_rt = prim_out + (long long)P_PRES * P.prim_fs;
+    double wm[5], wp[5], wq[NQ][5];
+    auto load_cell = [&](long long o, double &m, double &p, double (&qv)[NQ]) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      const long long o = cell_off(c - 2 + s);
-      wn[s] = pn[o];
-      wm[s] = mul_rn(pr[o], wn[s]);
-      wp[s] = pp[o];
-    }
-    double prevR_m = 0.0, prevR_p = 0.0, prevR_n = 0.0;
-    double F0_prev = 0.0, F1_prev = 0.0, F0_first = 0.0, F1_first = 0.0;
-    // pending loads of the cell that completes in the next iteration
-    double p_rho_in = 0.0, p_rho_0 = 0.0, p_u_0 = 0.0, p_y0l = 0.0, p_y0h = 0.0, p_y1l = 0.0, p_y1h = 0.0, p_z0l = 0.0,
-           p_z0h = 0.0, p_z1l = 0.0, p_z1h = 0.0;
-    auto finish = [&](int cc, double F0lo, double F0hi, double F1lo, double F1hi, double m_in_u) {
-      const long long o = pbase + (long long)cc * P.sx;
-      const double q0 = rk_combine<STAGE>(p_rho_0, p_rho_in, dt_dyn,
-                                          flux_divergence(P, F0lo, F0hi, p_y0l, p_y0h, p_z0l, p_z0h, rdzk));
-      const double rrho = fast_rcp(q0);
-      out_rho[o] = q0;
-      out_rr[o] = rrho;
-      const double m_0 = (STAGE > 1) ? mul_rn(p_u_0, p_rho_0) : 0.0;
-      const double q1 = rk_combine<STAGE>(m_0, m_in_u, dt_dyn,
-                                          flux_divergence(P, F1lo, F1hi, p_y1l, p_y1h, p_z1l, p_z1h, rdzk));
-      store_adv(P, prim_out, P_U, k, c2_0 + (long long)cc * P.sx, q1 * rrho, q1 * rrho);
+      for (int n = 0; n < NQ; n++) qv[n] = uni(prim_in + (long long)(P_U + n) * P.prim_fs + o)[eu];
+      m = mul_rn(uni(pr + o)[eu], qv[0]);
+      p = uni(pp + o)[eu];
     };
-    for (; c < nx; c++) {
-      const long long on = cell_off(c + 3);
-      const double nn = pn[on], nm = mul_rn(pr[on], nn), np_ = pp[on];
-      // loads for cell c (completed in iteration c+1, or after the loop for the last cell)
-      double n_rho_in = 0.0, n_rho_0 = 0.0, n_u_0 = 0.0, n_y0l = 0.0, n_y0h = 0.0, n_y1l = 0.0, n_y1h = 0.0, n_z0l = 0.0,
-             n_z0h = 0.0, n_z1l = 0.0, n_z1h = 0.0;
-      if (c >= 0) {
-        const long long o = pbase + (long long)c * P.sx, ix = fbase + (long long)c * P.sx;
-        n_rho_in = pr[o];
-        if (STAGE > 1) { n_rho_0 = r0[o]; n_u_0 = u0[o]; }
-        if (have_y) { n_y0l = fy0[ix]; n_y0h = fy0[ix + jp1]; n_y1l = fy1[ix]; n_y1h = fy1[ix + jp1]; }
-        n_z0l = fz0[ix]; n_z0h = fz0[ix + P.sz]; n_z1l = fz1[ix]; n_z1h = fz1[ix + P.sz];
+#pragma unroll
+    for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
+      double qv[NQ];
+      load_cell(cell_off(s - 3), wm[s], wp[s], qv);
+#pragma unroll
+      for (int n = 0; n < NQ; n++) wq[n][s] = qv[n];
+    }
+    double prevR_m, prevR_p, prevR_q[NQ];
+    {                                                      // cell -1: only its right-edge values are needed (face 0)
+      double L;
+      weno5_const(wm, wc, L, prevR_m);
+      weno5_const(wp, wc, L, prevR_p);
+#pragma unroll
+      for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, L, prevR_q[n]);
+      double nm, np_, nq[NQ];
+      load_cell(cell_off(2), nm, np_, nq);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        wm[s] = wm[s + 1]; wp[s] = wp[s + 1];
+#pragma unroll
+        for (int n = 0; n < NQ; n++) wq[n][s] = wq[n][s + 1];
       }
-      double Lm, Rm, Lp, Rp, Ln, Rn;
+      wm[4] = nm; wp[4] = np_;
+#pragma unroll
+      for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
+    }
+    double F_prev[1 + NQ], F_first[1 + NQ];                // face fluxes of rho, rho u, rho v, rho w, rho theta
+#pragma unroll
+    for (int l = 0; l <= NQ; l++) { F_prev[l] = 0.0; F_first[l] = 0.0; }
+    // everything cell cc needs besides its x fluxes
+    struct CellIn { double rho_in, rho_0, q0[NQ], yl[1 + NQ], yh[1 + NQ], zl[1 + NQ], zh[1 + NQ]; };
+    auto load_in = [&](int cc, CellIn &ci) {
+      const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
+      ci.rho_in = uni(pr + o)[eu];
+      ci.rho_0 = (STAGE > 1) ? uni(r0 + o)[eu] : 0.0;
+#pragma unroll
+      for (int n = 0; n < NQ; n++) ci.q0[n] = (STAGE > 1) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs + o)[eu] : 0.0;
+#pragma unroll
+      for (int l = 0; l <= NQ; l++) {
+        ci.yl[l] = 0.0; ci.yh[l] = 0.0;
+        if (have_y) { ci.yl[l] = uni(fy + (long long)l * P.ncell + ix)[eu]; ci.yh[l] = uni(fy + (long long)l * P.ncell + ix + jp1)[eu]; }
+        ci.zl[l] = uni(fz + (long long)l * P.fz_fs + ix)[eu];
+        ci.zh[l] = uni(fz + (long long)l * P.fz_fs + ix + P.sz)[eu];
+      }
+    };
+    // finish cell cc: F_lo/F_hi = its two x faces; m_in_u = rho*u of the stage input (the product window), q_in = v, w, theta
+    auto finish = [&](int cc, const CellIn &ci, const double (&Flo)[1 + NQ], const double (&Fhi)[1 + NQ], double m_in_u,
+                      double v_in, double w_in, double th_in) {
+      const long long o = pbase + (long long)cc * P.sx;
+      const double q0 = rk_combine<STAGE>(ci.rho_0, ci.rho_in, dt_dyn,
+                                          flux_divergence(P, Flo[0], Fhi[0], ci.yl[0], ci.yh[0], ci.zl[0], ci.zh[0], rdzk));
+      const double rrho = fast_rcp(q0);
+      uniw(out_rho + o)[eu] = q0;
+      const double q_in[NQ] = {0.0, v_in, w_in, th_in};
+#pragma unroll
+      for (int n = 0; n < NQ; n++) {
+        const int l = 1 + n;                               // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
+        double tend = flux_divergence(P, Flo[l], Fhi[l], ci.yl[l], ci.yh[l], ci.zl[l], ci.zh[l], rdzk);
+        if (l == 3) tend = add_gravity(P, tend, ci.rho_in, ke);
+        if (l == 2 && P.sim2d) tend = 0.0;
+        const double m_in = (n == 0) ? m_in_u : mul_rn(q_in[n], ci.rho_in);
+        const double m_0 = (STAGE > 1) ? mul_rn(ci.q0[n], ci.rho_0) : 0.0;
+        const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+        store_adv_u(P, prim_out, P_U + n, k, cu0 + (long long)cc * P.sx, eu, v * rrho, (l == 3) ? 0.0 : v * rrho);
+        // the new rho*theta goes where the pressure belongs: tracer_update_body turns it into the next stage's pressure
+        // (a pow per cell, kept out of this register-critical loop)
+        if (l == 4) uniw(out_rt + o)[eu] = v;
+      }
+    };
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
+      double nm, np_, nq[NQ];
+      load_cell(cell_off(c + 3), nm, np_, nq);
+      CellIn ci;
+      if (c > 0) load_in(c - 1, ci);                       // consumed at the bottom of this iteration
+      double Lm, Rm, Lp, Rp, Lq[NQ], Rq[NQ];
       weno5_const(wm, wc, Lm, Rm);
       weno5_const(wp, wc, Lp, Rp);
-      weno5_const(wn, wc, Ln, Rn);
-      if (c >= 0) {
-        double ruf, ppf;
-        acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
-        ruf_slot[c * nthr] = ruf;
-        const double val = (ruf > 0.0) ? prevR_n : Ln;        // upwind (Dycore.h:368)
-        const double f = fma(ruf, val, ppf);
-        if (c == 0) { F0_first = ruf; F1_first = f; }
-        else finish(c - 1, F0_prev, ruf, F1_prev, f, wm[1]);  // window = cells c-2..c+2: element 1 is cell c-1
-        F0_prev = ruf; F1_prev = f;
-      }
-      p_rho_in = n_rho_in; p_rho_0 = n_rho_0; p_u_0 = n_u_0; p_y0l = n_y0l; p_y0h = n_y0h; p_y1l = n_y1l; p_y1h = n_y1h;
-      p_z0l = n_z0l; p_z0h = n_z0h; p_z1l = n_z1l; p_z1h = n_z1h;
-      prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
 #pragma unroll
-      for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
-      wm[4] = nm; wp[4] = np_; wn[4] = nn;
+      for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, Lq[n], Rq[n]);
+      double ruf, ppf, F[1 + NQ];
+      acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
+      uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;      // for the tracer sweeps
+      const bool up = ruf > 0.0;                             // upwind (Dycore.h:368)
+      F[0] = ruf;
+      F[1] = fma(ruf, up ? prevR_q[0] : Lq[0], ppf);
+#pragma unroll
+      for (int n = 1; n < NQ; n++) F[1 + n] = mul_rn(ruf, up ? prevR_q[n] : Lq[n]);
+      if (c == 0) {
+#pragma unroll
+        for (int l = 0; l <= NQ; l++) F_first[l] = F[l];
+      } else {
+        finish(c - 1, ci, F_prev, F, wm[1], wq[1][1], wq[2][1], wq[3][1]);   // window element 1 is cell c-1
+      }
+#pragma unroll
+      for (int l = 0; l <= NQ; l++) F_prev[l] = F[l];
+      prevR_m = Rm; prevR_p = Rp;
+#pragma unroll
+      for (int n = 0; n < NQ; n++) prevR_q[n] = Rq[n];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        wm[s] = wm[s + 1]; wp[s] = wp[s + 1];
+#pragma unroll
+        for (int n = 0; n < NQ; n++) wq[n][s] = wq[n][s + 1];
+      }
+      wm[4] = nm; wp[4] = np_;
+#pragma unroll
+      for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
-    // the periodic face nx is face 0; the window now holds cells nx-2..nx+2, element 1 is cell nx-1
-    finish(nx - 1, F0_prev, F0_first, F1_prev, F1_first, wm[1]);
+    {   // the periodic face nx is face 0; the window now holds cells nx-2..nx+2, element 1 is cell nx-1
+      CellIn ci;
+      load_in(nx - 1, ci);
+      finish(nx - 1, ci, F_prev, F_first, wm[1], wq[1][1], wq[2][1], wq[3][1]);
+    }
   }
 
-  // ---------------- the other advected quantities, FLUX_NF per sweep; state variables are finished per cell -----------
+  // ---------------- tracers: FLUX_NF per sweep, x flux stored (Dycore.h:367-385) ---------------------------------------
   auto sweep = [&](auto nf_tag, const int *fa) {
     constexpr int NF = decltype(nf_tag)::value;
-    const double *q[NF], *q0p[NF], *fyl[NF], *fzl[NF];
+    const double *q[NF];
     double *fl[NF];
-    bool st[NF];                                  // state variable (finished here) or tracer (x flux stored)
-    int pfld[NF];
-    double w[NF][5], prevR[NF], Fprev[NF], Ffirst[NF];
+    double w[NF][5], prevR[NF];
 #pragma unroll
     for (int n = 0; n < NF; n++) {
-      pfld[n] = P_U + fa[n];
-      st[n] = fa[n] < 4;
-      q[n] = prim_in + (long long)pfld[n] * P.prim_fs;
-      q0p[n] = prim0 + (long long)pfld[n] * P.prim_fs;
+      q[n] = prim_in + (long long)(P_U + fa[n]) * P.prim_fs;
       fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
-      fyl[n] = fy + (long long)(1 + fa[n]) * P.ncell;
-      fzl[n] = fz + (long long)(1 + fa[n]) * P.fz_fs;
-      prevR[n] = 0.0; Fprev[n] = 0.0; Ffirst[n] = 0.0;
     }
-    const double *pr = prim_in + (long long)P_RHO * P.prim_fs, *r0 = prim0 + (long long)P_RHO * P.prim_fs;
-    double *out_rr = prim_out + (long long)P_PRES * P.prim_fs;
-    double p_rho_in = 0.0, p_rho_0 = 0.0, p_rr = 0.0, p_q0[NF], p_yl[NF], p_yh[NF], p_zl[NF], p_zh[NF];
 #pragma unroll
-    for (int n = 0; n < NF; n++) { p_q0[n] = 0.0; p_yl[n] = 0.0; p_yh[n] = 0.0; p_zl[n] = 0.0; p_zh[n] = 0.0; }
-    auto finish = [&](int n, int cc, double Flo, double Fhi, double q_in) {
-      const long long c2 = c2_0 + (long long)cc * P.sx;
-      const int l = 1 + fa[n];                                 // 2 rho v, 3 rho w, 4 rho theta
-      double tend = flux_divergence(P, Flo, Fhi, p_yl[n], p_yh[n], p_zl[n], p_zh[n], rdzk);
-      if (l == 3) tend = add_gravity(P, tend, p_rho_in, ke);
-      if (l == 2 && P.sim2d) tend = 0.0;
-      const double m_in = mul_rn(q_in, p_rho_in);
-      const double m_0 = (STAGE > 1) ? mul_rn(p_q0[n], p_rho_0) : 0.0;
-      const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
-      store_adv(P, prim_out, pfld[n], k, c2, v * p_rr, (l == 3) ? 0.0 : v * p_rr);
-      // theta: the conserved rho*theta replaces the parked reciprocal density; pressure_body turns it into the next
-      // stage's pressure (a pow per cell, kept out of this register-critical loop)
-      if (l == 4) out_rr[pbase + (long long)cc * P.sx] = v;
-    };
-    int c = -1;
+    for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
+      const long long o = cell_off(s - 3);
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      const long long o = cell_off(c - 2 + s);
-#pragma unroll
-      for (int n = 0; n < NF; n++) w[n][s] = q[n][o];
+      for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
     }
-    for (; c < nx; c++) {
+    {                                                      // cell -1: only its right-edge value is needed (face 0)
+      const long long on = cell_off(2);
+#pragma unroll
+      for (int n = 0; n < NF; n++) {
+        double L;
+        weno5_const(w[n], wc, L, prevR[n]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+        w[n][4] = uni(q[n] + on)[eu];
+      }
+    }
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
       const long long on = cell_off(c + 3);
       double nq[NF], L[NF], R[NF];
 #pragma unroll
-      for (int n = 0; n < NF; n++) nq[n] = q[n][on];
-      double n_rho_in = 0.0, n_rho_0 = 0.0, n_rr = 0.0, n_q0[NF], n_yl[NF], n_yh[NF], n_zl[NF], n_zh[NF];
-#pragma unroll
-      for (int n = 0; n < NF; n++) { n_q0[n] = 0.0; n_yl[n] = 0.0; n_yh[n] = 0.0; n_zl[n] = 0.0; n_zh[n] = 0.0; }
-      if (c >= 0) {
-        const long long o = pbase + (long long)c * P.sx, ix = fbase + (long long)c * P.sx;
-        bool any = false;
-#pragma unroll
-        for (int n = 0; n < NF; n++) {
-          if (!st[n]) continue;
-          any = true;
-          if (STAGE > 1) n_q0[n] = q0p[n][o];
-          if (have_y) { n_yl[n] = fyl[n][ix]; n_yh[n] = fyl[n][ix + jp1]; }
-          n_zl[n] = fzl[n][ix]; n_zh[n] = fzl[n][ix + P.sz];
-        }
-        if (any) {
-          n_rho_in = pr[o];
-          if (STAGE > 1) n_rho_0 = r0[o];
-          n_rr = out_rr[o];
-        }
-      }
+      for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
+      const double ruf = uni(ruf_line + (long long)c * P.sx)[eu];    // this lane's own store of the state pass
 #pragma unroll
       for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
-      if (c >= 0) {
-        const double ruf = ruf_slot[c * nthr];
-        const bool up = ruf > 0.0;                            // upwind (Dycore.h:368)
-#pragma unroll
-        for (int n = 0; n < NF; n++) {
-          const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
-          if (!st[n]) { fl[n][(long long)c * P.sx] = F; continue; }
-          if (c == 0) Ffirst[n] = F;
-          else finish(n, c - 1, Fprev[n], F, w[n][1]);
-          Fprev[n] = F;
-        }
-      }
-      p_rho_in = n_rho_in; p_rho_0 = n_rho_0; p_rr = n_rr;
+      const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
 #pragma unroll
       for (int n = 0; n < NF; n++) {
-        p_q0[n] = n_q0[n]; p_yl[n] = n_yl[n]; p_yh[n] = n_yh[n]; p_zl[n] = n_zl[n]; p_zh[n] = n_zh[n];
+        uniw(fl[n] + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
         prevR[n] = R[n];
 #pragma unroll
         for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
         w[n][4] = nq[n];
       }
     }
-#pragma unroll
-    for (int n = 0; n < NF; n++)
-      if (st[n]) finish(n, nx - 1, Fprev[n], Ffirst[n], w[n][1]);
   };
-  // sweep order: v, w, theta, tracers (theta is the last state variable: it overwrites the parked reciprocal density)
   const int nadv = 4 + P.nt;
   int fa[FLUX_NF], nfa = 0;
-  for (int a = 1; a < nadv; a++) {
+  for (int a = 4; a < nadv; a++) {
     fa[nfa++] = a;
     if (nfa == FLUX_NF) { sweep(std::integral_constant<int, FLUX_NF>{}, fa); nfa = 0; }
   }

@@ -56,19 +56,18 @@ struct FluxGrid {
   int nbx, nby, nbz;        // workgroups per sweep
   int spx, spy, spz;        // faces per thread (span) per sweep
   int nsx, nsy, nsz;        // spans per line
-  long long nux, nuy, nuz;  // work units (wavefronts) per sweep
+  int nux, nuy, nuz;        // work units (wavefronts) per sweep: lines x member blocks x spans
   int nbx_l, nby_l;         // x / y workgroups per vertical level when the two sweeps are interleaved level by level (else 0)
 };
 
 template <bool VZ_PER_ENS>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
+__global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
                                                                   const double *__restrict__ prim,
                                                                   double *__restrict__ fx, double *__restrict__ fy,
                                                                   double *__restrict__ fz) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nblk = (R.ne + 63) >> 6;          // blocks of 64 members per line
   // Dispatch order: the z-sweep workgroups first, then the x/y sweeps.
   int b = (int)blockIdx.x - G.nbz;
   if (b < 0) b += G.nbx + G.nby + G.nbz;      // blockIdx < nbz  ->  logical index in [nbx+nby, nbx+nby+nbz)
@@ -79,24 +78,25 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_kernel(Params P, FluxG
     const int lev = b / per, r = b % per;
     b = (r < G.nbx_l) ? lev * G.nbx_l + r : G.nbx + lev * G.nby_l + (r - G.nbx_l);
   }
+  // wave unit u of a sweep -> (group = u / nspan, span = u % nspan), group -> (line = group / nblk, member block)
   if (b < G.nbx) {
-    const long long u = (long long)b * FLUX_WAVES + wave;
-    const long long item = (u / G.nsx) * 64 + lane;
-    if (u < G.nux && item < (long long)P.nz * P.ny * R.ne)
-      flux_line_body<0, VZ_PER_ENS>(P, prim, fx, to_global(item, P.nens, R), (int)(u % G.nsx) * G.spx, G.spx, lds,
-                                    FLUX_THREADS, tid);
+    const int u = b * FLUX_WAVES + wave;
+    if (u < G.nux) {
+      const int grp = uni_int(u / G.nsx), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      if (el < R.ne) flux_line_body<0, VZ_PER_ENS>(P, prim, fx, line, R.e0 + el, (u - grp * G.nsx) * G.spx, G.spx);
+    }
   } else if (b < G.nbx + G.nby) {
-    const long long u = (long long)(b - G.nbx) * FLUX_WAVES + wave;
-    const long long item = (u / G.nsy) * 64 + lane;
-    if (u < G.nuy && item < (long long)P.nz * P.nx * R.ne)
-      flux_line_body<1, VZ_PER_ENS>(P, prim, fy, to_global(item, P.nens, R), (int)(u % G.nsy) * G.spy, G.spy, lds,
-                                    FLUX_THREADS, tid);
+    const int u = (b - G.nbx) * FLUX_WAVES + wave;
+    if (u < G.nuy) {
+      const int grp = uni_int(u / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      if (el < R.ne) flux_line_body<1, VZ_PER_ENS>(P, prim, fy, line, R.e0 + el, (u - grp * G.nsy) * G.spy, G.spy);
+    }
   } else {
-    const long long u = (long long)(b - G.nbx - G.nby) * FLUX_WAVES + wave;
-    const long long item = (u / G.nsz) * 64 + lane;
-    if (u < G.nuz && item < (long long)P.ny * P.nx * R.ne)
-      flux_line_body<2, VZ_PER_ENS>(P, prim, fz, to_global(item, P.nens, R), (int)(u % G.nsz) * G.spz, G.spz, lds,
-                                    FLUX_THREADS, tid);
+    const int u = (b - G.nbx - G.nby) * FLUX_WAVES + wave;
+    if (u < G.nuz) {
+      const int grp = uni_int(u / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      if (el < R.ne) flux_line_body<2, VZ_PER_ENS>(P, prim, fz, line, R.e0 + el, (u - grp * G.nsz) * G.spz, G.spz);
+    }
   }
 }
 
@@ -116,19 +116,20 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
   CellId c;
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
-// Fused x-sweep + state update (flux_x_update_body): every wavefront owns 64 consecutive (x line, member) items.
+// Fused x-sweep + state update (flux_x_update_body): wave unit u -> (x line = u / nblk, member block = u % nblk); the 64
+// lanes are 64 consecutive members of ONE line, so every address is a wave-uniform base + member (scalar addressing).
 template <int STAGE>
 __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                                  const double *__restrict__ prim0,
-                                                                  double *__restrict__ prim_out, double *__restrict__ fx,
-                                                                  const double *__restrict__ fy,
-                                                                  const double *__restrict__ fz, double dt_dyn) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x;
-  const long long item = (long long)blockIdx.x * FLUX_THREADS + tid;     // wave w of the block: items 64 w .. 64 w + 63
-  if (item < (long long)P.nz * P.ny * R.ne)
-    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, to_global(item, P.nens, R), dt_dyn, lds, FLUX_THREADS,
-                              tid);
+                                                                     const double *__restrict__ prim0,
+                                                                     double *__restrict__ prim_out, double *__restrict__ fx,
+                                                                     const double *__restrict__ fy,
+                                                                     const double *__restrict__ fz, double dt_dyn) {
+  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
+  const int nblk = (R.ne + 63) >> 6;
+  const int line = uni_int(u / nblk), blk = u - line * nblk;   // (the division runs on the vector unit)
+  const int el = blk * 64 + (int)(threadIdx.x & 63);
+  if (line < P.nz * P.ny && el < R.ne)
+    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, dt_dyn);
 }
 // Tracer-only update after the fused x-sweep and the FCT multiplier (tracer_update_body).
 template <int STAGE>
@@ -282,6 +283,7 @@ struct pam_amd_awfl {
   bool interleave_xy = true;
   bool fused = false;          // fused x-sweep + state update (needs prim2 and nx LDS slots per thread)
   bool fused_supported = false;
+  size_t xupd_lds_bytes = 0;   // dynamic LDS requested by the fused x-sweep: it uses none; a residency cap for tuning
   size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
@@ -370,13 +372,12 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
   return PAM_AMD_OK;
 }
 
-// Span (faces per thread) of one sweep: the longest piece of the line that fits the thread's LDS slots
-// (FLUX_MAX_SPAN faces: a whole 32-cell line, half of a 61-face column) if that still leaves enough wavefronts to fill
-// the chip (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail); otherwise the line is cut further, down to
-// `min_span` faces per thread (each span re-reads a 5-cell overlap and rebuilds one polynomial).  `span_override` > 0
-// forces a value (tests / tuning).
-static void choose_span(int nfaces, long long nitems, int min_span, int span_override, int &span, int &nspan, long long &nunits) {
-  const long long nib = (nitems + 63) / 64;
+// Span (faces swept by one wavefront) of one sweep: the whole line (up to FLUX_MAX_SPAN faces) if that still leaves enough
+// wavefronts to fill the chip (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail); otherwise the line is cut,
+// down to `min_span` faces (each span re-reads a 5-cell overlap and rebuilds one polynomial).  nlines x ceil(nens/64)
+// wavefronts sweep one span each.  `span_override` > 0 forces a value (tests / tuning).
+static void choose_span(int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
+  const long long nib = nlines * ((nens + 63) / 64);
   const long long want_units = 6144;
   if (span_override > 0) {
     span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
@@ -387,7 +388,6 @@ static void choose_span(int nfaces, long long nitems, int min_span, int span_ove
   }
   if (span < 1) span = 1;
   nspan = (nfaces + span - 1) / span;
-  nunits = nib * nspan;
 }
 
 // sweeps: bit 0 x, bit 1 y, bit 2 z (the fused stage runs y and z here and x in awfl_xupd_kernel)
@@ -395,29 +395,26 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   const Params &P = h->P;
   FluxGrid G;
   // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
-  choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, G.spx, G.nsx, G.nux);
-  choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, G.spy, G.nsy, G.nuy);
-  choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, G.spz, G.nsz, G.nuz);
-  G.nux = (sweeps & 1) ? (((long long)P.nz * P.ny * r.ne + 63) / 64) * G.nsx : 0;
-  G.nuy = (P.sim2d || !(sweeps & 2)) ? 0 : (((long long)P.nz * P.nx * r.ne + 63) / 64) * G.nsy;
-  G.nuz = (sweeps & 4) ? (((long long)P.ny * P.nx * r.ne + 63) / 64) * G.nsz : 0;
-  G.nbx = (int)((G.nux + FLUX_WAVES - 1) / FLUX_WAVES); G.nby = (int)((G.nuy + FLUX_WAVES - 1) / FLUX_WAVES);
-  G.nbz = (int)((G.nuz + FLUX_WAVES - 1) / FLUX_WAVES);
+  choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, G.spx, G.nsx);
+  choose_span(P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, G.spy, G.nsy);
+  choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, G.spz, G.nsz);
+  const long long nblk = (r.ne + 63) / 64;     // a wavefront = 64 consecutive members of ONE line
+  const long long ux = (sweeps & 1) ? (long long)P.nz * P.ny * nblk * G.nsx : 0;
+  const long long uy = (P.sim2d || !(sweeps & 2)) ? 0 : (long long)P.nz * P.nx * nblk * G.nsy;
+  const long long uz = (sweeps & 4) ? (long long)P.ny * P.nx * nblk * G.nsz : 0;
+  if (ux + uy + uz > 0x7fffffffll / 2) return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
+  G.nux = (int)ux; G.nuy = (int)uy; G.nuz = (int)uz;
+  G.nbx = (G.nux + FLUX_WAVES - 1) / FLUX_WAVES; G.nby = (G.nuy + FLUX_WAVES - 1) / FLUX_WAVES;
+  G.nbz = (G.nuz + FLUX_WAVES - 1) / FLUX_WAVES;
   G.nbx_l = G.nby_l = 0;
-  if (h->interleave_xy && !P.sim2d && G.nux > 0 && G.nuy > 0 && G.nux % ((long long)FLUX_WAVES * P.nz) == 0 && G.nuy % ((long long)FLUX_WAVES * P.nz) == 0) {
+  if (h->interleave_xy && !P.sim2d && G.nux > 0 && G.nuy > 0 && G.nux % (FLUX_WAVES * P.nz) == 0 && G.nuy % (FLUX_WAVES * P.nz) == 0) {
     G.nbx_l = G.nbx / P.nz;
     G.nby_l = G.nby / P.nz;
   }
-  // per-thread LDS: one mass-flux slot per face of the span
-  int spmax = 1;
-  if (G.nux > 0 && G.spx > spmax) spmax = G.spx;
-  if (G.nuy > 0 && G.spy > spmax) spmax = G.spy;
-  if (G.nuz > 0 && G.spz > spmax) spmax = G.spz;
   if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
-  size_t lds_bytes = (size_t)spmax * FLUX_THREADS * sizeof(double);
-#ifdef PAMA_RUF_GLOBAL
-  lds_bytes = 0;
-#endif
+  // the kernel uses no LDS; a dynamic LDS request only caps its residency per CU when other kernels should co-reside
+  size_t lds_bytes = 0;
+  if (h->chunks.size() > 1) lds_bytes = h->flux_lds_floor;
   ScopedTimer st(h, "flux", s);
   if (P.vz_per_ens)
     hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
@@ -451,10 +448,9 @@ template <int STAGE>
 int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
                 hipStream_t s) {
   const Params &P = h->P;
-  const long long nitems = (long long)P.nz * P.ny * r.ne;
-  const size_t lds_bytes = (size_t)P.nx * FLUX_THREADS * sizeof(double);      // one mass-flux slot per face of the line
+  const long long nunits = (long long)P.nz * P.ny * ((r.ne + 63) / 64);     // wavefronts: (x line, block of 64 members)
   ScopedTimer st(h, "xupd", s);
-  hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nitems, FLUX_THREADS)), dim3(FLUX_THREADS), lds_bytes, s, P, r,
+  hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), h->xupd_lds_bytes, s, P, r,
                      prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
@@ -517,11 +513,13 @@ int build_chunks(pam_amd_awfl *h) {
     // ensemble flux launch.  Measured: C2 (W=87k) 1/2/3 chunks -> 1.52/1.65/1.66 G/s; C3 (W=14k) 1.27/1.29/1.16;
     // C4 (W=4k) 0.60/0.57/0.45.
     const Params &P = h->P;
-    int sp, ns;
-    long long ux, uy, uz;
-    choose_span(P.nx, (long long)P.nz * P.ny * P.nens, P.seg, h->span_override, sp, ns, ux);
-    choose_span(P.ny, (long long)P.nz * P.nx * P.nens, P.seg, h->span_override, sp, ns, uy);
-    choose_span(P.nz + 1, (long long)P.ny * P.nx * P.nens, P.seg, h->span_override, sp, ns, uz);
+    int sp, nsx, nsy, nsz;
+    choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, sp, nsx);
+    choose_span(P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, sp, nsy);
+    choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, sp, nsz);
+    const long long nblk = (P.nens + 63) / 64;
+    const long long ux = (long long)P.nz * P.ny * nblk * nsx, uy = (long long)P.nz * P.nx * nblk * nsy;
+    const long long uz = (long long)P.ny * P.nx * nblk * nsz;
     const long long W = ux + (P.sim2d ? 0 : uy) + uz;
     // ~11.8 k wave-units of flux work per chunk (128 members of a 32x32x60 CRM) measured best on MI355X for 256..2048
     // members; smaller jobs run as one chunk
@@ -655,8 +653,8 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->n_seed = (size_t)P.nt * P.ncell;
   INIT_TRY(hipMalloc(&h->prim0, h->n_prim * 8));
   INIT_TRY(hipMalloc(&h->prim1, h->n_prim * 8));
-  // the fused x-sweep keeps a whole x line's face mass fluxes in the thread's LDS slots and writes into a third buffer
-  h->fused_supported = (size_t)P.nx * FLUX_THREADS * sizeof(double) <= 128 * 1024;
+  // the fused x-sweep writes into a third buffer (nothing may be updated in place along a periodic line)
+  h->fused_supported = true;
   h->fused = h->fused_supported;
   if (h->fused_supported) INIT_TRY(hipMalloc(&h->prim2, h->n_prim * 8));
   INIT_TRY(hipMalloc(&h->flux_x, h->n_flux_xy * 8));
@@ -693,7 +691,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
-  h->flux_lds_floor = 64 * 1024;   // with >1 chunk: at most 2 flux workgroups per CU, leaving wave slots for update blocks
+  h->flux_lds_floor = 0;   // no residency cap by default
   if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }
   *out = h;
   return PAM_AMD_OK;
@@ -847,94 +845,110 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     for (auto &c : h->chunks) HIP_TRY(hipStreamWaitEvent(c.stream, h->ev_fork, 0));
   }
-  // Dycore.h:128-134 (per chunk)
-  for (auto &c : h->chunks) {
-    if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
-    if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
-  }
-  // Launches are issued stage by stage, round-robin over the chunks.  With several chunks:
-  //  * flux kernels run on each chunk's high-priority flux stream and are chained ACROSS chunks by events
-  //    (A1 -> B1 -> C1 -> A2 ...): two VALU-bound flux kernels never share the chip;
-  //  * a chunk's HBM-bound FCT/update kernels run on its normal-priority stream beside the NEXT chunk's flux kernel.
-  hipEvent_t prev_flux = nullptr;
-  // One tendency stage of one chunk.  Unfused: flux (x,y,z) -> FCT -> update.  Fused: flux (y,z) -> x-sweep + state update
-  // -> FCT -> tracer update + pressure (pout differs from pin and p0).
-  auto stage = [&](Chunk &c, int st, const double *pin, const double *p0, double *pout, double dt_stage) -> int {
-    int r2;
-    if (h->fused) {
-      // Fused stage.  The two polynomial kernels (flux y,z and the fused x-sweep) of ALL chunks run back to back on ONE
-      // high-priority compute stream, chunk after chunk; a chunk's HBM-bound tail (FCT multiplier, tracer update + pressure)
-      // runs on the chunk's own stream beside the NEXT chunk's flux kernel.  The x-sweep is both VALU- and HBM-heavy and
-      // gets the chip to itself.
-      hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
-      if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
-      if ((r2 = launch_flux(h, pin, c.r, cs, 6))) return r2;
-      if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, c.r, cs);
-      else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, c.r, cs);
-      else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, c.r, cs);
-      if (r2) return r2;
+  // Everything between fork and join runs in a lambda: whatever fails in there (a launch, an event call), the join below
+  // still happens, so that the caller's stream stays ordered after the work already queued on the internal streams.
+  auto enqueue = [&]() -> int {
+    int rc = PAM_AMD_OK;
+    // Dycore.h:128-134 (per chunk)
+    for (auto &c : h->chunks) {
+      if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
+      if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+    }
+    // Launches are issued stage by stage, round-robin over the chunks.  With several chunks:
+    //  * flux kernels run on each chunk's high-priority flux stream and are chained ACROSS chunks by events
+    //    (A1 -> B1 -> C1 -> A2 ...): two VALU-bound flux kernels never share the chip;
+    //  * a chunk's HBM-bound FCT/update kernels run on its normal-priority stream beside the NEXT chunk's flux kernel.
+    hipEvent_t prev_flux = nullptr;
+    // One tendency stage of one chunk.  Unfused: flux (x,y,z) -> FCT -> update.  Fused: flux (y,z) -> x-sweep + state update
+    // -> FCT -> tracer update + pressure (pout differs from pin and p0).
+    auto stage = [&](Chunk &c, int st, const double *pin, const double *p0, double *pout, double dt_stage) -> int {
+      int r2;
+      if (h->fused) {
+        // Fused stage.  The two polynomial kernels (flux y,z and the fused x-sweep) of ALL chunks run back to back on ONE
+        // high-priority compute stream, chunk after chunk; a chunk's HBM-bound tail (FCT multiplier, tracer update + pressure)
+        // runs on the chunk's own stream beside the NEXT chunk's flux kernel.  The x-sweep is both VALU- and HBM-heavy and
+        // gets the chip to itself.
+        hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
+        if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
+        if ((r2 = launch_flux(h, pin, c.r, cs, 6))) return r2;
+        if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, c.r, cs);
+        else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, c.r, cs);
+        else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, c.r, cs);
+        if (r2) return r2;
+        if (forked) {
+          HIP_TRY(hipEventRecord(c.flux_done, cs));
+          HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
+        }
+        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
+        if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        if (r2) return r2;
+        if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+        return PAM_AMD_OK;
+      }
       if (forked) {
-        HIP_TRY(hipEventRecord(c.flux_done, cs));
+        HIP_TRY(hipStreamWaitEvent(c.fstream, c.upd_done, 0));               // this chunk's previous update / init
+        if (prev_flux) HIP_TRY(hipStreamWaitEvent(c.fstream, prev_flux, 0));  // the flux kernel launched just before
+      }
+      if ((r2 = launch_flux(h, pin, c.r, c.fstream, 7))) return r2;
+      if (forked) {
+        HIP_TRY(hipEventRecord(c.flux_done, c.fstream));
+        prev_flux = c.flux_done;
         HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
       }
       if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
-      if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-      else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-      else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      if (st == 1) r2 = launch_update<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      else if (st == 2) r2 = launch_update<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+      else r2 = launch_update<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
       if (r2) return r2;
       if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
       return PAM_AMD_OK;
+    };
+    for (int ic = 0; ic < ncycles; ic++) {
+      double *A = h->prim0, *B = h->prim1, *C = h->prim2;
+      if (h->fused) {
+        // three rotating buffers: A (sub-step start) -> B -> C -> B; the new state B becomes prim0
+        for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
+          if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+        for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
+          if ((rc = stage(c, 2, B, A, C, (1.0 / 4.0) * dt_dyn))) return rc;
+        for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
+          if ((rc = stage(c, 3, C, A, B, (2.0 / 3.0) * dt_dyn))) return rc;
+        h->prim0 = B;
+        h->prim1 = A;
+      } else {
+        // pointwise update kernel: stage 2 and 3 update in place
+        for (auto &c : h->chunks)
+          if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+        for (auto &c : h->chunks)
+          if ((rc = stage(c, 2, B, A, B, (1.0 / 4.0) * dt_dyn))) return rc;
+        for (auto &c : h->chunks)
+          if ((rc = stage(c, 3, B, A, A, (2.0 / 3.0) * dt_dyn))) return rc;
+      }
     }
-    if (forked) {
-      HIP_TRY(hipStreamWaitEvent(c.fstream, c.upd_done, 0));               // this chunk's previous update / init
-      if (prev_flux) HIP_TRY(hipStreamWaitEvent(c.fstream, prev_flux, 0));  // the flux kernel launched just before
-    }
-    if ((r2 = launch_flux(h, pin, c.r, c.fstream, 7))) return r2;
-    if (forked) {
-      HIP_TRY(hipEventRecord(c.flux_done, c.fstream));
-      prev_flux = c.flux_done;
-      HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
-    }
-    if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
-    if (st == 1) r2 = launch_update<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-    else if (st == 2) r2 = launch_update<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-    else r2 = launch_update<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-    if (r2) return r2;
-    if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+    // Dycore.h:254 (per chunk)
+    for (auto &c : h->chunks)
+      if ((rc = launch_finalize(h, fields, c.r, c.stream))) return rc;
     return PAM_AMD_OK;
   };
-  for (int ic = 0; ic < ncycles; ic++) {
-    double *A = h->prim0, *B = h->prim1, *C = h->prim2;
-    if (h->fused) {
-      // three rotating buffers: A (sub-step start) -> B -> C -> B; the new state B becomes prim0
-      for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
-        if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
-      for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
-        if ((rc = stage(c, 2, B, A, C, (1.0 / 4.0) * dt_dyn))) return rc;
-      for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
-        if ((rc = stage(c, 3, C, A, B, (2.0 / 3.0) * dt_dyn))) return rc;
-      h->prim0 = B;
-      h->prim1 = A;
-    } else {
-      // pointwise update kernel: stage 2 and 3 update in place
-      for (auto &c : h->chunks)
-        if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
-      for (auto &c : h->chunks)
-        if ((rc = stage(c, 2, B, A, B, (1.0 / 4.0) * dt_dyn))) return rc;
-      for (auto &c : h->chunks)
-        if ((rc = stage(c, 3, B, A, A, (2.0 / 3.0) * dt_dyn))) return rc;
-    }
-  }
-  // Dycore.h:254 (per chunk), then join: the caller's stream continues after every chunk has finished
-  for (auto &c : h->chunks)
-    if ((rc = launch_finalize(h, fields, c.r, c.stream))) return rc;
+  rc = enqueue();
+  // join: the caller's stream continues after every chunk (and the shared compute stream, which every chunk stream follows
+  // or is followed by through the events above) has finished -- also on the error path
   if (forked) {
+    int jrc = PAM_AMD_OK;
+    auto join_try = [&](hipError_t e) { if (e != hipSuccess && jrc == PAM_AMD_OK) jrc = fail(PAM_AMD_ENOGPU, std::string("time_step join: ") + hipGetErrorString(e)); };
     for (auto &c : h->chunks) {
-      HIP_TRY(hipEventRecord(c.done, c.stream));
-      HIP_TRY(hipStreamWaitEvent(h->stream, c.done, 0));
+      if (c.fstream && c.fstream != c.stream) {       // flux / compute streams: order them into the chunk stream first
+        join_try(hipEventRecord(c.flux_done, c.fstream));
+        join_try(hipStreamWaitEvent(c.stream, c.flux_done, 0));
+      }
+      join_try(hipEventRecord(c.done, c.stream));
+      join_try(hipStreamWaitEvent(h->stream, c.done, 0));
     }
+    if (rc == PAM_AMD_OK) rc = jrc;
   }
-  return PAM_AMD_OK;
+  return rc;
 }
 
 int pam_amd_awfl_init_idealized(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, const char *init_data,
@@ -1007,7 +1021,7 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h) {
 
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (faces < 1 || faces > FLUX_MAX_SPAN) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,32]");
+  if (faces < 1 || faces > FLUX_MAX_SPAN) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,64]");
   h->P.seg = faces;
   return PAM_AMD_OK;
 }
@@ -1033,8 +1047,7 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
 
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (enable && !h->fused_supported)
-    return fail(PAM_AMD_EINVAL, "set_fused_stage: the fused x-sweep needs nx <= 64 (one LDS slot per face of the line)");
+  if (enable && !h->fused_supported) return fail(PAM_AMD_EINVAL, "set_fused_stage: not available on this handle");
   h->fused = enable != 0;
   return PAM_AMD_OK;
 }

@@ -26,38 +26,32 @@ struct Emu {
 
 static void flux_launch(Emu *h, const double *prim, int sweeps = 7) {
   const Params &P = h->P;
-  std::vector<double> lds((size_t)FLUX_MAX_SPAN * FLUX_THREADS);
   for (int dir = 0; dir < 3; dir++) {
     if (dir == 1 && P.sim2d) continue;
     if (!((sweeps >> dir) & 1)) continue;
     const int nfaces = dir == 0 ? P.nx : (dir == 1 ? P.ny : P.nz + 1);
-    const long long nitems = dir == 0 ? (long long)P.nz * P.ny * P.nens
-                                      : (dir == 1 ? (long long)P.nz * P.nx * P.nens : (long long)P.ny * P.nx * P.nens);
+    const int nlines = dir == 0 ? P.nz * P.ny : (dir == 1 ? P.nz * P.nx : P.ny * P.nx);
     // span as in awfl_kernels.hip::choose_span with an override (h->span; 0 = whole line)
     const int pieces = (nfaces + FLUX_MAX_SPAN - 1) / FLUX_MAX_SPAN;
     int span = h->span > 0 ? (h->span < FLUX_MAX_SPAN ? h->span : FLUX_MAX_SPAN) : (nfaces + pieces - 1) / pieces;
     const int nspan = (nfaces + span - 1) / span;
-    const long long nunits = ((nitems + 63) / 64) * nspan;
     double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());
-    for (long long u = 0; u < nunits; u++) {
-      const int wave = (int)(u % 4);
-      for (int lane = 0; lane < 64; lane++) {
-        const int tid = wave * 64 + lane;
-        const long long item = (u / nspan) * 64 + lane;
-        const int f0 = (int)(u % nspan) * span;
-        if (item >= nitems) continue;
-        if (dir == 0) {
-          if (P.vz_per_ens) flux_line_body<0, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<0, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
-        } else if (dir == 1) {
-          if (P.vz_per_ens) flux_line_body<1, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<1, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
-        } else {
-          if (P.vz_per_ens) flux_line_body<2, true>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
-          else flux_line_body<2, false>(P, prim, fl, item, f0, span, lds.data(), FLUX_THREADS, tid);
+    // one wavefront per (line, block of 64 members, span); lanes = members
+    for (int line = 0; line < nlines; line++)
+      for (int sp = 0; sp < nspan; sp++)
+        for (int e = 0; e < P.nens; e++) {
+          const int f0 = sp * span;
+          if (dir == 0) {
+            if (P.vz_per_ens) flux_line_body<0, true>(P, prim, fl, line, e, f0, span);
+            else flux_line_body<0, false>(P, prim, fl, line, e, f0, span);
+          } else if (dir == 1) {
+            if (P.vz_per_ens) flux_line_body<1, true>(P, prim, fl, line, e, f0, span);
+            else flux_line_body<1, false>(P, prim, fl, line, e, f0, span);
+          } else {
+            if (P.vz_per_ens) flux_line_body<2, true>(P, prim, fl, line, e, f0, span);
+            else flux_line_body<2, false>(P, prim, fl, line, e, f0, span);
+          }
         }
-      }
-    }
   }
 }
 
@@ -73,15 +67,13 @@ static void update_launch(Emu *h, const double *in, const double *p0, double *ou
                        cell_of(h->P, idx));
 }
 
-// launch geometry of awfl_xupd_kernel: 256-thread blocks, thread t of block b owns item b*256 + t
+// launch geometry of awfl_xupd_kernel: one wavefront per (x line, block of 64 members); lanes = members
 template <int STAGE>
 static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   const Params &P = h->P;
-  std::vector<double> lds((size_t)P.nx * FLUX_THREADS);
-  const long long nitems = (long long)P.nz * P.ny * P.nens;
-  for (long long item = 0; item < nitems; item++)
-    flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), item, dt, lds.data(), FLUX_THREADS,
-                              (int)(item % FLUX_THREADS));
+  for (int line = 0; line < P.nz * P.ny; line++)
+    for (int e = 0; e < P.nens; e++)
+      flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, dt);
 }
 template <int STAGE>
 static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
@@ -201,7 +193,7 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     double *A = h->prim0.data(), *B = h->prim1.data(), *C = h->prim2.data();
     // poison the x fluxes of the state: the fused stage must not read them
     for (int ic = 0; ic < ncycles; ic++) {
-      std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);
+      std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);   // (field 0 is re-used as the x-sweep's own scratch)
       flux_launch(h, A, 6); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt); trupd_launch<1>(h, A, A, B, dt);
       flux_launch(h, B, 6); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt); trupd_launch<2>(h, B, A, C, dt);
       flux_launch(h, C, 6); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt); trupd_launch<3>(h, C, A, B, dt);

@@ -77,17 +77,27 @@ def test_fused_stage_is_chunking_invariant():
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_fused_stage_refuses_lines_longer_than_its_lds_slots():
+def test_fused_stage_handles_long_lines():
+    """no LDS slots any more: a line of any length is swept by its wavefront (nx = 80 here)"""
+    import torch
     from pam_amd import Dycore, PamCoupler
-    from pam_amd.capi import PamAmdError
     nens, nx, ny, nz = 2, 80, 1, 5
-    coupler = PamCoupler("cuda:0")
-    coupler.set_option("crm_dt", 1.0)
-    coupler.allocate_coupler_state(nz, ny, nx, nens)
-    coupler.set_grid(nx * 500.0, nx * 500.0, idz.uniform_interfaces(nz, 5000.0))
-    coupler.add_tracer("water_vapor", "", True, True)
-    dycore = Dycore()
-    dycore.init(coupler)                       # falls back to the three-kernel stage on its own
-    with pytest.raises(PamAmdError):
-        dycore.set_fused_stage(True)
-    dycore.finalize(coupler)
+    res = []
+    for fused in (False, True):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 1.0)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        zint = idz.uniform_interfaces(nz, 5000.0)
+        coupler.set_grid(nx * 500.0, nx * 500.0, zint)
+        coupler.add_tracer("water_vapor", "", True, True)
+        dycore = Dycore()
+        dycore.init(coupler)
+        dycore.set_fused_stage(fused)
+        coupler.load_fields(idz.supercell_fields(nens, nx, ny, nz, zint, magnitude=0.5))
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+        dycore.timeStep(coupler)
+        torch.cuda.synchronize()
+        res.append(coupler.dump_fields())
+        dycore.finalize(coupler)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k

