@@ -263,30 +263,30 @@ class Job:
 
 
 def stage_rooflines(job, alone):
-    """Per-kernel accounting of one tendency stage (nothing co-running: chunks=1).  `own_bytes`: what the kernel must move
-    given the kernel split (every field it reads or writes, once); `flops`: FP64 operations of its WENO polynomials (183 per
-    polynomial on average: 119/128 FP64 instructions, half of them FMAs -- ISA count) plus ~60 per cell
-    and state variable for the update arithmetic and ~250 for a pow."""
+    """Per-kernel accounting of one tendency stage (nothing co-running).  `own_bytes`: what the kernel must itself move given
+    the kernel split -- every field it reads or writes, once (sub-step-start values are read in 2 of the 3 stages: x 2/3);
+    `flops`: FP64 operations of its WENO polynomials (~183 per polynomial: 119/128 FP64 instructions, half of them FMAs -- ISA
+    count), ~60 per cell and variable for the update arithmetic and ~250 for a pow."""
     cells = float(job.nens * job.nz * job.ny * job.nx)
     nt, d3 = job.nt, job.ny > 1
     fb = cells * 8.0                       # one interior-sized field
     pb = fb * (job.nz + 6) / job.nz        # one prim field (3 ghost levels below and above)
     fused = "xupd" in alone
     poly = 183.0 * 1.03
+    nall = 3 if d3 else 2                  # sweep directions
     acct = {}
     if fused:
-        ndir = 2 if d3 else 1              # flux kernel sweeps y (3-D only) and z
-        acct["flux"] = (ndir * (6 + nt) * pb + ndir * (5 + nt) * fb, cells * ndir * (6 + nt) * poly)
-        nyz = 2 if d3 else 1
-        acct["xupd"] = ((6 + nt) * pb + 5 * pb + nyz * 2 * 5 * fb + 6 * pb + nt * fb,
+        nyz = nall - 1                     # the flux kernel sweeps y (3-D only) and z: mass + tracers as faces, the rest as differences
+        acct["flux"] = (nyz * (6 + nt) * pb + nyz * (5 + nt) * fb, cells * nyz * (6 + nt) * poly)
+        acct["xupd"] = ((6 + nt) * pb + (2.0 / 3.0) * 5 * pb + nyz * 5 * fb + 6 * pb + (1 + nt) * fb,
                         cells * ((6 + nt) * poly + 5 * 60.0))
-        acct["fct_mult"] = (nt * ((3 if d3 else 2) + 2) * fb, cells * nt * 20.0)
-        acct["trupd"] = (nt * ((3 if d3 else 2) + 1) * fb + (2 * nt + 6) * pb + nt * pb + pb + nt * fb, cells * (nt * 60.0 + 250.0))
+        acct["fct_mult"] = (nt * (nall + 2) * fb, cells * nt * 20.0)
+        acct["trupd"] = (nt * (nall + 1) * fb + (nt + 1) * pb * (1 + 2.0 / 3.0) + 3 * pb + (nt + 1) * pb + nt * fb,
+                         cells * (nt * 60.0 + 250.0))
     else:
-        ndir = 3 if d3 else 2
-        acct["flux"] = (ndir * (6 + nt) * pb + ndir * (5 + nt) * fb, cells * ndir * (6 + nt) * poly)
-        acct["fct_mult"] = (nt * (ndir + 2) * fb, cells * nt * 20.0)
-        acct["update"] = (ndir * (5 + nt) * fb + 2 * (6 + nt) * pb + nt * fb + (6 + nt) * pb + nt * fb,
+        acct["flux"] = (nall * (6 + nt) * pb + nall * (5 + nt) * fb, cells * nall * (6 + nt) * poly)
+        acct["fct_mult"] = (nt * (nall + 2) * fb, cells * nt * 20.0)
+        acct["update"] = (nall * (5 + nt) * fb + (6 + nt) * pb * (1 + 2.0 / 3.0) + nt * fb + (6 + nt) * pb + nt * fb,
                           cells * ((5 + nt) * 60.0 + 250.0))
     out = []
     for name, (nbytes, flops) in acct.items():
@@ -376,6 +376,10 @@ def worker(args):
                     tnote = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, this build (%s)" % prof["csrc_hash"]
                 else:
                     tnote = "profiles/r02_c2_traffic.json was measured on another build of pam_amd/csrc (or lacks this kernel): not reported"
+            if traffic is not None:
+                for kr in kernel_rooflines:
+                    if kr["kernel"] in prof["kernels"]:
+                        kr["traffic"] = prof["kernels"][kr["kernel"]]["hbm_bytes_per_launch"]
             stage_ms = sum(alone[k]["avg_ms"] for k in stage)
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,

@@ -82,6 +82,14 @@ int pam_amd_broadcast_initial_gcm_column(int nens, int nx, int ny, int nz, int n
  * formula is used instead -- everything else (seed, range, decay, rescale, summation order) follows the reference. */
 int pam_amd_perturb_temperature(int nens, int nx, int ny, int nz, double *temp, const int *id, double magnitude, void *stream);
 
+/* supercell_init(vert_interface, rho_d_col, uvel_col, vvel_col, wvel_col, temp_col, rho_v_col, Rd, Rv, grav)
+ * (standalone/mmf_simplified/supercell_init.h:7-135): the standalone driver's idealised supercell column, which the driver
+ * then broadcasts to every CRM cell (pam_amd_broadcast_initial_gcm_column) and perturbs.  vert_interface: DEVICE, nz+1
+ * interface heights of ONE column; the six outputs: DEVICE, nz values each. */
+int pam_amd_supercell_init(int nz, const double *vert_interface, double R_d, double R_v, double grav, double *rho_d_col,
+                           double *uvel_col, double *vvel_col, double *wvel_col, double *temp_col, double *rho_v_col,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1130,6 +1130,82 @@ void awfl_oracle_init_supercell(const awfl_oracle_t *o, const double *zmid, cons
 }
 
 /* ---------------------------------------------------------------------------------------------- */
+/* standalone/mmf_simplified/supercell_init.h:7-135: the driver's supercell column (hydrostatically integrated total
+ * pressure on 5 Gauss-Lobatto points per cell, then 5-point cell averages of dry density, winds, temperature and vapour
+ * density).  Host code; zint: nz+1 interface heights; outputs: nz values each. */
+void awfl_oracle_supercell_init(int nz, const double *zint, double Rd, double Rv, double grav, double *rho_d_col,
+                                double *uvel_col, double *vvel_col, double *wvel_col, double *temp_col, double *rho_v_col) {
+  enum { ord = 5 };
+  const double gll_pts[ord] = {-0.50000000000000000000000000000000000000, -0.32732683535398857189914622812342917778,
+                               0.00000000000000000000000000000000000000, 0.32732683535398857189914622812342917778,
+                               0.50000000000000000000000000000000000000};
+  const double gll_wts[ord] = {0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
+                               0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
+                               0.050000000000000000000000000000000000000};
+  const double z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
+  double *quad_temp = (double *)malloc((size_t)nz * (ord - 1) * ord * sizeof(double));
+  double *hyp = (double *)malloc((size_t)nz * ord * sizeof(double));
+  const double ztop = zint[nz];
+  for (int k = 0; k < nz; k++)                                             /* :46-66 */
+    for (int kk = 0; kk < ord - 1; kk++)
+      for (int kkk = 0; kkk < ord; kkk++) {
+        double dz = zint[k + 1] - zint[k];
+        double cellmid = zint[k] + 0.5 * dz;
+        double ord_b = cellmid + gll_pts[kk] * dz;
+        double ord_t = cellmid + gll_pts[kk + 1] * dz;
+        double ord_m = 0.5 * (ord_b + ord_t);
+        double ord_dz = dz * (gll_pts[kk + 1] - gll_pts[kk]);
+        double zloc = ord_m + ord_dz * gll_pts[kkk];
+        double temp = sc_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+        double press_dry = sc_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, Rd, grav);
+        double qvs = sc_sat_mix_dry(press_dry, temp);
+        double relhum = sc_relhum(zloc, z_0, z_trop);
+        if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+        double qv = fmin(0.014, qvs * relhum);                             /* std::min(0.014, NaN) == 0.014 */
+        quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] = -(1 + qv) * grav / (Rd + qv * Rv) / temp;
+      }
+  hyp[0] = p_0;                                                            /* :70-87 */
+  for (int k = 0; k < nz; k++) {
+    double dz = zint[k + 1] - zint[k];
+    for (int kk = 0; kk < ord - 1; kk++) {
+      double tot = 0;
+      for (int kkk = 0; kkk < ord; kkk++) tot += quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] * gll_wts[kkk];
+      tot *= dz * (gll_pts[kk + 1] - gll_pts[kk]);
+      hyp[(size_t)k * ord + kk + 1] = hyp[(size_t)k * ord + kk] * exp(tot);
+      if (kk == ord - 2 && k < nz - 1) hyp[(size_t)(k + 1) * ord] = hyp[(size_t)k * ord + ord - 1];
+    }
+  }
+  for (int k = 0; k < nz; k++) {                                           /* :92-133 */
+    rho_d_col[k] = 0; uvel_col[k] = 0; vvel_col[k] = 0; wvel_col[k] = 0; temp_col[k] = 0; rho_v_col[k] = 0;
+    for (int kk = 0; kk < ord; kk++) {
+      double dz = zint[k + 1] - zint[k];
+      double zmid = 0.5 * (zint[k] + zint[k + 1]);
+      double zloc = zmid + gll_pts[kk] * dz;
+      double temp = sc_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+      double press_dry = sc_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, Rd, grav);
+      double qvs = sc_sat_mix_dry(press_dry, temp);
+      double relhum = sc_relhum(zloc, z_0, z_trop);
+      if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+      double qv = fmin(0.014, qvs * relhum);
+      double p = hyp[(size_t)k * ord + kk];
+      double rho_d = p / (Rd + qv * Rv) / temp;
+      double rho_v = qv * rho_d;
+      double uvel;
+      const double zs = 5000, us = 30, uc = 15;
+      if (zloc < zs) uvel = us * (zloc / zs) - uc;
+      else uvel = us - uc;
+      double vvel = 0, wvel = 0;
+      rho_d_col[k] += rho_d * gll_wts[kk];
+      uvel_col[k] += uvel * gll_wts[kk];
+      vvel_col[k] += vvel * gll_wts[kk];
+      wvel_col[k] += wvel * gll_wts[kk];
+      temp_col[k] += temp * gll_wts[kk];
+      rho_v_col[k] += rho_v * gll_wts[kk];
+    }
+  }
+  free(quad_temp); free(hyp);
+}
+
 /* Kessler microphysics, "next row" N4 (physics/micro/kessler/Microphysics.h:120-268 timeStep, :346-457 kessler()).
  * Arrays are the coupler's (nz, ncol) collapsed views, ncol = ny*nx*nens (get_lev_col); zmid (nz,nens); precl (ncol).
  * rainsplit_in > 0 overrides the sub-cycle count (ensemble shards must agree on the global minimum).  Returns rainsplit. */

@@ -70,6 +70,7 @@ def load(path=None):
     lib.awfl_oracle_gcm_forcing_apply.argtypes = [C.c_int] * 4 + [C.POINTER(_DP)] * 3 + [_DP, C.c_double, C.c_double]
     lib.awfl_oracle_broadcast_gcm_column.argtypes = [C.c_int] * 5 + [C.POINTER(_DP)] * 2
     lib.awfl_oracle_perturb_temperature.argtypes = [C.c_int] * 4 + [_DP, C.POINTER(C.c_int), C.c_double]
+    lib.awfl_oracle_supercell_init.argtypes = [C.c_int, _DP] + [C.c_double] * 3 + [_DP] * 6
     lib.awfl_oracle_kessler.restype = C.c_int
     lib.awfl_oracle_kessler.argtypes = [C.c_int] * 4 + [_DP] * 7 + [C.c_double] * 5 + [C.c_int]
     lib.awfl_oracle_sponge_layer.argtypes = [C.c_int] * 5 + [C.POINTER(_DP), _DP, _DP, C.c_double, C.c_int, C.c_double]
@@ -237,6 +238,17 @@ class OracleDycore:
             self.lib.awfl_oracle_set_flux_taps(self.h, None, None, None)
             return st, tt, fl
         return st, tt
+
+
+def supercell_init(zint, consts, lib=None):
+    """the standalone driver's supercell column (standalone/mmf_simplified/supercell_init.h:7-135): zint (nz+1,) ->
+    (rho_d, uvel, vvel, wvel, temp, rho_v), each (nz,)"""
+    lib = lib or load()
+    z = np.ascontiguousarray(zint, dtype=np.float64)
+    nz = len(z) - 1
+    out = [np.zeros(nz) for _ in range(6)]
+    lib.awfl_oracle_supercell_init(nz, _p(z), consts["R_d"], consts["R_v"], consts["grav"], *[_p(a) for a in out])
+    return out
 
 
 def sponge_layer(fields, zint, zmid, dt, num_layers=5, time_scale=60.0, lib=None):

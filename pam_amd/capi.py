@@ -77,6 +77,7 @@ MODULE_SYMBOLS = {
                                                                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "pam_amd_broadcast_initial_gcm_column": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p)] * 2 + [C.c_void_p]),
     "pam_amd_perturb_temperature": (C.c_int, [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "pam_amd_supercell_init": (C.c_int, [C.c_int, C.c_void_p] + [C.c_double] * 3 + [C.c_void_p] * 6 + [C.c_void_p]),
     "pam_amd_kessler_max_stable_dt": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_double, C.c_void_p, C.c_void_p,
                                                                                    C.POINTER(C.c_double)]),
 }

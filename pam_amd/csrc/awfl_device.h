@@ -372,6 +372,14 @@ PAMA_D double flux_divergence(const Params &P, double xlo, double xhi, double yl
   return fma(zlo - zhi, rdzk, tend);
 }
 
+// the same with the y and z differences already formed (ylo - yhi, zlo - zhi: what the DIFF sweeps store)
+PAMA_D double flux_divergence_d(const Params &P, double xlo, double xhi, double dyv, double dzv, double rdzk) {
+#pragma clang fp contract(off)
+  double tend = (xlo - xhi) * P.rdx;
+  if (!P.sim2d) tend = fma(dyv, P.rdy, tend);
+  return fma(dzv, rdzk, tend);
+}
+
 // gravity source of the vertical momentum (Dycore.h:562-566): mode A -variable_gravity*rho, mode B -grav*(rho - hy_dens)
 PAMA_D double add_gravity(const Params &P, double tend, double rho_in, long long ke) {
 #pragma clang fp contract(off)
@@ -492,9 +500,14 @@ PAMA_D int wrap(int c, int n) {
 //            (Dycore.h:367-385).
 // Every cell polynomial is computed once and evaluated at both edges; the only redundant polynomial is the one of cell
 // f0-1 at the start of the span.
+//   DIFF     (the fused stage's y/z sweeps) the four momentum/theta variables are stored as the flux difference of each
+//            cell, F[c] - F[c+1] -- exactly the subtraction the divergence performs (flux_divergence), so the consumer loads ONE
+//            value per cell, variable and direction instead of two faces of which one belongs to a neighbouring line.  The
+//            mass flux (the later passes upwind with its faces) and the tracers (the FCT limiter works on faces) keep the
+//            face form.  Periodic lines must then be swept whole (f0 = 0, span >= n).
 // Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
 // with vertical ghosts already filled (Dycore.h:662-710).
-template <int DIR, bool VZ_PER_ENS>
+template <int DIR, bool VZ_PER_ENS, bool DIFF>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
                            int f0, int span) {
   const unsigned eu = member_offset(e);
@@ -514,7 +527,11 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     pbase = (long long)HS * P.sz + (long long)line * P.sx;
     fbase = (long long)line * P.sx;
   }
-  const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive
+  const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive: the faces this span owns
+  // DIFF: the five state variables leave as flux DIFFERENCES of cells (F[c] - F[c+1], what the divergence needs), so the
+  // sweep also computes the face that closes its last cell: face fend, or the periodic face n == face 0 (same bits)
+  const int cl = DIFF ? (fend < g.n ? fend : g.n) : fend - 1;          // last face computed (inclusive)
+  const bool periodic = (DIR != 2);
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
 
   auto cell_off = [&](int c) -> long long {
@@ -530,7 +547,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     else weno5_table(u, as_constant(tab), 1, wc, L, R);
   };
   const int nadv = 4 + P.nt;
-  double *fl0 = flux + fbase;                                          // flux field 0 of this line: the mass flux
+  double *fl0 = flux + fbase;                                          // flux field 0 of this line: the face mass flux
 
   // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
   {
@@ -558,8 +575,9 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
       wn[4] = nn; wm[4] = mul_rn(uni(pr + on)[eu], nn); wp[4] = uni(pp + on)[eu];
     }
+    double Fpn = 0.0;                                      // DIFF: the previous face's normal-momentum flux
 #pragma clang loop unroll(disable)
-    for (int c = f0; c < fend; c++) {                      // window = cells c-2..c+2; face c lies between cells c-1 and c
+    for (int c = f0; c <= cl; c++) {                       // window = cells c-2..c+2; face c lies between cells c-1 and c
       const long long on = cell_off(c + 3);                // the next cell entering the window
       const double nn = uni(pn + on)[eu], nm = mul_rn(uni(pr + on)[eu], nn), np_ = uni(pp + on)[eu];
       double Lm, Rm, Lp, Rp, Ln, Rn;
@@ -569,9 +587,16 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       const bool wall = (DIR == 2) && (c == 0 || c == P.nz);   // Dycore.h:477,482,496
       double ruf, ppf;
       acoustic_face(prevR_m, Lm, prevR_p, Lp, wall, ruf, ppf);
-      uniw(fl0 + (long long)c * g.cs)[eu] = ruf;                 // flux field 0
       const double val = (ruf > 0.0) ? prevR_n : Ln;            // upwind (Dycore.h:368)
-      uniw(fln + (long long)c * g.cs)[eu] = fma(ruf, val, ppf);
+      const double fn = fma(ruf, val, ppf);
+      // the mass flux always leaves as FACES: the later passes upwind with it (face n of a periodic line is face 0)
+      if (!(DIFF && periodic && c == g.n)) uniw(fl0 + (long long)c * g.cs)[eu] = ruf;
+      if (DIFF) {
+        if (c > f0) uniw(fln + (long long)(c - 1) * g.cs)[eu] = Fpn - fn;   // cell c-1 is closed by faces c-1 and c
+        Fpn = fn;
+      } else {
+        uniw(fln + (long long)c * g.cs)[eu] = fn;
+      }
       prevR_m = Rm; prevR_p = Rp; prevR_n = Rn;
 #pragma unroll
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
@@ -581,8 +606,11 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   // ---------------- the other advected quantities (Dycore.h:367-385), FLUX_NF fields per sweep ------------------
   // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with few
   // wavefronts per SIMD a single chain per iteration leaves issue slots empty, several independent chains fill them.
-  auto sweep = [&](auto nf_tag, const int *fa) {
+  // NS: the first NS fields of the sweep are state variables whose DIFFERENCE is stored (DIFF only; the sweep order puts the
+  // state variables first), the others store faces
+  auto sweep = [&](auto nf_tag, auto ns_tag, const int *fa) {
     constexpr int NF = decltype(nf_tag)::value;
+    constexpr int NS = decltype(ns_tag)::value;
     const double *q[NF];
     double *fl[NF];
     double w[NF][5], prevR[NF];
@@ -608,19 +636,29 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         w[n][4] = uni(q[n] + on)[eu];
       }
     }
+    double Fp[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) Fp[n] = 0.0;
 #pragma clang loop unroll(disable)
-    for (int c = f0; c < fend; c++) {
+    for (int c = f0; c <= cl; c++) {
       const long long on = cell_off(c + 3);
       double nq[NF], L[NF], R[NF];
 #pragma unroll
       for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
-      const double ruf = uni(fl0 + (long long)c * g.cs)[eu];  // this lane's own store of pass 1
+      // this lane's own store of pass 1 (the periodic face n is face 0)
+      const double ruf = uni(fl0 + (long long)((DIFF && periodic && c == g.n) ? 0 : c) * g.cs)[eu];
 #pragma unroll
       for (int n = 0; n < NF; n++) weno(w[n], c, L[n], R[n]);
       const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
 #pragma unroll
       for (int n = 0; n < NF; n++) {
-        uniw(fl[n] + (long long)c * g.cs)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
+        const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
+        if (n < NS) {
+          if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = Fp[n] - F;
+          Fp[n] = F;
+        } else if (c < fend) {
+          uniw(fl[n] + (long long)c * g.cs)[eu] = F;
+        }
         prevR[n] = R[n];
 #pragma unroll
         for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
@@ -628,16 +666,27 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       }
     }
   };
+  // dispatch: NF fields per sweep, of which the leading ns are state variables in difference form
+  auto run = [&](int nf, const int *fa) {
+    int ns = 0;
+    if (DIFF)
+      for (int n = 0; n < nf; n++) ns += (fa[n] < 4) ? 1 : 0;
+    using std::integral_constant;
+    if (nf == 1) { if (ns == 1) sweep(integral_constant<int, 1>{}, integral_constant<int, 1>{}, fa); else sweep(integral_constant<int, 1>{}, integral_constant<int, 0>{}, fa); }
+    else if (nf == 2) {
+      if (ns == 2) sweep(integral_constant<int, 2>{}, integral_constant<int, 2>{}, fa);
+      else if (ns == 1) sweep(integral_constant<int, 2>{}, integral_constant<int, 1>{}, fa);
+      else sweep(integral_constant<int, 2>{}, integral_constant<int, 0>{}, fa);
+    }
+  };
+  static_assert(FLUX_NF == 2, "the sweep dispatch is written for two fields per sweep");
   int fa[FLUX_NF], nfa = 0;
   for (int a = 0; a < nadv; a++) {
     if (P_U + a == ncomp) continue;
     fa[nfa++] = a;
-    if (nfa == FLUX_NF) { sweep(std::integral_constant<int, FLUX_NF>{}, fa); nfa = 0; }
+    if (nfa == FLUX_NF) { run(FLUX_NF, fa); nfa = 0; }
   }
-  if (FLUX_NF >= 4 && nfa == 3) { sweep(std::integral_constant<int, 3>{}, fa); nfa = 0; }
-  if (FLUX_NF >= 3 && nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
-  if (nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
-  if (nfa == 1) sweep(std::integral_constant<int, 1>{}, fa);
+  if (nfa == 1) run(1, fa);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -950,8 +999,8 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 
 // ------------------------------------------------------------------------------------------------
 // FUSED x-sweep: reconstruction + fluxes in x (as flux_line_body<0>) AND, in the same pass, the stage update of the five
-// state variables of every cell of the line (as update_body), with the y and z face fluxes read from the flux arrays the
-// y/z sweeps wrote earlier.  Reference: Dycore.h:334-386 (x fluxes), :553-571 (divergence, gravity), :162-221 (SSPRK3
+// state variables of every cell of the line (as update_body), with the y and z flux differences of the cell read from the
+// arrays the y/z sweeps (flux_line_body<.., DIFF = true>) wrote earlier.  Reference: Dycore.h:334-386 (x fluxes), :553-571 (divergence, gravity), :162-221 (SSPRK3
 // combine), next stage's :310-321 (divide by rho) and :662-710 (vertical ghosts of the advected variables).
 //
 // Why: in the three-kernel stage every x face flux of the state makes a round trip through HBM (written by the flux
@@ -1041,19 +1090,22 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
     for (int l = 0; l <= NQ; l++) { F_prev[l] = 0.0; F_first[l] = 0.0; }
     // everything cell cc needs besides its x fluxes
-    struct CellIn { double rho_in, rho_0, q0[NQ], yl[1 + NQ], yh[1 + NQ], zl[1 + NQ], zh[1 + NQ]; };
+    // y0*/z0*: the two y / z faces of the mass flux; dy, dz: flux differences of the other variables (DIFF sweeps)
+    struct CellIn { double rho_in, rho_0, q0[NQ], y0l, y0h, z0l, z0h, dy[1 + NQ], dz[1 + NQ]; };
     auto load_in = [&](int cc, CellIn &ci) {
       const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
       ci.rho_in = uni(pr + o)[eu];
       ci.rho_0 = (STAGE > 1) ? uni(r0 + o)[eu] : 0.0;
 #pragma unroll
       for (int n = 0; n < NQ; n++) ci.q0[n] = (STAGE > 1) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs + o)[eu] : 0.0;
+      ci.y0l = have_y ? uni(fy + ix)[eu] : 0.0;
+      ci.y0h = have_y ? uni(fy + ix + jp1)[eu] : 0.0;
+      ci.z0l = uni(fz + ix)[eu];
+      ci.z0h = uni(fz + ix + P.sz)[eu];
 #pragma unroll
-      for (int l = 0; l <= NQ; l++) {
-        ci.yl[l] = 0.0; ci.yh[l] = 0.0;
-        if (have_y) { ci.yl[l] = uni(fy + (long long)l * P.ncell + ix)[eu]; ci.yh[l] = uni(fy + (long long)l * P.ncell + ix + jp1)[eu]; }
-        ci.zl[l] = uni(fz + (long long)l * P.fz_fs + ix)[eu];
-        ci.zh[l] = uni(fz + (long long)l * P.fz_fs + ix + P.sz)[eu];
+      for (int l = 1; l <= NQ; l++) {
+        ci.dy[l] = have_y ? uni(fy + (long long)l * P.ncell + ix)[eu] : 0.0;
+        ci.dz[l] = uni(fz + (long long)l * P.fz_fs + ix)[eu];
       }
     };
     // finish cell cc: F_lo/F_hi = its two x faces; m_in_u = rho*u of the stage input (the product window), q_in = v, w, theta
@@ -1061,14 +1113,14 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
                       double v_in, double w_in, double th_in) {
       const long long o = pbase + (long long)cc * P.sx;
       const double q0 = rk_combine<STAGE>(ci.rho_0, ci.rho_in, dt_dyn,
-                                          flux_divergence(P, Flo[0], Fhi[0], ci.yl[0], ci.yh[0], ci.zl[0], ci.zh[0], rdzk));
+                                          flux_divergence(P, Flo[0], Fhi[0], ci.y0l, ci.y0h, ci.z0l, ci.z0h, rdzk));
       const double rrho = fast_rcp(q0);
       uniw(out_rho + o)[eu] = q0;
       const double q_in[NQ] = {0.0, v_in, w_in, th_in};
 #pragma unroll
       for (int n = 0; n < NQ; n++) {
         const int l = 1 + n;                               // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
-        double tend = flux_divergence(P, Flo[l], Fhi[l], ci.yl[l], ci.yh[l], ci.zl[l], ci.zh[l], rdzk);
+        double tend = flux_divergence_d(P, Flo[l], Fhi[l], ci.dy[l], ci.dz[l], rdzk);
         if (l == 3) tend = add_gravity(P, tend, ci.rho_in, ke);
         if (l == 2 && P.sim2d) tend = 0.0;
         const double m_in = (n == 0) ? m_in_u : mul_rn(q_in[n], ci.rho_in);

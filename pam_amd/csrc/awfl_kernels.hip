@@ -60,11 +60,13 @@ struct FluxGrid {
   int nbx_l, nby_l;         // x / y workgroups per vertical level when the two sweeps are interleaved level by level (else 0)
 };
 
-template <bool VZ_PER_ENS>
+// DIFF (the fused stage's y/z sweeps): momentum and theta leave as per-cell flux differences (flux_line_body); there is no x
+// sweep in that mode (the fused x-sweep kernel does it).
+template <bool VZ_PER_ENS, bool DIFF>
 __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
-                                                                  const double *__restrict__ prim,
-                                                                  double *__restrict__ fx, double *__restrict__ fy,
-                                                                  double *__restrict__ fz) {
+                                                                     const double *__restrict__ prim,
+                                                                     double *__restrict__ fx, double *__restrict__ fy,
+                                                                     double *__restrict__ fz) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nblk = (R.ne + 63) >> 6;          // blocks of 64 members per line
@@ -83,19 +85,22 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
     const int u = b * FLUX_WAVES + wave;
     if (u < G.nux) {
       const int grp = uni_int(u / G.nsx), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne) flux_line_body<0, VZ_PER_ENS>(P, prim, fx, line, R.e0 + el, (u - grp * G.nsx) * G.spx, G.spx);
+      if (!DIFF && el < R.ne)
+        flux_line_body<0, VZ_PER_ENS, false>(P, prim, fx, line, R.e0 + el, (u - grp * G.nsx) * G.spx, G.spx);
     }
   } else if (b < G.nbx + G.nby) {
     const int u = (b - G.nbx) * FLUX_WAVES + wave;
     if (u < G.nuy) {
       const int grp = uni_int(u / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne) flux_line_body<1, VZ_PER_ENS>(P, prim, fy, line, R.e0 + el, (u - grp * G.nsy) * G.spy, G.spy);
+      if (el < R.ne)
+        flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, line, R.e0 + el, (u - grp * G.nsy) * G.spy, G.spy);
     }
   } else {
     const int u = (b - G.nbx - G.nby) * FLUX_WAVES + wave;
     if (u < G.nuz) {
       const int grp = uni_int(u / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne) flux_line_body<2, VZ_PER_ENS>(P, prim, fz, line, R.e0 + el, (u - grp * G.nsz) * G.spz, G.spz);
+      if (el < R.ne)
+        flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (u - grp * G.nsz) * G.spz, G.spz);
     }
   }
 }
@@ -209,10 +214,16 @@ __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *_
   double m = INFINITY;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < P.ncell;
        idx += (long long)gridDim.x * blockDim.x)
-    m = fmin(m, cfl_body(P, rho_d, u, v, w, temp, rho_v, cfl, idx));
-  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+  {
+    const double dtc = cfl_body(P, rho_d, u, v, w, temp, rho_v, cfl, idx);
+    m = (dtc != dtc || m != m) ? NAN : fmin(m, dtc);     // fmin() drops a NaN operand: keep it, one bad cell must fail the step
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(m, off, 64);
+    m = (o != o || m != m) ? NAN : fmin(m, o);
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (!(m > 0.0)) m = 0.0;   // NaN or non-positive: propagate as 0 (the host reports it)
+    if (!(m > 0.0)) m = 0.0;   // NaN or non-positive anywhere in the wavefront's cells: reported as 0 (the host refuses it)
     atomicMin(result, (unsigned long long)__double_as_longlong(m));
   }
 }
@@ -391,13 +402,15 @@ static void choose_span(int nfaces, long long nlines, int nens, int min_span, in
 }
 
 // sweeps: bit 0 x, bit 1 y, bit 2 z (the fused stage runs y and z here and x in awfl_xupd_kernel)
-int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, int sweeps = 7) {
+int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, int sweeps = 7, bool diff = false) {
   const Params &P = h->P;
   FluxGrid G;
+  if (diff && (sweeps & 1)) return fail(PAM_AMD_EINVAL, "flux launch: the difference form has no x sweep");
   // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
   choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, G.spx, G.nsx);
   choose_span(P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, G.spy, G.nsy);
   choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, G.spz, G.nsz);
+  if (diff) { G.spy = P.ny; G.nsy = 1; }   // difference form: a periodic line is swept whole (its last cell needs face n == face 0)
   const long long nblk = (r.ne + 63) / 64;     // a wavefront = 64 consecutive members of ONE line
   const long long ux = (sweeps & 1) ? (long long)P.nz * P.ny * nblk * G.nsx : 0;
   const long long uy = (P.sim2d || !(sweeps & 2)) ? 0 : (long long)P.nz * P.nx * nblk * G.nsy;
@@ -416,12 +429,12 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   size_t lds_bytes = 0;
   if (h->chunks.size() > 1) lds_bytes = h->flux_lds_floor;
   ScopedTimer st(h, "flux", s);
-  if (P.vz_per_ens)
-    hipLaunchKernelGGL(awfl_flux_kernel<true>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
-                       h->flux_x, h->flux_y, h->flux_z);
-  else
-    hipLaunchKernelGGL(awfl_flux_kernel<false>, dim3(G.nbx + G.nby + G.nbz), dim3(FLUX_THREADS), lds_bytes, s, P, G, r, prim,
-                       h->flux_x, h->flux_y, h->flux_z);
+  const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
+#define PAMA_LAUNCH_FLUX(VZ, DF)                                                                                        \
+  hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
+  if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true); else PAMA_LAUNCH_FLUX(true, false); }
+  else { if (diff) PAMA_LAUNCH_FLUX(false, true); else PAMA_LAUNCH_FLUX(false, false); }
+#undef PAMA_LAUNCH_FLUX
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -509,9 +522,11 @@ int build_chunks(pam_amd_awfl *h) {
   const int nens = h->P.nens;
   int n = h->chunks_requested;
   if (n <= 0) {
-    // automatic: chunking only pays when every chunk's flux launch still fills the chip.  W = wavefronts of one whole-
-    // ensemble flux launch.  Measured: C2 (W=87k) 1/2/3 chunks -> 1.52/1.65/1.66 G/s; C3 (W=14k) 1.27/1.29/1.16;
-    // C4 (W=4k) 0.60/0.57/0.45.
+    // automatic.  Fused stage: ONE range -- its two big kernels are each bound by their own resource (flux y,z: the FP64
+    // pipe; fused x-sweep: HBM) and lose more from sharing the chip than the pointwise tail gains (measured on C2, round 2:
+    // 1/2/8 ranges -> 2.08/2.05/1.72 G cell-updates/s).  Three-kernel stage: ranges on internal streams so that the HBM-bound
+    // update of one range runs beside the FP64-bound flux kernel of the next; chunking only pays when every range's flux
+    // launch still fills the chip (W = wavefronts of one whole-ensemble flux launch).
     const Params &P = h->P;
     int sp, nsx, nsy, nsz;
     choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, sp, nsx);
@@ -524,7 +539,7 @@ int build_chunks(pam_amd_awfl *h) {
     // ~11.8 k wave-units of flux work per chunk (128 members of a 32x32x60 CRM) measured best on MI355X for 256..2048
     // members; smaller jobs run as one chunk
     n = (int)((W + 8000) / 11776);
-    if (n < 1) n = 1;
+    if (n < 1 || h->fused) n = 1;
     if (n > 16) n = 16;
   }
   const int per = (((nens + n - 1) / n + 63) / 64) * 64;
@@ -685,8 +700,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->n_vert_s2c = vt.s2c.size(); h->n_vert_wrl = vt.wrl.size();
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -870,7 +887,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
         // gets the chip to itself.
         hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
         if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
-        if ((r2 = launch_flux(h, pin, c.r, cs, 6))) return r2;
+        if ((r2 = launch_flux(h, pin, c.r, cs, 6, true))) return r2;
         if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, c.r, cs);
         else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, c.r, cs);
         else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, c.r, cs);
@@ -1048,7 +1065,12 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (enable && !h->fused_supported) return fail(PAM_AMD_EINVAL, "set_fused_stage: not available on this handle");
+  const bool changed = h->fused != (enable != 0);
   h->fused = enable != 0;
+  if (changed && h->chunks_requested <= 0) {   // the automatic range count depends on the stage structure
+    USE_DEVICE(h);
+    return build_chunks(h);
+  }
   return PAM_AMD_OK;
 }
 
@@ -1085,7 +1107,7 @@ int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
   USE_DEVICE(h);
   const EnsRange r = full_range(h->P);
   int rc;
-  if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7))) return rc;
+  if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
   if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream))) return rc;
   if ((rc = launch_fct(h, dt_dyn, r, h->stream))) return rc;
   if (h->fused) rc = launch_trupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);

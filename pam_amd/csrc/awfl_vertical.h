@@ -17,6 +17,7 @@
 #include <cstring>
 #include <vector>
 #include "awfl_constants.h"
+#include "supercell_sounding.h"
 #include "awfl_device.h"
 
 namespace pama {
@@ -125,33 +126,7 @@ inline VerticalTables build_vertical_tables(const double *dz, int nz, int nens) 
   return vt;
 }
 
-// ---- init_supercell column integration (Dycore.h:1096-1230), host side, once at init --------------------------------
-namespace sc {
-inline double temperature(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top) {
-  if (z <= z_trop) { double lapse = -(T_trop - T_0) / (z_trop - z_0); return T_0 - lapse * (z - z_0); }
-  double lapse = -(T_top - T_trop) / (z_top - z_trop);
-  return T_trop - lapse * (z - z_trop);
-}
-inline double pressure_dry(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top,
-                           double p_0, double R_d, double grav) {
-  if (z <= z_trop) {
-    double lapse = -(T_trop - T_0) / (z_trop - z_0);
-    double T = temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
-    return p_0 * std::pow(T / T_0, grav / (R_d * lapse));
-  }
-  double lapse = -(T_trop - T_0) / (z_trop - z_0);
-  double p_trop = p_0 * std::pow(T_trop / T_0, grav / (R_d * lapse));
-  lapse = -(T_top - T_trop) / (z_top - z_trop);
-  if (lapse != 0) {
-    double T = temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
-    return p_trop * std::pow(T / T_trop, grav / (R_d * lapse));
-  }
-  return p_trop * std::exp(-grav * (z - z_trop) / (R_d * T_trop));
-}
-inline double relhum(double z, double z_0, double z_trop) { return z <= z_trop ? 1.0 - 0.75 * std::pow(z / z_trop, 1.25) : 0.25; }
-inline double sat_mix_dry(double press, double T) { return 380 / (press)*std::exp(17.27 * (T - 273) / (T - 36)); }
-}  // namespace sc
-
+// ---- init_supercell column integration (Dycore.h:1096-1230), host side, once at init; the sounding: supercell_sounding.h
 struct SupercellColumns { std::vector<double> hy_dens, hy_pres, dens_vap_gll; };   // (nz,nens), (nz,nens), (nz,9,nens)
 
 // dz, zmid (nz,nens), zint (nz+1,nens): host copies.  Quirk Q10: the reference's cell-mean kernel broadcasts every
@@ -159,23 +134,15 @@ struct SupercellColumns { std::vector<double> hy_dens, hy_pres, dens_vap_gll; };
 // reference's serial order the last member's value wins for every member, which is what is restated here.
 inline SupercellColumns supercell_columns(const double *dz, const double *zmid, const double *zint, int nz, int nens,
                                           double R_d, double R_v, double grav, double gamma, double C0) {
-  const double z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
+  const double p_0 = 100000;
   const double pts[9] = AWFL_GLL9_PTS_INIT, wts[9] = AWFL_GLL9_WTS_INIT;
   SupercellColumns out;
   out.hy_dens.assign((size_t)nz * nens, 0.0);
   out.hy_pres.assign((size_t)nz * nens, 0.0);
   out.dens_vap_gll.assign((size_t)nz * 9 * nens, 0.0);
   std::vector<double> pg((size_t)nz * 9), dg((size_t)nz * 9);
-  auto qv_at = [&](double zloc, double ztop, double &temp) {
-    temp = sc::temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
-    double pd = sc::pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
-    double qvs = sc::sat_mix_dry(pd, temp);
-    double rh = sc::relhum(zloc, z_0, z_trop);
-    if (rh * qvs > 0.014) rh = 0.014 / qvs;
-    return std::fmin(0.014, qvs * rh);
-  };
   for (int e = 0; e < nens; e++) {
-    const double ztop = zint[(size_t)nz * nens + e];
+    const Sounding snd = Sounding::make(zint[(size_t)nz * nens + e], R_d, grav);
     pg[0] = p_0;
     for (int k = 0; k < nz; k++) {
       const double dzk = dz[(size_t)k * nens + e], cellmid = zmid[(size_t)k * nens + e];
@@ -184,7 +151,7 @@ inline SupercellColumns supercell_columns(const double *dz, const double *zmid, 
         double m = 0.5 * (b + t), gdz = dzk * (pts[kk + 1] - pts[kk]);
         double tot = 0;
         for (int kkk = 0; kkk < 9; kkk++) {
-          double temp, qv = qv_at(m + gdz * pts[kkk], ztop, temp);
+          double temp, qv = snd.vapour_mixing_ratio(m + gdz * pts[kkk], temp);
           tot += (-(1 + qv) * grav / (R_d + qv * R_v) / temp) * wts[kkk];
         }
         tot *= dzk * (pts[kk + 1] - pts[kk]);
@@ -196,7 +163,7 @@ inline SupercellColumns supercell_columns(const double *dz, const double *zmid, 
       const double dzk = dz[(size_t)k * nens + e], cellmid = zmid[(size_t)k * nens + e];
       double press_tot = 0, dens_tot = 0;
       for (int kk = 0; kk < 9; kk++) {
-        double temp, qv = qv_at(cellmid + pts[kk] * dzk, ztop, temp);
+        double temp, qv = snd.vapour_mixing_ratio(cellmid + pts[kk] * dzk, temp);
         double press = pg[(size_t)k * 9 + kk];
         double dens_dry = press / (R_d + qv * R_v) / temp, dens_vap = qv * dens_dry;
         out.dens_vap_gll[((size_t)k * 9 + kk) * nens + e] = dens_vap;

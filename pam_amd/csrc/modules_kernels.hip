@@ -6,6 +6,7 @@
 
 #include "../../include/pam_amd_awfl.h"
 #include "../../include/pam_amd_modules.h"
+#include "supercell_sounding.h"
 
 namespace {
 
@@ -455,11 +456,15 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
-  hipMemsetAsync(slot, 0x7f, 8, s);
-  hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
-                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
   int n = rainsplit_hint;
-  if (n <= 0) {   // the reference's yakl::intrinsics::minval (:389-390): one 8-byte read-back
+  if (n <= 0) {
+    // The sub-cycle count comes from a global minimum (the reference's yakl::intrinsics::minval, :389-390): one 8-byte
+    // read-back.  It is taken with the NON-writing form of the prep kernel, so that a failure here (a NaN state, an absurd
+    // sub-cycle count, a HIP error) leaves the coupler arrays untouched -- the writing form below converts rho_x -> q and
+    // T -> theta in place and cannot be undone from an error path.
+    hipMemsetAsync(slot, 0x7f, 8, s);
+    hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
+                       rho_v, rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
     double dt_max;
     if (int rc = kessler_read_dt_max((const double *)slot, s, &dt_max)) return rc;
     const double want = ceil(dt / dt_max);
@@ -467,6 +472,9 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     n = (int)want;
     if (n < 1) n = 1;
   }
+  hipMemsetAsync(slot, 0x7f, 8, s);
+  hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
+                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
   hipLaunchKernelGGL(kessler_column_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
                      rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, cp_d, p0);
   hipError_t err = hipGetLastError();
@@ -584,6 +592,99 @@ extern "C" int pam_amd_perturb_temperature(int nens, int nx, int ny, int nz, dou
   const long long n = (long long)num_levels * nens;
   hipLaunchKernelGGL(perturb_temperature_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, nens, nx, ny,
                      num_levels, temp, id, magnitude);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
+  return PAM_AMD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// supercell_init (standalone/mmf_simplified/supercell_init.h:7-135): the standalone driver's supercell COLUMN -- dry density,
+// winds, temperature and vapour density of each level, from the analytic sounding (supercell_sounding.h) with the total
+// pressure integrated hydrostatically through 5 Gauss-Lobatto points per cell.  One workgroup (the column is nz ~ 60 levels):
+//   phase 1  every (level, GLL interval) integrates -(1+qv) g / ((R_d + qv R_v) T) over its 5 sub-points   (:46-66,:76-79)
+//   phase 2  one lane chains the exponentials from the ground up (the reference does the same in a 1-iteration kernel, :70-87)
+//   phase 3  every level averages its 5 GLL points                                                           (:92-133)
+namespace {
+__global__ void __launch_bounds__(256) supercell_init_kernel(int nz, const double *__restrict__ zint, double R_d, double R_v,
+                                                             double grav, double *__restrict__ rho_d_col,
+                                                             double *__restrict__ uvel_col, double *__restrict__ vvel_col,
+                                                             double *__restrict__ wvel_col, double *__restrict__ temp_col,
+                                                             double *__restrict__ rho_v_col) {
+  constexpr int ord = 5;
+  const double gll_pts[ord] = {-0.50000000000000000000000000000000000000, -0.32732683535398857189914622812342917778,
+                               0.00000000000000000000000000000000000000, 0.32732683535398857189914622812342917778,
+                               0.50000000000000000000000000000000000000};
+  const double gll_wts[ord] = {0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
+                               0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
+                               0.050000000000000000000000000000000000000};
+  extern __shared__ double sc_lds[];
+  double *tot = sc_lds;                       // (nz, ord-1): integral of the log-pressure gradient over each GLL interval
+  double *hyp = sc_lds + (size_t)nz * (ord - 1);   // (nz, ord): total pressure at the GLL points
+  const pama::Sounding snd = pama::Sounding::make(zint[nz], R_d, grav);
+  for (int t = threadIdx.x; t < nz * (ord - 1); t += blockDim.x) {
+    const int k = t / (ord - 1), kk = t - k * (ord - 1);
+    const double dz = zint[k + 1] - zint[k];
+    const double cellmid = zint[k] + 0.5 * dz;
+    const double ord_b = cellmid + gll_pts[kk] * dz, ord_t = cellmid + gll_pts[kk + 1] * dz;
+    const double ord_m = 0.5 * (ord_b + ord_t);
+    const double ord_dz = dz * (gll_pts[kk + 1] - gll_pts[kk]);
+    double acc = 0;
+    for (int kkk = 0; kkk < ord; kkk++) {
+      double temp;
+      const double qv = snd.vapour_mixing_ratio(ord_m + ord_dz * gll_pts[kkk], temp);
+      acc += (-(1 + qv) * grav / (R_d + qv * R_v) / temp) * gll_wts[kkk];
+    }
+    tot[t] = acc * (dz * (gll_pts[kk + 1] - gll_pts[kk]));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hyp[0] = snd.p_0;
+    for (int k = 0; k < nz; k++)
+      for (int kk = 0; kk < ord - 1; kk++) {
+        hyp[k * ord + kk + 1] = hyp[k * ord + kk] * exp(tot[k * (ord - 1) + kk]);
+        if (kk == ord - 2 && k < nz - 1) hyp[(k + 1) * ord] = hyp[k * ord + ord - 1];
+      }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nz; k += blockDim.x) {
+    double rd = 0, u = 0, v = 0, w = 0, T = 0, rv = 0;
+    const double dz = zint[k + 1] - zint[k];
+    const double zmid = 0.5 * (zint[k] + zint[k + 1]);
+    for (int kk = 0; kk < ord; kk++) {
+      const double zloc = zmid + gll_pts[kk] * dz;
+      double temp;
+      const double qv = snd.vapour_mixing_ratio(zloc, temp);
+      const double rho_d = hyp[k * ord + kk] / (R_d + qv * R_v) / temp;
+      const double zs = 5000, us = 30, uc = 15;
+      const double uvel = (zloc < zs) ? us * (zloc / zs) - uc : us - uc;
+      rd += rho_d * gll_wts[kk];
+      u += uvel * gll_wts[kk];
+      v += 0.0 * gll_wts[kk];
+      w += 0.0 * gll_wts[kk];
+      T += temp * gll_wts[kk];
+      rv += (qv * rho_d) * gll_wts[kk];
+    }
+    rho_d_col[k] = rd; uvel_col[k] = u; vvel_col[k] = v; wvel_col[k] = w; temp_col[k] = T; rho_v_col[k] = rv;
+  }
+}
+}  // namespace
+
+extern "C" int pam_amd_supercell_init(int nz, const double *vert_interface, double R_d, double R_v, double grav,
+                                      double *rho_d_col, double *uvel_col, double *vvel_col, double *wvel_col, double *temp_col,
+                                      double *rho_v_col, void *stream) {
+  if (nz < 1 || !vert_interface || !rho_d_col || !uvel_col || !vvel_col || !wvel_col || !temp_col || !rho_v_col)
+    return pam_amd_set_last_error_(PAM_AMD_EINVAL, "supercell_init: bad nz or null pointer");
+  const size_t lds = (size_t)nz * 9 * sizeof(double);
+  if (lds > 160 * 1024) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "supercell_init: more than 2275 levels");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "supercell_init: no HIP device available (this library has no CPU path)");
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void *)supercell_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "supercell_init: cannot raise the LDS limit");
+  hipLaunchKernelGGL(supercell_init_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, nz, vert_interface, R_d, R_v, grav,
+                     rho_d_col, uvel_col, vvel_col, wvel_col, temp_col, rho_v_col);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;

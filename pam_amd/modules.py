@@ -121,3 +121,19 @@ def perturb_temperature(coupler, ids, magnitude=0.1):
                                               ids.data_ptr(), float(magnitude),
                                               torch.cuda.current_stream(coupler.device).cuda_stream))
     return ids   # keeps the id array alive until the caller drops it (the launch is asynchronous)
+
+
+def supercell_init(vert_interface, R_d, R_v, grav):
+    """supercell_init(...) of the standalone driver (standalone/mmf_simplified/supercell_init.h:7-135) on the device:
+    vert_interface (nz+1,) CUDA tensor -> (rho_d_col, uvel_col, vvel_col, wvel_col, temp_col, rho_v_col), each (nz,)."""
+    lib = capi.load()
+    z = vert_interface.contiguous()
+    if z.dim() != 1 or z.dtype != torch.float64 or not z.is_cuda:
+        from .coupler import endrun
+        endrun("ERROR: supercell_init: vert_interface must be a 1-D fp64 device array")
+    nz = z.numel() - 1
+    cols = [torch.empty(nz, dtype=torch.float64, device=z.device) for _ in range(6)]
+    with torch.cuda.device(z.device):
+        check(lib.pam_amd_supercell_init(nz, z.data_ptr(), float(R_d), float(R_v), float(grav), *[c.data_ptr() for c in cols],
+                                         torch.cuda.current_stream(z.device).cuda_stream))
+    return tuple(cols)

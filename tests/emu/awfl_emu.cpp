@@ -24,7 +24,7 @@ struct Emu {
   int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
 };
 
-static void flux_launch(Emu *h, const double *prim, int sweeps = 7) {
+static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = false) {
   const Params &P = h->P;
   for (int dir = 0; dir < 3; dir++) {
     if (dir == 1 && P.sim2d) continue;
@@ -34,6 +34,7 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7) {
     // span as in awfl_kernels.hip::choose_span with an override (h->span; 0 = whole line)
     const int pieces = (nfaces + FLUX_MAX_SPAN - 1) / FLUX_MAX_SPAN;
     int span = h->span > 0 ? (h->span < FLUX_MAX_SPAN ? h->span : FLUX_MAX_SPAN) : (nfaces + pieces - 1) / pieces;
+    if (diff && dir == 1) span = nfaces;                 // difference form: periodic lines are swept whole
     const int nspan = (nfaces + span - 1) / span;
     double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());
     // one wavefront per (line, block of 64 members, span); lanes = members
@@ -42,14 +43,14 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7) {
         for (int e = 0; e < P.nens; e++) {
           const int f0 = sp * span;
           if (dir == 0) {
-            if (P.vz_per_ens) flux_line_body<0, true>(P, prim, fl, line, e, f0, span);
-            else flux_line_body<0, false>(P, prim, fl, line, e, f0, span);
+            if (P.vz_per_ens) flux_line_body<0, true, false>(P, prim, fl, line, e, f0, span);
+            else flux_line_body<0, false, false>(P, prim, fl, line, e, f0, span);
           } else if (dir == 1) {
-            if (P.vz_per_ens) flux_line_body<1, true>(P, prim, fl, line, e, f0, span);
-            else flux_line_body<1, false>(P, prim, fl, line, e, f0, span);
+            if (P.vz_per_ens) { if (diff) flux_line_body<1, true, true>(P, prim, fl, line, e, f0, span); else flux_line_body<1, true, false>(P, prim, fl, line, e, f0, span); }
+            else { if (diff) flux_line_body<1, false, true>(P, prim, fl, line, e, f0, span); else flux_line_body<1, false, false>(P, prim, fl, line, e, f0, span); }
           } else {
-            if (P.vz_per_ens) flux_line_body<2, true>(P, prim, fl, line, e, f0, span);
-            else flux_line_body<2, false>(P, prim, fl, line, e, f0, span);
+            if (P.vz_per_ens) { if (diff) flux_line_body<2, true, true>(P, prim, fl, line, e, f0, span); else flux_line_body<2, true, false>(P, prim, fl, line, e, f0, span); }
+            else { if (diff) flux_line_body<2, false, true>(P, prim, fl, line, e, f0, span); else flux_line_body<2, false, false>(P, prim, fl, line, e, f0, span); }
           }
         }
   }
@@ -194,9 +195,9 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     // poison the x fluxes of the state: the fused stage must not read them
     for (int ic = 0; ic < ncycles; ic++) {
       std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);   // (field 0 is re-used as the x-sweep's own scratch)
-      flux_launch(h, A, 6); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt); trupd_launch<1>(h, A, A, B, dt);
-      flux_launch(h, B, 6); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt); trupd_launch<2>(h, B, A, C, dt);
-      flux_launch(h, C, 6); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt); trupd_launch<3>(h, C, A, B, dt);
+      flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt); trupd_launch<1>(h, A, A, B, dt);
+      flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt); trupd_launch<2>(h, B, A, C, dt);
+      flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt); trupd_launch<3>(h, C, A, B, dt);
       std::swap(A, B);
     }
     if (A != h->prim0.data()) h->prim0.swap(h->prim1);   // an odd number of sub-steps: the state sits in prim1

@@ -335,3 +335,18 @@ def test_long_run_parity_120_substeps():
         assert np.abs(got[k] - fo[k]).max() <= tol * np.abs(fo[k]).max(), k
     assert np.abs(got["tracers"][0] - fo["tracers"][0]).max() <= 1e-12 * np.abs(fo["tracers"][0]).max()
     dycore.finalize(coupler)
+
+
+def test_a_single_nan_cell_fails_the_step():
+    """The CFL reduction must not swallow a NaN (fmin() drops NaN operands): one bad cell anywhere in the ensemble makes
+    timeStep refuse to run instead of sub-cycling on a time step derived from the healthy cells."""
+    import torch
+    from pam_amd import PamAmdError
+    coupler, dycore, oracle, fo, names = _setup(70, 6, 3, 8, idz.TRACERS_NONE, idz.uniform_interfaces(8, 8000.0))
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    assert dycore.compute_time_step(coupler) > 0
+    coupler.dm.get("temp")[5, 1, 3, 67] = float("nan")
+    assert dycore.compute_time_step(coupler) == 0.0
+    with pytest.raises(PamAmdError):
+        dycore.timeStep(coupler)
+    dycore.finalize(coupler)

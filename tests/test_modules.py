@@ -260,3 +260,23 @@ def test_gpu_broadcast_and_perturb_match_oracle():
     assert np.abs(got - gcm["gcm_temp"][:, None, None, :]).max() > 0.1
     with pytest.raises(Exception):
         modules.perturb_temperature(coupler, ids[:-1], 0.25)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", ["L60", "uniform40"])
+def test_driver_supercell_column_matches_oracle(grid):
+    """supercell_init of the standalone driver (standalone/mmf_simplified/supercell_init.h:7-135) as a device kernel against
+    the oracle's restatement: exp/pow of the device libm vs glibc -> 1e-13 relative to the column maximum."""
+    import torch
+    from oracle import awfl_oracle as ao
+    from pam_amd import modules
+    zint = idz.l60_interfaces() if grid == "L60" else idz.uniform_interfaces(40, 20000.0)
+    c = idz.CONSTS_DEFAULT
+    got = modules.supercell_init(torch.from_numpy(np.ascontiguousarray(zint)).to("cuda:0"), c["R_d"], c["R_v"], c["grav"])
+    torch.cuda.synchronize()
+    exp = ao.supercell_init(zint, c)
+    for name, g, e in zip(("rho_d", "uvel", "vvel", "wvel", "temp", "rho_v"), got, exp):
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all(), name
+        assert np.abs(g - e).max() <= 1e-13 * max(np.abs(e).max(), 1e-300), (name, np.abs(g - e).max())
+    assert exp[5].max() > 0 and exp[0][0] > 1.0      # a moist, ground-based column

@@ -13,12 +13,10 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("awfl_flux_kernel", "awfl_update_kernel<1>", "awfl_update_kernel<2>", "awfl_update_kernel<3>",
-              "awfl_fct_kernel", "awfl_init_prim_kernel", "awfl_finalize_kernel", "awfl_cfl_kernel", "awfl_hydro_kernel",
-              "awfl_stage_kernel", "awfl_update_kernel_kt"):
-        if k in name:
-            return k
-    return None
+    """awfl_flux_kernel<false, true>(...) -> awfl_flux_kernel<false, true>; other kernels (torch fills etc.) are skipped"""
+    import re
+    m = re.search(r"(awfl_\w+_kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else None
 
 
 def main():
@@ -38,7 +36,7 @@ def main():
                 extra = "  = %.3f GB/launch" % (mean * 1024 / 1e9)
                 if c == "FETCH_SIZE":
                     extra += "  (x2 gfx950 correction: %.3f GB)" % (2 * mean * 1024 / 1e9)
-            print("%-26s %-22s n=%4d mean=%.6g%s" % (k, c, len(v), mean, extra))
+            print("%-34s %-22s n=%4d mean=%.6g%s" % (k, c, len(v), mean, extra))
     for k in sorted(acc):
         a = acc[k]
         if "GRBM_GUI_ACTIVE" in a and "SQ_INSTS_VALU" in a:
@@ -46,14 +44,32 @@ def main():
             # 256 CUs x 4 SIMDs
             cyc = sum(a["GRBM_GUI_ACTIVE"]) / len(a["GRBM_GUI_ACTIVE"]) / 8.0
             inst = sum(a["SQ_INSTS_VALU"]) / len(a["SQ_INSTS_VALU"])
-            print("%-26s derived: %.3g busy cycles per XCD, VALU issue occupancy (4 cycles per wave-instruction, 1024 SIMDs) = %.1f %%"
+            print("%-34s derived: %.3g busy cycles per XCD, VALU issue occupancy (4 cycles per wave-instruction, 1024 SIMDs) = %.1f %%"
                   % (k, cyc, 100.0 * inst * 4.0 / (cyc * 1024.0)))
-    if "--flux-json" in sys.argv and "awfl_flux_kernel" in acc:
-        import json
-        f = acc["awfl_flux_kernel"]
-        fetch = sum(f["FETCH_SIZE"]) / len(f["FETCH_SIZE"]) * 1024 * 2      # gfx950: x2 (calibrated)
-        write = sum(f["WRITE_SIZE"]) / len(f["WRITE_SIZE"]) * 1024
-        print(json.dumps({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write,
+    for k in sorted(acc):
+        a = acc[k]
+        if "SQ_WAVE_CYCLES" in a and "SQ_WAIT_ANY" in a:
+            m = {c: sum(v) / len(v) for c, v in a.items()}
+            wc = m["SQ_WAVE_CYCLES"]
+            print("%-34s wave-cycle split: waiting (s_waitcnt/barrier) %.1f %%, issue-stalled %.1f %%, issuing %.1f %%"
+                  % (k, 100 * m["SQ_WAIT_ANY"] / wc, 100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * m.get("SQ_ACTIVE_INST_ANY", 0) / wc))
+    if "--traffic-json" in sys.argv:
+        # HBM bytes per launch of every stage kernel: FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated on
+        # kernels of known byte counts) + WRITE_SIZE; template instances of one kernel are averaged
+        import json, re
+        out = {}
+        for k in acc:
+            if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+                base = re.sub(r"<.*", "", k)
+                f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
+                out.setdefault(base, []).append((sum(f) * 1024 * 2, sum(w) * 1024, len(f)))
+        res = {}
+        for base, rows in out.items():
+            n = sum(r[2] for r in rows)
+            fetch, write = sum(r[0] for r in rows) / n, sum(r[1] for r in rows) / n
+            res[base] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "launches": n}
+        i = sys.argv.index("--traffic-json")
+        print(json.dumps({"csrc_hash": sys.argv[i + 1], "kernels": res,
                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --chunks 1, config c2"}))
 
 
