@@ -55,7 +55,7 @@ CONFIGS = {
     "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
     "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
 }
-STAGE_KERNELS = ("flux", "xupd", "fct_mult", "trupd", "update")
+STAGE_KERNELS = ("flux", "xupd", "xtr", "fct_mult", "trupd", "update")
 
 
 def csrc_hash():

@@ -129,7 +129,7 @@ int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_aw
 /* Enable HIP-event timing of every kernel launch on the handle's stream (off by default: zero overhead). */
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
 /* Accumulated device time (ms) and launch count of kernel `name` ("flux","fct_mult","update","init_prim",
- * "finalize","cfl","hydro","xupd","trupd") since the last reset; synchronises the stream. */
+ * "finalize","cfl","hydro","xupd","xtr","trupd") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 /* flux-kernel tuning knobs; results do not depend on them.

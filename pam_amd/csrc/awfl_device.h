@@ -937,8 +937,9 @@ PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_
   const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
   tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
   // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
-  store_rho_pres(P, prim_out, c.k, c2, c.e, rho_new, prim_out[P_THETA * P.prim_fs + o], prim_out[P_PRES * P.prim_fs + o],
-                 !P.grav_balance);
+  // (theta is needed for the density/pressure ghosts only, i.e. on the two boundary levels)
+  const double th = (c.k == 0 || c.k == P.nz - 1) ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
+  store_rho_pres(P, prim_out, c.k, c2, c.e, rho_new, th, prim_out[P_PRES * P.prim_fs + o], !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -997,6 +998,66 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   store_adv(P, prim_out, P_THETA, k, c2, th, th);
 }
 
+// x flux of NF tracers (advected-field indices fa[0..NF): 4 = tracer 0, 5 = tracer 1, ...) along one periodic x line,
+// upwinded by the face mass flux the fused state pass left in flux_x field 0 (Dycore.h:367-385).  One polynomial per cell.
+template <int NF>
+PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, double *__restrict__ fx, int line, int e,
+                           const int *fa) {
+  static_assert(FLUX_NF == 2, "tracers are swept in pairs");
+  const unsigned eu = member_offset(e);
+  const WenoConsts wc = weno_consts();
+  const int nx = P.nx;
+  const int k = uni_int(line / P.ny), j = line - k * P.ny;
+  const long long cu0 = (long long)j * P.sy;
+  const long long pbase = (long long)(k + HS) * P.sz + cu0, fbase = (long long)k * P.sz + cu0;
+  const double *ruf_line = fx + fbase;
+  auto cell_off = [&](int c) -> long long { return pbase + (long long)(c < 0 ? c + nx : (c >= nx ? c - nx : c)) * P.sx; };
+  const double *q[NF];
+  double *fl[NF];
+  double w[NF][5], prevR[NF];
+#pragma unroll
+  for (int n = 0; n < NF; n++) {
+    q[n] = prim_in + (long long)(P_U + fa[n]) * P.prim_fs;
+    fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
+  }
+#pragma unroll
+  for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
+    const long long o = cell_off(s - 3);
+#pragma unroll
+    for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
+  }
+  {                                                      // cell -1: only its right-edge value is needed (face 0)
+    const long long on = cell_off(2);
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+      double L;
+      weno5_const(w[n], wc, L, prevR[n]);
+#pragma unroll
+      for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+      w[n][4] = uni(q[n] + on)[eu];
+    }
+  }
+#pragma clang loop unroll(disable)
+  for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
+    const long long on = cell_off(c + 3);
+    double nq[NF], L[NF], R[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
+    const double ruf = uni(ruf_line + (long long)c * P.sx)[eu];
+#pragma unroll
+    for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
+    const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+      uniw(fl[n] + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
+      prevR[n] = R[n];
+#pragma unroll
+      for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
+      w[n][4] = nq[n];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // FUSED x-sweep: reconstruction + fluxes in x (as flux_line_body<0>) AND, in the same pass, the stage update of the five
 // state variables of every cell of the line (as update_body), with the y and z flux differences of the cell read from the
@@ -1024,10 +1085,11 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 // end of the sweep) and later passes re-read the stage-input density, so nothing may be updated in place.
 // Bit-for-bit the arithmetic of flux_line_body<0> + update_body (shared helpers above; tests/test_fused_stage.py).
 //   line   wave-uniform index of the x line: k * ny + j          e   ensemble member of this lane
+//   tracers_inline   sweep tracers 1.. here (else the caller launches awfl_xtr_kernel)
 template <int STAGE>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, int line, int e, double dt_dyn) {
+                               const double *__restrict__ fz, int line, int e, double dt_dyn, bool tracers_inline) {
   const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
   const int nx = P.nx;
@@ -1053,7 +1115,10 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     const double *pp = prim_in + (long long)P_PRES * P.prim_fs;
     const double *r0 = prim0 + (long long)P_RHO * P.prim_fs;
     double *out_rho = prim_out + (long long)P_RHO * P.prim_fs, *out_rt = prim_out + (long long)P_PRES * P.prim_fs;
-    double wm[5], wp[5], wq[NQ][5];
+    double wm[5], wp[5], wq[NQ][5], wt[5];                 // wt: tracer 0 (there is always one: water_vapor) rides along, flux only
+    const double *pt = prim_in + (long long)P_TR0 * P.prim_fs;
+    double *flt = fx + (long long)5 * P.ncell + fbase;     // x flux of tracer 0
+    const bool more_tracers = P.nt > 1;                    // the tracer sweeps below need the mass flux
     auto load_cell = [&](long long o, double &m, double &p, double (&qv)[NQ]) {
 #pragma unroll
       for (int n = 0; n < NQ; n++) qv[n] = uni(prim_in + (long long)(P_U + n) * P.prim_fs + o)[eu];
@@ -1066,23 +1131,26 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       load_cell(cell_off(s - 3), wm[s], wp[s], qv);
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][s] = qv[n];
+      wt[s] = uni(pt + cell_off(s - 3))[eu];
     }
-    double prevR_m, prevR_p, prevR_q[NQ];
+    double prevR_m, prevR_p, prevR_q[NQ], prevR_t;
     {                                                      // cell -1: only its right-edge values are needed (face 0)
       double L;
       weno5_const(wm, wc, L, prevR_m);
       weno5_const(wp, wc, L, prevR_p);
+      weno5_const(wt, wc, L, prevR_t);
 #pragma unroll
       for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, L, prevR_q[n]);
       double nm, np_, nq[NQ];
       load_cell(cell_off(2), nm, np_, nq);
+      const double nt0 = uni(pt + cell_off(2))[eu];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        wm[s] = wm[s + 1]; wp[s] = wp[s + 1];
+        wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wt[s] = wt[s + 1];
 #pragma unroll
         for (int n = 0; n < NQ; n++) wq[n][s] = wq[n][s + 1];
       }
-      wm[4] = nm; wp[4] = np_;
+      wm[4] = nm; wp[4] = np_; wt[4] = nt0;
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
@@ -1136,6 +1204,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
       double nm, np_, nq[NQ];
       load_cell(cell_off(c + 3), nm, np_, nq);
+      const double nt0 = uni(pt + cell_off(c + 3))[eu];
       CellIn ci;
       if (c > 0) load_in(c - 1, ci);                       // consumed at the bottom of this iteration
       double Lm, Rm, Lp, Rp, Lq[NQ], Rq[NQ];
@@ -1143,10 +1212,13 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       weno5_const(wp, wc, Lp, Rp);
 #pragma unroll
       for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, Lq[n], Rq[n]);
+      double Lt, Rt;
+      weno5_const(wt, wc, Lt, Rt);
       double ruf, ppf, F[1 + NQ];
       acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
-      uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;      // for the tracer sweeps
+      if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
       const bool up = ruf > 0.0;                             // upwind (Dycore.h:368)
+      uniw(flt + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR_t : Lt);
       F[0] = ruf;
       F[1] = fma(ruf, up ? prevR_q[0] : Lq[0], ppf);
 #pragma unroll
@@ -1159,16 +1231,16 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       }
 #pragma unroll
       for (int l = 0; l <= NQ; l++) F_prev[l] = F[l];
-      prevR_m = Rm; prevR_p = Rp;
+      prevR_m = Rm; prevR_p = Rp; prevR_t = Rt;
 #pragma unroll
       for (int n = 0; n < NQ; n++) prevR_q[n] = Rq[n];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        wm[s] = wm[s + 1]; wp[s] = wp[s + 1];
+        wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wt[s] = wt[s + 1];
 #pragma unroll
         for (int n = 0; n < NQ; n++) wq[n][s] = wq[n][s + 1];
       }
-      wm[4] = nm; wp[4] = np_;
+      wm[4] = nm; wp[4] = np_; wt[4] = nt0;
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
@@ -1179,64 +1251,16 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     }
   }
 
-  // ---------------- tracers: FLUX_NF per sweep, x flux stored (Dycore.h:367-385) ---------------------------------------
-  auto sweep = [&](auto nf_tag, const int *fa) {
-    constexpr int NF = decltype(nf_tag)::value;
-    const double *q[NF];
-    double *fl[NF];
-    double w[NF][5], prevR[NF];
-#pragma unroll
-    for (int n = 0; n < NF; n++) {
-      q[n] = prim_in + (long long)(P_U + fa[n]) * P.prim_fs;
-      fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
+  // ---------------- the other tracers (Dycore.h:367-385): inline here, or -- small ensembles, where a wavefront per line is
+  // too little parallelism for a chain this long -- by awfl_xtr_kernel, one wavefront per (line, pair of tracers)
+  if (tracers_inline) {
+    const int nadv = 4 + P.nt;
+    for (int a = 5; a < nadv; a += FLUX_NF) {              // tracer 0 went with the state pass
+      const int fa[2] = {a, a + 1};
+      if (a + 1 < nadv) x_tracer_sweep<2>(P, prim_in, fx, line, e, fa);
+      else x_tracer_sweep<1>(P, prim_in, fx, line, e, fa);
     }
-#pragma unroll
-    for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
-      const long long o = cell_off(s - 3);
-#pragma unroll
-      for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
-    }
-    {                                                      // cell -1: only its right-edge value is needed (face 0)
-      const long long on = cell_off(2);
-#pragma unroll
-      for (int n = 0; n < NF; n++) {
-        double L;
-        weno5_const(w[n], wc, L, prevR[n]);
-#pragma unroll
-        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
-        w[n][4] = uni(q[n] + on)[eu];
-      }
-    }
-#pragma clang loop unroll(disable)
-    for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
-      const long long on = cell_off(c + 3);
-      double nq[NF], L[NF], R[NF];
-#pragma unroll
-      for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
-      const double ruf = uni(ruf_line + (long long)c * P.sx)[eu];    // this lane's own store of the state pass
-#pragma unroll
-      for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
-      const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
-#pragma unroll
-      for (int n = 0; n < NF; n++) {
-        uniw(fl[n] + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
-        prevR[n] = R[n];
-#pragma unroll
-        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
-        w[n][4] = nq[n];
-      }
-    }
-  };
-  const int nadv = 4 + P.nt;
-  int fa[FLUX_NF], nfa = 0;
-  for (int a = 4; a < nadv; a++) {
-    fa[nfa++] = a;
-    if (nfa == FLUX_NF) { sweep(std::integral_constant<int, FLUX_NF>{}, fa); nfa = 0; }
   }
-  if (FLUX_NF >= 4 && nfa == 3) { sweep(std::integral_constant<int, 3>{}, fa); nfa = 0; }
-  if (FLUX_NF >= 3 && nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
-  if (nfa == 2) { sweep(std::integral_constant<int, 2>{}, fa); nfa = 0; }
-  if (nfa == 1) sweep(std::integral_constant<int, 1>{}, fa);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -128,13 +128,28 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
                                                                      const double *__restrict__ prim0,
                                                                      double *__restrict__ prim_out, double *__restrict__ fx,
                                                                      const double *__restrict__ fy,
-                                                                     const double *__restrict__ fz, double dt_dyn) {
+                                                                     const double *__restrict__ fz, double dt_dyn,
+                                                                     int tracers_inline) {
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int line = uni_int(u / nblk), blk = u - line * nblk;   // (the division runs on the vector unit)
   const int el = blk * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne)
-    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, dt_dyn);
+    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, dt_dyn, tracers_inline != 0);
+}
+// x fluxes of tracers 1.. for small ensembles: wave unit u -> (x line, member block, pair of tracers); after awfl_xupd_kernel.
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                               double *__restrict__ fx, int npairs) {
+  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
+  const int nblk = (R.ne + 63) >> 6;
+  const int grp = uni_int(u / npairs), pair = u - grp * npairs;
+  const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + (int)(threadIdx.x & 63);
+  if (line < P.nz * P.ny && el < R.ne) {
+    const int a = 5 + 2 * pair;                 // advected-field index of the pair's first tracer (tracer 0 rides with the state)
+    const int fa[2] = {a, a + 1};
+    if (a + 1 < 4 + P.nt) x_tracer_sweep<2>(P, prim_in, fx, line, R.e0 + el, fa);
+    else x_tracer_sweep<1>(P, prim_in, fx, line, R.e0 + el, fa);
+  }
 }
 // Tracer-only update after the fused x-sweep and the FCT multiplier (tracer_update_body).
 template <int STAGE>
@@ -462,10 +477,22 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
                 hipStream_t s) {
   const Params &P = h->P;
   const long long nunits = (long long)P.nz * P.ny * ((r.ne + 63) / 64);     // wavefronts: (x line, block of 64 members)
-  ScopedTimer st(h, "xupd", s);
-  hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), h->xupd_lds_bytes, s, P, r,
-                     prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn);
-  HIP_TRY(hipGetLastError());
+  // a wavefront sweeps its line once for the state and once per pair of further tracers, one after the other: when there
+  // are fewer wavefronts than the chip has slots, the tracer sweeps go to their own launch, one wavefront per pair
+  const int npairs = (P.nt - 1 + 1) / 2;
+  const bool split = npairs > 0 && nunits < 4096;
+  {
+    ScopedTimer st(h, "xupd", s);
+    hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), h->xupd_lds_bytes, s, P, r,
+                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn, split ? 0 : 1);
+    HIP_TRY(hipGetLastError());
+  }
+  if (split) {
+    ScopedTimer st(h, "xtr", s);
+    hipLaunchKernelGGL(awfl_xtr_kernel, dim3(nblocks(nunits * npairs, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                       h->flux_x, npairs);
+    HIP_TRY(hipGetLastError());
+  }
   return PAM_AMD_OK;
 }
 

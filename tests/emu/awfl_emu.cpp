@@ -74,7 +74,7 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
   const Params &P = h->P;
   for (int line = 0; line < P.nz * P.ny; line++)
     for (int e = 0; e < P.nens; e++)
-      flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, dt);
+      flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, dt, true);
 }
 template <int STAGE>
 static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {

@@ -21,7 +21,11 @@ def short(name):
 
 def main():
     acc = defaultdict(lambda: defaultdict(list))
-    for path in [a for a in sys.argv[1:] if not a.startswith('--')]:
+    args = sys.argv[1:]
+    if "--traffic-json" in args:   # the flag's value (content hash of pam_amd/csrc) is not a file
+        i = args.index("--traffic-json")
+        args = args[:i] + args[i + 2:]
+    for path in [a for a in args if not a.startswith('--')]:
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row["Kernel_Name"])
