@@ -509,7 +509,7 @@ PAMA_D int wrap(int c, int n) {
 // with vertical ghosts already filled (Dycore.h:662-710).
 template <int DIR, bool VZ_PER_ENS, bool DIFF>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
-                           int f0, int span) {
+                           int f0, int span, int pair_sel = -1) {
   const unsigned eu = member_offset(e);
   const LineGeom g = line_geom(P, DIR);
   const WenoConsts wc = weno_consts();
@@ -549,8 +549,10 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   const int nadv = 4 + P.nt;
   double *fl0 = flux + fbase;                                          // flux field 0 of this line: the face mass flux
 
+  // pair_sel: -1 = the whole sweep in this wavefront; 0 = pass 1 only; p >= 1 = only the p-th pair of advected fields (small
+  // ensembles: the passes of a sweep are spread over wavefronts, pass 1 in a launch of its own before the pairs)
   // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
-  {
+  if (pair_sel <= 0) {
     const double *pr = prim + (long long)P_RHO * P.prim_fs;
     const double *pn = prim + (long long)ncomp * P.prim_fs;
     const double *pp = prim + (long long)P_PRES * P.prim_fs;
@@ -680,13 +682,21 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     }
   };
   static_assert(FLUX_NF == 2, "the sweep dispatch is written for two fields per sweep");
-  int fa[FLUX_NF], nfa = 0;
+  if (pair_sel == 0) return;
+  int fa[FLUX_NF], nfa = 0, ipair = 0;
   for (int a = 0; a < nadv; a++) {
     if (P_U + a == ncomp) continue;
     fa[nfa++] = a;
-    if (nfa == FLUX_NF) { run(FLUX_NF, fa); nfa = 0; }
+    if (nfa == FLUX_NF) {
+      ipair++;
+      if (pair_sel < 0 || pair_sel == ipair) run(FLUX_NF, fa);
+      nfa = 0;
+    }
   }
-  if (nfa == 1) run(1, fa);
+  if (nfa == 1) {
+    ipair++;
+    if (pair_sel < 0 || pair_sel == ipair) run(1, fa);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -998,15 +1008,16 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   store_adv(P, prim_out, P_THETA, k, c2, th, th);
 }
 
-// x flux of NF tracers (advected-field indices fa[0..NF): 4 = tracer 0, 5 = tracer 1, ...) along one periodic x line,
+// x flux of NF tracers (advected-field indices fa[0..NF): 4 = tracer 0, 5 = tracer 1, ...) at the faces c0..c0+span-1 of one periodic x line,
 // upwinded by the face mass flux the fused state pass left in flux_x field 0 (Dycore.h:367-385).  One polynomial per cell.
 template <int NF>
 PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, double *__restrict__ fx, int line, int e,
-                           const int *fa) {
+                           int c0, int span, const int *fa) {
   static_assert(FLUX_NF == 2, "tracers are swept in pairs");
   const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
   const int nx = P.nx;
+  const int c1 = (c0 + span < nx) ? c0 + span : nx;      // faces c0 .. c1-1
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
   const long long cu0 = (long long)j * P.sy;
   const long long pbase = (long long)(k + HS) * P.sz + cu0, fbase = (long long)k * P.sz + cu0;
@@ -1021,13 +1032,13 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
     fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
   }
 #pragma unroll
-  for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
-    const long long o = cell_off(s - 3);
+  for (int s = 0; s < 5; s++) {                          // cells c0-3..c0+1: the window of cell c0-1
+    const long long o = cell_off(c0 - 3 + s);
 #pragma unroll
     for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
   }
-  {                                                      // cell -1: only its right-edge value is needed (face 0)
-    const long long on = cell_off(2);
+  {                                                      // cell c0-1: only its right-edge value is needed (face c0)
+    const long long on = cell_off(c0 + 2);
 #pragma unroll
     for (int n = 0; n < NF; n++) {
       double L;
@@ -1038,7 +1049,7 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
     }
   }
 #pragma clang loop unroll(disable)
-  for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
+  for (int c = c0; c < c1; c++) {                        // window = cells c-2..c+2
     const long long on = cell_off(c + 3);
     double nq[NF], L[NF], R[NF];
 #pragma unroll
@@ -1089,10 +1100,12 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
 template <int STAGE>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, int line, int e, double dt_dyn, bool tracers_inline) {
+                               const double *__restrict__ fz, int line, int e, int c0, int span, double dt_dyn,
+                               bool tracers_inline) {
   const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
   const int nx = P.nx;
+  const int c1 = (c0 + span < nx) ? c0 + span : nx;      // this wavefront owns the cells c0 .. c1-1 (faces c0 .. c1)
   const int k = uni_int(line / P.ny), j = line - k * P.ny;   // (integer division runs on the vector unit: re-assert uniformity)
   const long long cu0 = (long long)j * P.sy;                          // (j, i=0, member 0) inside a level
   const long long pbase = (long long)(k + HS) * P.sz + cu0;            // cell i=0 inside a prim field (uniform)
@@ -1126,15 +1139,15 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       p = uni(pp + o)[eu];
     };
 #pragma unroll
-    for (int s = 0; s < 5; s++) {                          // cells -3..1: the window of cell -1
+    for (int s = 0; s < 5; s++) {                          // cells c0-3..c0+1: the window of cell c0-1
       double qv[NQ];
-      load_cell(cell_off(s - 3), wm[s], wp[s], qv);
+      load_cell(cell_off(c0 - 3 + s), wm[s], wp[s], qv);
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][s] = qv[n];
-      wt[s] = uni(pt + cell_off(s - 3))[eu];
+      wt[s] = uni(pt + cell_off(c0 - 3 + s))[eu];
     }
     double prevR_m, prevR_p, prevR_q[NQ], prevR_t;
-    {                                                      // cell -1: only its right-edge values are needed (face 0)
+    {                                                      // cell c0-1: only its right-edge values are needed (face c0)
       double L;
       weno5_const(wm, wc, L, prevR_m);
       weno5_const(wp, wc, L, prevR_p);
@@ -1142,8 +1155,8 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, L, prevR_q[n]);
       double nm, np_, nq[NQ];
-      load_cell(cell_off(2), nm, np_, nq);
-      const double nt0 = uni(pt + cell_off(2))[eu];
+      load_cell(cell_off(c0 + 2), nm, np_, nq);
+      const double nt0 = uni(pt + cell_off(c0 + 2))[eu];
 #pragma unroll
       for (int s = 0; s < 4; s++) {
         wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wt[s] = wt[s + 1];
@@ -1154,9 +1167,9 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
-    double F_prev[1 + NQ], F_first[1 + NQ];                // face fluxes of rho, rho u, rho v, rho w, rho theta
+    double F_prev[1 + NQ];                                 // face fluxes of rho, rho u, rho v, rho w, rho theta
 #pragma unroll
-    for (int l = 0; l <= NQ; l++) { F_prev[l] = 0.0; F_first[l] = 0.0; }
+    for (int l = 0; l <= NQ; l++) F_prev[l] = 0.0;
     // everything cell cc needs besides its x fluxes
     // y0*/z0*: the two y / z faces of the mass flux; dy, dz: flux differences of the other variables (DIFF sweeps)
     struct CellIn { double rho_in, rho_0, q0[NQ], y0l, y0h, z0l, z0h, dy[1 + NQ], dz[1 + NQ]; };
@@ -1200,13 +1213,15 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         if (l == 4) uniw(out_rt + o)[eu] = v;
       }
     };
+    // Faces c0 .. c1: the last one closes the last cell.  It belongs to the next span (or is the periodic face nx == face 0)
+    // and is computed here a second time, with the same bits -- one polynomial set per span instead of a dependency.
 #pragma clang loop unroll(disable)
-    for (int c = 0; c < nx; c++) {                         // window = cells c-2..c+2
+    for (int c = c0; c <= c1; c++) {                       // window = cells c-2..c+2
       double nm, np_, nq[NQ];
       load_cell(cell_off(c + 3), nm, np_, nq);
       const double nt0 = uni(pt + cell_off(c + 3))[eu];
       CellIn ci;
-      if (c > 0) load_in(c - 1, ci);                       // consumed at the bottom of this iteration
+      if (c > c0) load_in(c - 1, ci);                      // consumed at the bottom of this iteration
       double Lm, Rm, Lp, Rp, Lq[NQ], Rq[NQ];
       weno5_const(wm, wc, Lm, Rm);
       weno5_const(wp, wc, Lp, Rp);
@@ -1216,19 +1231,16 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       weno5_const(wt, wc, Lt, Rt);
       double ruf, ppf, F[1 + NQ];
       acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
-      if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
       const bool up = ruf > 0.0;                             // upwind (Dycore.h:368)
-      uniw(flt + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR_t : Lt);
+      if (c < c1) {                                          // the faces this span owns
+        if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
+        uniw(flt + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR_t : Lt);
+      }
       F[0] = ruf;
       F[1] = fma(ruf, up ? prevR_q[0] : Lq[0], ppf);
 #pragma unroll
       for (int n = 1; n < NQ; n++) F[1 + n] = mul_rn(ruf, up ? prevR_q[n] : Lq[n]);
-      if (c == 0) {
-#pragma unroll
-        for (int l = 0; l <= NQ; l++) F_first[l] = F[l];
-      } else {
-        finish(c - 1, ci, F_prev, F, wm[1], wq[1][1], wq[2][1], wq[3][1]);   // window element 1 is cell c-1
-      }
+      if (c > c0) finish(c - 1, ci, F_prev, F, wm[1], wq[1][1], wq[2][1], wq[3][1]);   // window element 1 is cell c-1
 #pragma unroll
       for (int l = 0; l <= NQ; l++) F_prev[l] = F[l];
       prevR_m = Rm; prevR_p = Rp; prevR_t = Rt;
@@ -1244,11 +1256,6 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
-    {   // the periodic face nx is face 0; the window now holds cells nx-2..nx+2, element 1 is cell nx-1
-      CellIn ci;
-      load_in(nx - 1, ci);
-      finish(nx - 1, ci, F_prev, F_first, wm[1], wq[1][1], wq[2][1], wq[3][1]);
-    }
   }
 
   // ---------------- the other tracers (Dycore.h:367-385): inline here, or -- small ensembles, where a wavefront per line is
@@ -1257,8 +1264,8 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     const int nadv = 4 + P.nt;
     for (int a = 5; a < nadv; a += FLUX_NF) {              // tracer 0 went with the state pass
       const int fa[2] = {a, a + 1};
-      if (a + 1 < nadv) x_tracer_sweep<2>(P, prim_in, fx, line, e, fa);
-      else x_tracer_sweep<1>(P, prim_in, fx, line, e, fa);
+      if (a + 1 < nadv) x_tracer_sweep<2>(P, prim_in, fx, line, e, c0, span, fa);
+      else x_tracer_sweep<1>(P, prim_in, fx, line, e, c0, span, fa);
     }
   }
 }

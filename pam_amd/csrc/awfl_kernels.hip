@@ -58,6 +58,8 @@ struct FluxGrid {
   int nsx, nsy, nsz;        // spans per line
   int nux, nuy, nuz;        // work units (wavefronts) per sweep: lines x member blocks x spans
   int nbx_l, nby_l;         // x / y workgroups per vertical level when the two sweeps are interleaved level by level (else 0)
+  int part;                 // -1: whole sweeps per wavefront; 0: pass 1 only; 1: one pair of advected fields per wavefront
+  int npx, npy, npz;        // part == 1: pairs per sweep (the unit index carries the pair)
 };
 
 // DIFF (the fused stage's y/z sweeps): momentum and theta leave as per-cell flux differences (flux_line_body); there is no x
@@ -84,23 +86,26 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
   if (b < G.nbx) {
     const int u = b * FLUX_WAVES + wave;
     if (u < G.nux) {
-      const int grp = uni_int(u / G.nsx), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      const int up = (G.part == 1) ? uni_int(u / G.npx) : u, psel = (G.part == 1) ? 1 + (u - up * G.npx) : G.part;
+      const int grp = uni_int(up / G.nsx), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
       if (!DIFF && el < R.ne)
-        flux_line_body<0, VZ_PER_ENS, false>(P, prim, fx, line, R.e0 + el, (u - grp * G.nsx) * G.spx, G.spx);
+        flux_line_body<0, VZ_PER_ENS, false>(P, prim, fx, line, R.e0 + el, (up - grp * G.nsx) * G.spx, G.spx, psel);
     }
   } else if (b < G.nbx + G.nby) {
     const int u = (b - G.nbx) * FLUX_WAVES + wave;
     if (u < G.nuy) {
-      const int grp = uni_int(u / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      const int up = (G.part == 1) ? uni_int(u / G.npy) : u, psel = (G.part == 1) ? 1 + (u - up * G.npy) : G.part;
+      const int grp = uni_int(up / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
       if (el < R.ne)
-        flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, line, R.e0 + el, (u - grp * G.nsy) * G.spy, G.spy);
+        flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, line, R.e0 + el, (up - grp * G.nsy) * G.spy, G.spy, psel);
     }
   } else {
     const int u = (b - G.nbx - G.nby) * FLUX_WAVES + wave;
     if (u < G.nuz) {
-      const int grp = uni_int(u / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      const int up = (G.part == 1) ? uni_int(u / G.npz) : u, psel = (G.part == 1) ? 1 + (u - up * G.npz) : G.part;
+      const int grp = uni_int(up / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
       if (el < R.ne)
-        flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (u - grp * G.nsz) * G.spz, G.spz);
+        flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
     }
   }
 }
@@ -121,34 +126,38 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
   CellId c;
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
 }
-// Fused x-sweep + state update (flux_x_update_body): wave unit u -> (x line = u / nblk, member block = u % nblk); the 64
-// lanes are 64 consecutive members of ONE line, so every address is a wave-uniform base + member (scalar addressing).
+// Fused x-sweep + state update (flux_x_update_body): wave unit u -> (x line, member block, span of cells); the 64 lanes are
+// 64 consecutive members of ONE line, so every address is a wave-uniform base + member (scalar addressing).
 template <int STAGE>
 __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
                                                                      const double *__restrict__ prim0,
                                                                      double *__restrict__ prim_out, double *__restrict__ fx,
                                                                      const double *__restrict__ fy,
                                                                      const double *__restrict__ fz, double dt_dyn,
-                                                                     int tracers_inline) {
+                                                                     int tracers_inline, int span, int nspan) {
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
-  const int line = uni_int(u / nblk), blk = u - line * nblk;   // (the division runs on the vector unit)
+  const int grp = uni_int(u / nspan), sp = u - grp * nspan;
+  const int line = uni_int(grp / nblk), blk = grp - line * nblk;
   const int el = blk * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne)
-    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, dt_dyn, tracers_inline != 0);
+    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, sp * span, span, dt_dyn,
+                              tracers_inline != 0);
 }
-// x fluxes of tracers 1.. for small ensembles: wave unit u -> (x line, member block, pair of tracers); after awfl_xupd_kernel.
+// x fluxes of tracers 1.. for small ensembles: wave unit u -> (x line, member block, span, pair of tracers); after
+// awfl_xupd_kernel.
 __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                               double *__restrict__ fx, int npairs) {
+                                                               double *__restrict__ fx, int npairs, int span, int nspan) {
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
-  const int grp = uni_int(u / npairs), pair = u - grp * npairs;
+  const int g2 = uni_int(u / npairs), pair = u - g2 * npairs;
+  const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
   const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne) {
     const int a = 5 + 2 * pair;                 // advected-field index of the pair's first tracer (tracer 0 rides with the state)
     const int fa[2] = {a, a + 1};
-    if (a + 1 < 4 + P.nt) x_tracer_sweep<2>(P, prim_in, fx, line, R.e0 + el, fa);
-    else x_tracer_sweep<1>(P, prim_in, fx, line, R.e0 + el, fa);
+    if (a + 1 < 4 + P.nt) x_tracer_sweep<2>(P, prim_in, fx, line, R.e0 + el, sp * span, span, fa);
+    else x_tracer_sweep<1>(P, prim_in, fx, line, R.e0 + el, sp * span, span, fa);
   }
 }
 // Tracer-only update after the fused x-sweep and the FCT multiplier (tracer_update_body).
@@ -427,23 +436,35 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, G.spz, G.nsz);
   if (diff) { G.spy = P.ny; G.nsy = 1; }   // difference form: a periodic line is swept whole (its last cell needs face n == face 0)
   const long long nblk = (r.ne + 63) / 64;     // a wavefront = 64 consecutive members of ONE line
-  const long long ux = (sweeps & 1) ? (long long)P.nz * P.ny * nblk * G.nsx : 0;
-  const long long uy = (P.sim2d || !(sweeps & 2)) ? 0 : (long long)P.nz * P.nx * nblk * G.nsy;
-  const long long uz = (sweeps & 4) ? (long long)P.ny * P.nx * nblk * G.nsz : 0;
-  if (ux + uy + uz > 0x7fffffffll / 2) return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
-  G.nux = (int)ux; G.nuy = (int)uy; G.nuz = (int)uz;
-  G.nbx = (G.nux + FLUX_WAVES - 1) / FLUX_WAVES; G.nby = (G.nuy + FLUX_WAVES - 1) / FLUX_WAVES;
-  G.nbz = (G.nuz + FLUX_WAVES - 1) / FLUX_WAVES;
-  G.nbx_l = G.nby_l = 0;
-  if (h->interleave_xy && !P.sim2d && G.nux > 0 && G.nuy > 0 && G.nux % (FLUX_WAVES * P.nz) == 0 && G.nuy % (FLUX_WAVES * P.nz) == 0) {
-    G.nbx_l = G.nbx / P.nz;
-    G.nby_l = G.nby / P.nz;
-  }
-  if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
+  const long long nblk_all = (P.nens + 63) / 64;
+  const long long ux0 = (sweeps & 1) ? (long long)P.nz * P.ny * G.nsx : 0;
+  const long long uy0 = (P.sim2d || !(sweeps & 2)) ? 0 : (long long)P.nz * P.nx * G.nsy;
+  const long long uz0 = (sweeps & 4) ? (long long)P.ny * P.nx * G.nsz : 0;
+  // Small ensembles: a wavefront that sweeps its span for pass 1 and then for every pair of advected fields, one after the
+  // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
+  // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
+  const int npairs = (3 + P.nt + 1) / 2;       // advected fields besides the normal velocity: 3 + NT, two per sweep
+  const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < 8192;
+  const int nphase = two_phase ? 2 : 1;
+  if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
+    return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
   // the kernel uses no LDS; a dynamic LDS request only caps its residency per CU when other kernels should co-reside
   size_t lds_bytes = 0;
   if (h->chunks.size() > 1) lds_bytes = h->flux_lds_floor;
   ScopedTimer st(h, "flux", s);
+  for (int phase = 0; phase < nphase; phase++) {
+  G.part = two_phase ? phase : -1;
+  G.npx = G.npy = G.npz = npairs;
+  const long long mult = (G.part == 1) ? npairs : 1;
+  G.nux = (int)(ux0 * nblk * mult); G.nuy = (int)(uy0 * nblk * mult); G.nuz = (int)(uz0 * nblk * mult);
+  G.nbx = (G.nux + FLUX_WAVES - 1) / FLUX_WAVES; G.nby = (G.nuy + FLUX_WAVES - 1) / FLUX_WAVES;
+  G.nbz = (G.nuz + FLUX_WAVES - 1) / FLUX_WAVES;
+  G.nbx_l = G.nby_l = 0;
+  if (!two_phase && h->interleave_xy && !P.sim2d && G.nux > 0 && G.nuy > 0 && G.nux % (FLUX_WAVES * P.nz) == 0 && G.nuy % (FLUX_WAVES * P.nz) == 0) {
+    G.nbx_l = G.nbx / P.nz;
+    G.nby_l = G.nby / P.nz;
+  }
+  if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
   const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
 #define PAMA_LAUNCH_FLUX(VZ, DF)                                                                                        \
   hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
@@ -451,6 +472,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   else { if (diff) PAMA_LAUNCH_FLUX(false, true); else PAMA_LAUNCH_FLUX(false, false); }
 #undef PAMA_LAUNCH_FLUX
   HIP_TRY(hipGetLastError());
+  }
   return PAM_AMD_OK;
 }
 
@@ -476,21 +498,28 @@ template <int STAGE>
 int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
                 hipStream_t s) {
   const Params &P = h->P;
-  const long long nunits = (long long)P.nz * P.ny * ((r.ne + 63) / 64);     // wavefronts: (x line, block of 64 members)
-  // a wavefront sweeps its line once for the state and once per pair of further tracers, one after the other: when there
+  // wavefronts: (x line, block of 64 members, span of cells).  Normally a wavefront owns a whole line; when the ensemble alone
+  // does not fill the chip the lines are cut into spans (each recomputes its closing face) as choose_span decides from the
+  // WHOLE ensemble, so that results and schedule do not depend on the chunking
+  int span, nspan;
+  choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, span, nspan);
+  const long long nlb = (long long)P.nz * P.ny * ((r.ne + 63) / 64);
+  const long long nunits = nlb * nspan;
+  // a wavefront sweeps its cells once for the state and once per pair of further tracers, one after the other: when there
   // are fewer wavefronts than the chip has slots, the tracer sweeps go to their own launch, one wavefront per pair
   const int npairs = (P.nt - 1 + 1) / 2;
-  const bool split = npairs > 0 && nunits < 4096;
+  const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < 8192;
+  if (nunits * (split ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
   {
     ScopedTimer st(h, "xupd", s);
     hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), h->xupd_lds_bytes, s, P, r,
-                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn, split ? 0 : 1);
+                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn, split ? 0 : 1, span, nspan);
     HIP_TRY(hipGetLastError());
   }
   if (split) {
     ScopedTimer st(h, "xtr", s);
     hipLaunchKernelGGL(awfl_xtr_kernel, dim3(nblocks(nunits * npairs, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
-                       h->flux_x, npairs);
+                       h->flux_x, npairs, span, nspan);
     HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;

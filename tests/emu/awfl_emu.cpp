@@ -72,9 +72,11 @@ static void update_launch(Emu *h, const double *in, const double *p0, double *ou
 template <int STAGE>
 static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   const Params &P = h->P;
+  const int span = h->span > 0 ? h->span : P.nx, nspan = (P.nx + span - 1) / span;   // emu_set_span cuts the x lines too
   for (int line = 0; line < P.nz * P.ny; line++)
-    for (int e = 0; e < P.nens; e++)
-      flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, dt, true);
+    for (int sp = 0; sp < nspan; sp++)
+      for (int e = 0; e < P.nens; e++)
+        flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, sp * span, span, dt, true);
 }
 template <int STAGE>
 static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {

@@ -65,8 +65,9 @@ def test_emulated_kernels_match_oracle(case, fused):
         assert _rel(f2["tracers"][t], f1["tracers"][t]) < 1e-11
 
 
+@pytest.mark.parametrize("span", [0, 3], ids=["whole_lines", "spans_of_3"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
+def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span):
     """flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update + pressure must reproduce flux(x,y,z) -> FCT ->
     update exactly: same helpers, same rounding points (awfl_device.h: acoustic_face, flux_divergence, rk_combine...).
     Odd and even numbers of sub-steps exercise both parities of the three-buffer rotation."""
@@ -86,6 +87,8 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
         g = eh.EmuDycore(nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, consts=consts, seg=seg)
         g.set_grav_balance(mode_a)
         g.set_fused(fused)
+        if fused:
+            g.set_span(span)      # the fused x-sweep cut into spans (each recomputes its closing face) vs whole-line three-kernel stage
         g.declare_current_profile_as_hydrostatic(ff)
         ncyc = [g.time_step(ff, dt)[0] for dt in (2.0, 0.7, 2.0)]
         out.append((ncyc, ff))

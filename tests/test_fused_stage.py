@@ -18,7 +18,7 @@ CASES = {
     "2d_nt10_perens_p3": (70, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), True, True, idz.CONSTS_P3),
     "3d_minimal_3x3x3": (1, 3, 3, 3, idz.TRACERS_NONE, idz.uniform_interfaces(3, 3000.0), False, True, idz.CONSTS_DEFAULT),
     # >= 4096 (line, member block) wavefronts: the fused x-sweep keeps the tracer sweeps inline (smaller cases launch them apart)
-    "3d_nt4_many_lines_inline_tracers": (130, 8, 32, 60, idz.TRACERS_KESSLER_SHOC, idz.l60_interfaces(), False, True, idz.CONSTS_DEFAULT),
+    "3d_nt4_many_lines_inline_tracers": (140, 8, 32, 60, idz.TRACERS_KESSLER_SHOC, idz.l60_interfaces(), False, True, idz.CONSTS_DEFAULT),
     "3d_nx64_widest_fused_line": (2, 64, 3, 5, idz.TRACERS_NONE, idz.uniform_interfaces(5, 5000.0), False, True, idz.CONSTS_DEFAULT),
 }
 
