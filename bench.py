@@ -452,7 +452,7 @@ def main():
     ap.add_argument("--span", type=int, default=-1, help="flux-kernel faces per thread (default: automatic)")
     ap.add_argument("--chunks", type=int, default=-1, help="internal ensemble chunks / HIP streams (default: automatic)")
     ap.add_argument("--fused", type=int, default=-1, help="1/0: fused x-sweep stage / three-kernel stage (default: library default)")
-    ap.add_argument("--lds-floor", type=int, default=64 * 1024, help="flux-kernel LDS floor in bytes when chunks > 1")
+    ap.add_argument("--lds-floor", type=int, default=0, help="tuning: LDS request per flux workgroup when chunks > 1 (residency cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")

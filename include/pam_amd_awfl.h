@@ -132,21 +132,21 @@ int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
  * "finalize","cfl","hydro","xupd","xtr","trupd") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
-/* flux-kernel tuning knobs; results do not depend on them.
- *   segment: shortest span a line may be cut into when the ensemble alone does not fill the chip (default 8; 1..32)
- *   span:    faces swept by one thread, at most 32 = the thread's LDS slots (0 = automatic: the whole 32-cell line /
- *            half of a 61-face column when the ensemble fills the chip) */
+/* Sweep-kernel tuning knobs; results do not depend on them (bit for bit).
+ *   segment: shortest span (faces) a line may be cut into when the ensemble alone does not fill the chip (default 8; 1..64)
+ *   span:    faces swept by one wavefront (0 = automatic: the whole line, cut only for small ensembles; at most 64 per span) */
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
 int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
-/* Ensemble chunking inside one handle: the members are split into `chunks` contiguous ranges advanced on internal HIP
- * streams (forked from / joined to the handle's stream with events), so that the HBM-bound update kernels of one range
- * overlap the FP64-bound flux kernel of another.  chunks = 0: automatic (1-16, from the number of wavefronts a whole-ensemble flux launch has).
- * flux_lds_floor_bytes: minimum LDS requested per flux workgroup when chunks > 1 (caps its residency per CU so the
- * other range's blocks can co-reside; default 64 KiB = 2 workgroups per CU).  Results do not depend on either. */
+/* Ensemble ranges inside one handle: the members are split into `chunks` contiguous ranges advanced on internal HIP
+ * streams (forked from / joined to the handle's stream with events).  chunks = 0: automatic -- ONE range for the fused stage
+ * (its kernels gain nothing from sharing the chip); 1-16 for the three-kernel stage, whose HBM-bound
+ * update kernel overlaps the FP64-bound flux kernel of another range.  flux_lds_floor_bytes: dynamic LDS requested per flux
+ * workgroup when chunks > 1 (the kernel itself uses none: it caps the flux kernel's residency per CU so that another range's
+ * blocks can co-reside; default 0 = no cap).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
 
-/* Stage structure.  1 (default where supported: nx <= 64): per stage  flux(y,z) -> fused x-sweep + state update -> FCT
- * multiplier -> tracer update, the state's x fluxes never reach HBM.  0: flux(x,y,z) -> FCT multiplier ->
+/* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + state update -> FCT multiplier -> tracer update +
+ * pressure; the state's x fluxes never reach HBM.  0: flux(x,y,z) -> FCT multiplier ->
  * update, every face flux stored.  Both produce the same bits (tests/test_fused_stage.py). */
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
 

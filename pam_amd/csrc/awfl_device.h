@@ -1,6 +1,6 @@
 // awfl_device.h -- device-side arithmetic of the MI355X-native AWFL dycore step (gfx950, fp64).
 //
-// Kernel BODIES live here as device functions taking explicit (block, thread, LDS) coordinates; the
+// Kernel BODIES live here as device functions taking explicit (line / cell, member) coordinates; the
 // __global__ wrappers are in awfl_kernels.hip.  The same bodies are compiled by g++ into the host-side
 // emulation harness under tests/emu/ (test infrastructure only: it lets the index logic be checked against
 // the oracle without a GPU; the product library never contains or calls it).
@@ -60,7 +60,7 @@ struct Params {
   int sim2d;          // ny == 1 (Dycore.h:279)
   int grav_balance;   // option balance_hydrostasis_with_gravity (Dycore.h:284)
   int vz_per_ens;     // 0: vertical matrices identical for every ensemble member (wave-uniform table)
-  int seg;            // faces per flux-kernel chunk (LDS face slots per thread)
+  int seg;            // shortest span a sweep line may be cut into when the ensemble alone does not fill the chip
   double dx, dy, rdx, rdy;
   double C0, gamma, grav, R_d, R_v;
   long long sx, sy, sz;   // cell strides in doubles: nens, nx*nens, ny*nx*nens

@@ -285,10 +285,10 @@ struct KernelTimer {
 struct Chunk {
   EnsRange r;
   hipStream_t stream = nullptr;   // FCT/update/convert kernels (== the caller's stream when there is a single chunk)
-  hipStream_t fstream = nullptr;  // flux kernels: a separate HIGHER-priority stream.  The chain of flux kernels is the critical
-                                  // path of a stage (FP64-issue-bound, LDS-capped at two workgroups per CU); with priority its
-                                  // workgroups are replaced as soon as they retire and the HBM-bound FCT/update blocks of the
-                                  // previous chunk fill the remaining wave slots (measured +4 % over the opposite order)
+  hipStream_t fstream = nullptr;  // flux kernels (three-kernel stage) / both polynomial kernels (fused stage, chunk 0's is shared):
+                                  // a separate HIGHER-priority stream.  The chain of flux kernels is the critical path of a
+                                  // three-kernel stage (FP64-issue-bound); with priority its workgroups are replaced as soon
+                                  // as they retire and the HBM-bound FCT/update blocks of the previous chunk fill what is left
   hipEvent_t done = nullptr;      // end of this chunk's work in a timeStep (join)
   hipEvent_t flux_done = nullptr; // end of this chunk's most recent flux kernel
   hipEvent_t upd_done = nullptr;  // end of this chunk's most recent update (or init) kernel
@@ -316,10 +316,9 @@ struct pam_amd_awfl {
   int chunks_requested = 0;    // 0: automatic
   bool use_priorities = true;  // flux streams get the device's highest stream priority (see Chunk)
   bool interleave_xy = true;
-  bool fused = false;          // fused x-sweep + state update (needs prim2 and nx LDS slots per thread)
+  bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
   bool fused_supported = false;
-  size_t xupd_lds_bytes = 0;   // dynamic LDS requested by the fused x-sweep: it uses none; a residency cap for tuning
-  size_t flux_lds_floor = 0;   // minimum dynamic LDS per flux workgroup (caps flux residency per CU when chunks overlap)
+  size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
@@ -512,7 +511,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   if (nunits * (split ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
   {
     ScopedTimer st(h, "xupd", s);
-    hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), h->xupd_lds_bytes, s, P, r,
+    hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
                        prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn, split ? 0 : 1, span, nspan);
     HIP_TRY(hipGetLastError());
   }

@@ -213,7 +213,7 @@ class Dycore:
     def set_flux_span(self, faces):
         check(self._lib.pam_amd_awfl_set_flux_span(self._h, int(faces)))
 
-    def set_ensemble_chunks(self, chunks, flux_lds_floor_bytes=64 * 1024):
+    def set_ensemble_chunks(self, chunks, flux_lds_floor_bytes=0):
         check(self._lib.pam_amd_awfl_set_ensemble_chunks(self._h, int(chunks), int(flux_lds_floor_bytes)))
 
     def set_fused_stage(self, enable):
