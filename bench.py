@@ -26,7 +26,7 @@ Extra objects on the JSON line:
                 launch / mean launch duration; one launch = one tendency stage over all cells = cells/3 cell-updates x
                 64*(5+NT) B.  Launch durations are measured live with HIP events on the stream the kernels
                 run on (inside libpam_amd_awfl.so: pam_amd_awfl_set_kernel_timing), in a separate un-timed pass.
-                `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command, valid only for the build they
+                `traffic` = HBM bytes per stage from rocprofv3 PMC passes of this command, valid only for the build they
                 were taken from (content hash of pam_amd/csrc; null when the sources have changed since).
                 `kernels` lists every stage kernel with the bytes it must itself move and its FP64 work.
   cpu_baseline  the CPU oracle (a port of the reference algorithm, oracle/awfl_oracle.c, OpenMP over the flux loop)
@@ -262,6 +262,12 @@ class Job:
         self.torch.cuda.empty_cache()
 
 
+def stage_count(timings):
+    """tendency stages in a timed pass: every stage has exactly one update-type launch"""
+    k = "xupd" if "xupd" in timings else "update"
+    return max(1, timings[k]["launches"])
+
+
 def stage_rooflines(job, alone):
     """Per-kernel accounting of one tendency stage (nothing co-running).  `own_bytes`: what the kernel must itself move given
     the kernel split -- every field it reads or writes, once (sub-step-start values are read in 2 of the 3 stages: x 2/3);
@@ -278,10 +284,10 @@ def stage_rooflines(job, alone):
     if fused:
         nyz = nall - 1                     # the flux kernel sweeps y (3-D only) and z: mass + tracers as faces, the rest as differences
         acct["flux"] = (nyz * (6 + nt) * pb + nyz * (5 + nt) * fb, cells * nyz * (6 + nt) * poly)
-        acct["xupd"] = ((6 + nt) * pb + (2.0 / 3.0) * 5 * pb + nyz * 5 * fb + 6 * pb + (1 + nt) * fb,
+        acct["xupd"] = ((6 + nt) * pb + (2.0 / 3.0) * 5 * pb + nyz * 5 * fb + 6 * pb + (nt + (1 if nt > 1 else 0)) * fb,
                         cells * ((6 + nt) * poly + 5 * 60.0))
         acct["fct_mult"] = (nt * (nall + 2) * fb, cells * nt * 20.0)
-        acct["trupd"] = (nt * (nall + 1) * fb + (nt + 1) * pb * (1 + 2.0 / 3.0) + 3 * pb + (nt + 1) * pb + nt * fb,
+        acct["trupd"] = (nt * (nall + 1) * fb + (nt + 1) * pb * (1 + 2.0 / 3.0) + 2 * pb + (nt + 1) * pb + nt * fb,
                          cells * (nt * 60.0 + 250.0))
     else:
         acct["flux"] = (nall * (6 + nt) * pb + nall * (5 + nt) * fb, cells * nall * (6 + nt) * poly)
@@ -289,11 +295,13 @@ def stage_rooflines(job, alone):
         acct["update"] = (nall * (5 + nt) * fb + (6 + nt) * pb * (1 + 2.0 / 3.0) + nt * fb + (6 + nt) * pb + nt * fb,
                           cells * ((5 + nt) * 60.0 + 250.0))
     out = []
+    nstage = stage_count(alone)
     for name, (nbytes, flops) in acct.items():
         if name not in alone:
             continue
-        s = alone[name]["avg_ms"] * 1e-3
-        out.append({"kernel": "awfl_%s_kernel" % name.replace("fct_mult", "fct"), "avg_launch_ms": alone[name]["avg_ms"],
+        s = alone[name]["total_ms"] / nstage * 1e-3
+        out.append({"kernel": "awfl_%s_kernel" % name.replace("fct_mult", "fct"), "ms_per_stage": alone[name]["total_ms"] / nstage,
+                    "launches_per_stage": alone[name]["launches"] / nstage,
                     "own_bytes_per_launch": nbytes, "own_GBps": nbytes / s / 1e9, "hbm_frac": nbytes / s / 1e9 / HBM_PEAK_GBS,
                     "fp64_flops_per_launch": flops, "fp64_TFLOPs": flops / s / 1e12,
                     "valu_frac": flops / s / 1e12 / FP64_VALU_PEAK_TFLOPS})
@@ -361,8 +369,9 @@ def worker(args):
         kernel_rooflines = stage_rooflines(job, alone)
         stage = [k for k in STAGE_KERNELS if k in alone]
         if stage:
+            nstage = stage_count(alone)
             dom = max(stage, key=lambda k: alone[k]["total_ms"])
-            avg_s = alone[dom]["avg_ms"] * 1e-3
+            avg_s = alone[dom]["total_ms"] / nstage * 1e-3    # per stage (the y and z sweeps are two launches of one kernel)
             alg_bytes = cells / 3.0 * 64.0 * (5 + nt)            # 64*(5+NT) B per cell-update, 1/3 per stage
             achieved = alg_bytes / avg_s / 1e9
             kname = "awfl_%s_kernel" % dom.replace("fct_mult", "fct")
@@ -372,22 +381,23 @@ def worker(args):
             if args.config == "c2" and args.nens == 0 and args.scaling == "weak" and os.path.exists(tpath):
                 prof = json.load(open(tpath))
                 if prof.get("csrc_hash") == csrc_hash() and kname in prof.get("kernels", {}):
-                    traffic = prof["kernels"][kname]["hbm_bytes_per_launch"]
+                    traffic = prof["kernels"][kname]["hbm_bytes_per_stage"]
                     tnote = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, this build (%s)" % prof["csrc_hash"]
                 else:
                     tnote = "profiles/r02_c2_traffic.json was measured on another build of pam_amd/csrc (or lacks this kernel): not reported"
             if traffic is not None:
                 for kr in kernel_rooflines:
                     if kr["kernel"] in prof["kernels"]:
-                        kr["traffic"] = prof["kernels"][kr["kernel"]]["hbm_bytes_per_launch"]
-            stage_ms = sum(alone[k]["avg_ms"] for k in stage)
+                        kr["traffic"] = prof["kernels"][kr["kernel"]]["hbm_bytes_per_stage"]
+            stage_ms = sum(alone[k]["total_ms"] for k in stage) / nstage
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,
-                        "avg_launch_ms": alone[dom]["avg_ms"], "alg_bytes_per_launch": alg_bytes,
+                        "ms_per_stage": alone[dom]["total_ms"] / nstage, "launches_per_stage": alone[dom]["launches"] / nstage,
+                        "alg_bytes_per_launch": alg_bytes,
                         "binding_roofline": "fp64-valu",
-                        "note": "one launch = one tendency stage of the whole ensemble, measured with --chunks 1 (nothing "
-                                "co-running); achieved = SURVEY 8d algorithmic bytes of a whole stage / this kernel's "
-                                "duration.  The kernel is FP64-VALU-bound (SURVEY F5), see `valu`; all stage kernels "
+                        "note": "per tendency stage of the whole ensemble (the y and z sweeps are two launches of this kernel), "
+                                "measured with one ensemble range (nothing co-running); achieved = SURVEY 8d algorithmic "
+                                "bytes of a whole stage / this kernel's time per stage.  The kernel is FP64-VALU-bound (SURVEY F5), see `valu`; all stage kernels "
                                 "back to back take %.2f ms" % stage_ms,
                         "stage_ms_back_to_back": stage_ms,
                         "stage_frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -68,10 +68,15 @@ def main():
                 f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
                 out.setdefault(base, []).append((sum(f) * 1024 * 2, sum(w) * 1024, len(f)))
         res = {}
+        nlaunch = {base: sum(r[2] for r in rows) for base, rows in out.items()}
+        # tendency stages in the profiled run: every stage has exactly one update-type launch
+        nstage = nlaunch.get("awfl_xupd_kernel") or nlaunch.get("awfl_update_kernel") or 1
         for base, rows in out.items():
-            n = sum(r[2] for r in rows)
-            fetch, write = sum(r[0] for r in rows) / n, sum(r[1] for r in rows) / n
-            res[base] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_x2_corrected": fetch, "write_bytes": write, "launches": n}
+            n = nlaunch[base]
+            fetch, write = sum(r[0] for r in rows), sum(r[1] for r in rows)
+            res[base] = {"hbm_bytes_per_launch": (fetch + write) / n, "launches": n, "launches_per_stage": n / nstage,
+                         "hbm_bytes_per_stage": (fetch + write) / nstage, "fetch_bytes_x2_corrected_per_stage": fetch / nstage,
+                         "write_bytes_per_stage": write / nstage}
         i = sys.argv.index("--traffic-json")
         print(json.dumps({"csrc_hash": sys.argv[i + 1], "kernels": res,
                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --chunks 1, config c2"}))
