@@ -213,7 +213,7 @@ class Job:
         self.coupler, self.dycore = coupler, dycore
 
     def one_step(self):
-        if self.world > 1:
+        if self.world > 1 or getattr(self, "sharded", False):
             return self.parallel.sharded_time_step(self.dycore, self.coupler)
         return self.dycore.timeStep(self.coupler)
 
@@ -341,16 +341,21 @@ def worker(args):
     backend = os.environ.get("PAM_AMD_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # PAM_AMD_DIST_SELFTEST=1: run the N>1 code path (process group, RCCL all-reduce of dt, barrier) with a single rank --
+    # the only way to exercise the RCCL calls on a 1-GPU box
+    selftest = world == 1 and os.environ.get("PAM_AMD_DIST_SELFTEST") == "1"
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    dd = dist if world > 1 else None
+    dd = dist if (world > 1 or selftest) else None
 
     job = Job(args.config, args, dev, rank, world, args.nens)
+    job.sharded = dd is not None
     updates, elapsed, substeps = job.timed(args.steps, args.warmup, dd, backend, dev)
     value = updates / elapsed
     cells = job.nens * job.nz * job.ny * job.nx
@@ -446,7 +451,7 @@ def worker(args):
                "other_configs": others}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if dd is not None:
         dist.destroy_process_group()
 
 
