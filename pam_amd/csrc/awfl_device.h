@@ -381,10 +381,14 @@ PAMA_D double flux_divergence_d(const Params &P, double xlo, double xhi, double 
 }
 
 // gravity source of the vertical momentum (Dycore.h:562-566): mode A -variable_gravity*rho, mode B -grav*(rho - hy_dens)
-PAMA_D double add_gravity(const Params &P, double tend, double rho_in, long long ke) {
+//   gcoef = gravity_coef(P, ke): the (level, member) entry the mode needs.  Sweeps that own a whole x line load it ONCE: inside the
+//   loop the compiler cannot hoist it (its stores may alias anything) and the load sits at the end of a dependency chain,
+//   where its full round trip -- behind every outstanding store -- stalls the wavefront once per cell.
+PAMA_D double gravity_coef(const Params &P, long long ke) { return P.grav_balance ? P.grav_var[ke] : P.hy_dens[ke]; }
+PAMA_D double add_gravity(const Params &P, double tend, double rho_in, double gcoef) {
 #pragma clang fp contract(off)
-  if (P.grav_balance) return fma(-P.grav_var[ke], rho_in, tend);
-  return fma(-P.grav, rho_in - P.hy_dens[ke], tend);
+  if (P.grav_balance) return fma(-gcoef, rho_in, tend);
+  return fma(-P.grav, rho_in - gcoef, tend);
 }
 
 // SSPRK3 combines (Dycore.h:162-221):
@@ -713,6 +717,7 @@ PAMA_D void store_adv(const Params &P, double *prim, int pf, int k, long long c2
 }
 
 // density and pressure of the cell + their hydrostatically extrapolated ghosts (Dycore.h:682-709)
+template <bool STORE_RHO = true>   // false: the interior density is already in place (the fused x-sweep wrote it)
 PAMA_D void store_rho_pres(const Params &P, double *prim, int k, long long c2, int e, double rho, double th,
                            double rho_theta, bool subtract_hy) {
 #pragma clang fp contract(off)
@@ -720,7 +725,7 @@ PAMA_D void store_rho_pres(const Params &P, double *prim, int k, long long c2, i
   const long long o = (long long)(k + HS) * P.sz + c2;
   double pres = P.C0 * pow(rho_theta, P.gamma);
   if (subtract_hy) pres -= P.hy_pres[(long long)k * P.nens + e];
-  fr[o] = rho;
+  if (STORE_RHO) fr[o] = rho;
   fp[o] = pres;
   const bool bot = (k == 0), top = (k == P.nz - 1);
   if (bot || top) {
@@ -949,7 +954,7 @@ PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_
   // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
   // (theta is needed for the density/pressure ghosts only, i.e. on the two boundary levels)
   const double th = (c.k == 0 || c.k == P.nz - 1) ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
-  store_rho_pres(P, prim_out, c.k, c2, c.e, rho_new, th, prim_out[P_PRES * P.prim_fs + o], !P.grav_balance);
+  store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, prim_out[P_PRES * P.prim_fs + o], !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -986,7 +991,7 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
     const double *sx_ = fx + (long long)l * P.ncell, *sy_ = fy + (long long)l * P.ncell, *sz_ = fz + (long long)l * P.fz_fs;
     const double ylo = P.sim2d ? 0.0 : sy_[idx], yhi = P.sim2d ? 0.0 : sy_[jp1];   // no y-flux array in 2-D
     double tend = flux_divergence(P, sx_[idx], sx_[ip1], ylo, yhi, sz_[idx], sz_[idx + P.sz], rdzk);
-    if (l == 3) tend = add_gravity(P, tend, rho_in, ke);
+    if (l == 3) tend = add_gravity(P, tend, rho_in, gravity_coef(P, ke));
     if (l == 2 && P.sim2d) tend = 0.0;
     const int pf = (l == 0) ? P_RHO : P_U + (l - 1);
     double m_in = prim_in[pf * P.prim_fs + o];
@@ -1113,6 +1118,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
   const long long jp1 = (j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy;   // offset of the (j+1) neighbour
   const long long ke = (long long)k * P.nens + e;
   const double rdzk = fast_rcp(P.dz[ke]);
+  const double gcoef = gravity_coef(P, ke);
   const bool have_y = !P.sim2d;
   double *ruf_line = fx + fbase;                                       // flux_x field 0 of this line: the mass flux
   // periodic wrap of c in [-3, nx+2] without a division (nx >= 3): stays on the scalar unit
@@ -1202,7 +1208,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       for (int n = 0; n < NQ; n++) {
         const int l = 1 + n;                               // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
         double tend = flux_divergence_d(P, Flo[l], Fhi[l], ci.dy[l], ci.dz[l], rdzk);
-        if (l == 3) tend = add_gravity(P, tend, ci.rho_in, ke);
+        if (l == 3) tend = add_gravity(P, tend, ci.rho_in, gcoef);
         if (l == 2 && P.sim2d) tend = 0.0;
         const double m_in = (n == 0) ? m_in_u : mul_rn(q_in[n], ci.rho_in);
         const double m_0 = (STAGE > 1) ? mul_rn(ci.q0[n], ci.rho_0) : 0.0;
@@ -1220,8 +1226,13 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       double nm, np_, nq[NQ];
       load_cell(cell_off(c + 3), nm, np_, nq);
       const double nt0 = uni(pt + cell_off(c + 3))[eu];
+      // consumed at the bottom of this iteration.  Loaded on EVERY trip, also the first one, which completes no cell (it
+      // loads cell c0's values, to be loaded again by the next trip): s_waitcnt vmcnt(N) is a static count of the memory
+      // operations that may still be outstanding, the compiler takes the minimum over all paths that reach the wait, and
+      // a first trip without these loads made that minimum 2-4 -- every trip then began by draining the previous trip's
+      // stores (seen in the ISA: vmcnt(4) right after the window loads, vmcnt(2) at the loop tail).
       CellIn ci;
-      if (c > c0) load_in(c - 1, ci);                      // consumed at the bottom of this iteration
+      load_in(c > c0 ? c - 1 : c0, ci);
       double Lm, Rm, Lp, Rp, Lq[NQ], Rq[NQ];
       weno5_const(wm, wc, Lm, Rm);
       weno5_const(wp, wc, Lp, Rp);

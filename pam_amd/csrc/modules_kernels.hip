@@ -67,7 +67,12 @@ __device__ __forceinline__ double kessler_velqr(double qr, double r, double rhal
   return 36.34 * pow(qr * r, 0.1364) * rhalf;   // :375, :449
 }
 
-// timeStep :167-174 + kessler "main 1" :369-386.  WRITE=false only evaluates the sedimentation time-step limit.
+// timeStep :167-174 + kessler "main 1" :369-386, in two forms.  WRITE=false only evaluates the sedimentation time-step
+// limit (:376-386, the input of the global minimum) and touches nothing; WRITE=true does the in-place conversions and
+// does not need the limit any more (the sub-cycle count is known by then).
+// The minimum: wavefront shuffle reduce, then an atomicMin ONLY when the wavefront's value undercuts what the slot already
+// holds -- ~1e6 wavefronts hammering one L2 address with unconditional atomics cost 11 ms at 1024 x 32x32x60, ten times
+// the kernel's HBM time; the plain load in front leaves a handful.
 template <bool WRITE>
 __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long ncol, int nens, double *rho_v, double *rho_c,
                                                            double *rho_r, const double *__restrict__ rho_dry, double *temp,
@@ -76,37 +81,41 @@ __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long nco
                                                            unsigned long long *dt_max_bits) {
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  double dt2d = dt;
-  bool have = false;
-  if (col < ncol) {
+  if (WRITE) {
+    if (col >= ncol) return;
+    const long long idx = (long long)k * ncol + col;
+    const double rho = rho_dry[idx];
+    const double rv = rho_v[idx], T = temp[idx];
+    const double pressure = R_d * rho * T + R_v * rv * T;
+    const double ex = pow(pressure / p0, R_d / cp_d);
+    rho_v[idx] = rv / rho;
+    rho_c[idx] = rho_c[idx] / rho;
+    rho_r[idx] = rho_r[idx] / rho;
+    temp[idx] = T / ex;
+    exner_out[idx] = ex;
+    if (k == 0) precl[col] = 0;
+    return;
+  }
+  // positive doubles order like their bit patterns; 0 = "this state is not usable" (NaN or negative fall speed), which
+  // wins every minimum and fails the host's "limit must be positive" test
+  unsigned long long bits = ~0ull;
+  if (col < ncol && k < nz - 1) {
     const long long idx = (long long)k * ncol + col;
     const int e = (int)(col % nens);
     const double rho = rho_dry[idx];
     const double qr = rho_r[idx] / rho;
     const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho_dry[col] / rho));
-    if (k < nz - 1) {
-      have = true;
-      if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
-    }
-    if (WRITE) {
-      const double rv = rho_v[idx], T = temp[idx];
-      const double pressure = R_d * rho * T + R_v * rv * T;
-      const double ex = pow(pressure / p0, R_d / cp_d);
-      rho_v[idx] = rv / rho;
-      rho_c[idx] = rho_c[idx] / rho;
-      rho_r[idx] = qr;
-      temp[idx] = T / ex;
-      exner_out[idx] = ex;
-      if (k == 0) precl[col] = 0;
-    }
+    double dt2d = dt;
+    if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
+    bits = (velqr >= 0 && dt2d > 0) ? (unsigned long long)__double_as_longlong(dt2d) : 0ull;
   }
-  // block minimum -> one atomic per wavefront (positive doubles order like their bit patterns)
-  unsigned long long bits = have ? (unsigned long long)__double_as_longlong(dt2d) : ~0ull;
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long o = __shfl_xor(bits, off);
     bits = o < bits ? o : bits;
   }
-  if ((threadIdx.x & 63) == 0 && bits != ~0ull) atomicMin(dt_max_bits, bits);
+  if ((threadIdx.x & 63) == 0 && bits != ~0ull &&
+      bits < __hip_atomic_load(dt_max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMin(dt_max_bits, bits);
 }
 
 // kessler "main 2" + "main 3" (:394-453) for all sub-cycles, then timeStep :243-250.  One thread marches one column
@@ -472,7 +481,6 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     n = (int)want;
     if (n < 1) n = 1;
   }
-  hipMemsetAsync(slot, 0x7f, 8, s);
   hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
                      rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
   hipLaunchKernelGGL(kessler_column_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
