@@ -854,10 +854,36 @@ PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row flags of the FCT multiplier.  The limiter acts in few cells (edges of clouds and rain shafts; never in a smooth positive
+// field such as water vapour), so `mult` is 1.0 almost everywhere -- and the tracer update would still read seven of them per
+// cell and tracer.  A *row* is (tracer, cell, block of 64 consecutive members), i.e. what one wavefront of the pointwise kernels
+// touches per access; flags[row] == seq says "some member of this row was limited by THIS stage's FCT kernel" (seq is the
+// stage's launch number, so the flags are never cleared).  The update loads a multiplier only from flagged rows and uses the
+// exact value 1.0 otherwise (F * 1.0 == F bitwise): same results, 7 loads per cell and tracer fewer almost everywhere.
+//   sparse_store   (FCT kernel) every wavefront of the launch IS one row (member range aligned to 64) and the caller does not
+//                  need a complete `mult`: an unflagged row's multipliers are not even stored.  Otherwise (ragged ranges, the
+//                  three-kernel stage, the host emulation) they are always stored.
+struct FctRows {
+  int *flags;          // (nt, nz, ny, nx, ceil(nens/64)); nullptr: no flags, every multiplier is stored and loaded
+  int seq;
+  int sparse_store;
+};
+PAMA_D long long fct_rows_per_tracer(const Params &P) { return (long long)P.nz * P.ny * P.nx * ((P.nens + 63) >> 6); }
+PAMA_D long long fct_row(const Params &P, int k, int j, int i, int e) {
+  return (((long long)k * P.ny + j) * P.nx + i) * ((P.nens + 63) >> 6) + (e >> 6);
+}
+PAMA_D bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(x) != 0;
+#else
+  return true;
+#endif
+}
+
 // FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
 PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const double *__restrict__ fy,
                           const double *__restrict__ fz, const double *__restrict__ seed, double *__restrict__ mult,
-                          double dt, const CellId &c) {
+                          const FctRows &rows, double dt, const CellId &c) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const double dzk = P.dz[(long long)k * P.nens + e];
@@ -876,7 +902,13 @@ PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const 
       double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
       if (mass_out > mass_available) m = mass_available / mass_out;
     }
-    mult[(long long)t * P.ncell + idx] = m;
+    bool store = true;
+    if (rows.flags) {
+      const bool limited = (m != 1.0);
+      if (limited) rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
+      if (rows.sparse_store) store = wave_any(limited);
+    }
+    if (store) mult[(long long)t * P.ncell + idx] = m;
   }
 }
 
@@ -898,8 +930,8 @@ PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
 template <int STAGE>
 PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
                                const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
-                               const double *__restrict__ mult, double *__restrict__ seed, double dt_dyn, const CellId &c,
-                               double rho_in, double rho_0, double rrho, double rdzk) {
+                               const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
+                               const CellId &c, double rho_in, double rho_0, double rrho, double rdzk) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
@@ -908,26 +940,62 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
   const long long im1 = idx + ((i == 0) ? (long long)(P.nx - 1) * P.sx : -P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
   const long long jm1 = idx + ((j == 0) ? (long long)(P.ny - 1) * P.sy : -P.sy);
+  // the same neighbours in units of flag rows (fct_row)
+  const long long nblk = (P.nens + 63) >> 6, row_c = fct_row(P, k, j, i, e);
+  const long long r_ip1 = (i == P.nx - 1) ? -(long long)(P.nx - 1) * nblk : nblk, r_im1 = (i == 0) ? (long long)(P.nx - 1) * nblk : -nblk;
+  const long long r_jp1 = ((j == P.ny - 1) ? -(long long)(P.ny - 1) : 1) * P.nx * nblk, r_jm1 = ((j == 0) ? (long long)(P.ny - 1) : -1) * P.nx * nblk;
+  const long long r_kz = (long long)P.ny * P.nx * nblk;
   for (int t = 0; t < P.nt; t++) {
     const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
     const double *tz = fz + (long long)(5 + t) * P.fz_fs;
     const double *mt = mult + (long long)t * P.ncell;
-    const double m_c = mt[idx];
-    double f_x = limited_flux(tx[idx], mt[im1], m_c, i == 0);
-    double f_xp1 = limited_flux(tx[ip1], m_c, mt[ip1], i == P.nx - 1);
+    // Multipliers of the cell and its six neighbours: loaded only when one of their rows was flagged by this stage's FCT
+    // kernel, else exactly 1.0.  ONE wave-uniform branch: the seven flags and every other input of the cell are requested
+    // first and are in flight together; in the (rare) flagged case all seven multipliers are loaded unconditionally and the
+    // ones from unflagged rows (possibly never written) are discarded by the select.
+    const bool zlo = (k > 0), zhi = (k < P.nz - 1);
+    double m_c = 1.0, m_im1 = 1.0, m_ip1 = 1.0, m_jm1 = 1.0, m_jp1 = 1.0, m_km1 = 1.0, m_kp1 = 1.0;
+    const double Fx = tx[idx], Fxp1 = tx[ip1], Fz = tz[idx], Fzp1 = tz[idx + P.sz];
+    const double Fy = P.sim2d ? 0.0 : ty[idx], Fyp1 = P.sim2d ? 0.0 : ty[jp1];
+    const int pf = P_TR0 + t;
+    const double q_in = prim_in[pf * P.prim_fs + o];
+    const double q_0 = (STAGE > 1) ? prim0[pf * P.prim_fs + o] : 0.0;
+    if (rows.flags) {
+      const int *fl = rows.flags + (long long)t * fct_rows_per_tracer(P) + row_c;
+      const int sq = rows.seq;
+      // all seven flags are requested unconditionally (no short-circuit: a guarded load is a branch with a full memory round
+      // trip behind it); in 2-D the y offsets are 0, at the walls the z offsets are clamped to the cell itself
+      const int a_c = fl[0], a_im1 = fl[r_im1], a_ip1 = fl[r_ip1], a_jm1 = fl[r_jm1], a_jp1 = fl[r_jp1];
+      const int a_km1 = fl[zlo ? -r_kz : 0], a_kp1 = fl[zhi ? r_kz : 0];
+      const bool g_c = (a_c == sq), g_im1 = (a_im1 == sq), g_ip1 = (a_ip1 == sq), g_jm1 = (a_jm1 == sq), g_jp1 = (a_jp1 == sq);
+      const bool g_km1 = zlo & (a_km1 == sq), g_kp1 = zhi & (a_kp1 == sq);
+      if (wave_any(g_c | g_im1 | g_ip1 | g_jm1 | g_jp1 | g_km1 | g_kp1)) {
+        const double l_c = mt[idx], l_im1 = mt[im1], l_ip1 = mt[ip1], l_jm1 = mt[jm1], l_jp1 = mt[jp1];
+        const double l_km1 = mt[zlo ? idx - P.sz : idx], l_kp1 = mt[zhi ? idx + P.sz : idx];
+        m_c = g_c ? l_c : 1.0; m_im1 = g_im1 ? l_im1 : 1.0; m_ip1 = g_ip1 ? l_ip1 : 1.0;
+        m_jm1 = g_jm1 ? l_jm1 : 1.0; m_jp1 = g_jp1 ? l_jp1 : 1.0;
+        m_km1 = g_km1 ? l_km1 : 1.0; m_kp1 = g_kp1 ? l_kp1 : 1.0;
+      }
+    } else {
+      m_c = mt[idx]; m_im1 = mt[im1]; m_ip1 = mt[ip1];
+      if (!P.sim2d) { m_jm1 = mt[jm1]; m_jp1 = mt[jp1]; }
+      if (zlo) m_km1 = mt[idx - P.sz];
+      if (zhi) m_kp1 = mt[idx + P.sz];
+    }
+    double f_x = limited_flux(Fx, m_im1, m_c, i == 0);
+    double f_xp1 = limited_flux(Fxp1, m_c, m_ip1, i == P.nx - 1);
     double f_y = 0.0, f_yp1 = 0.0;
     if (!P.sim2d) {
-      f_y = limited_flux(ty[idx], mt[jm1], m_c, j == 0);
-      f_yp1 = limited_flux(ty[jp1], m_c, mt[jp1], j == P.ny - 1);
+      f_y = limited_flux(Fy, m_jm1, m_c, j == 0);
+      f_yp1 = limited_flux(Fyp1, m_c, m_jp1, j == P.ny - 1);
     }
     // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
-    const double f_z = limited_flux(tz[idx], (k > 0) ? mt[idx - P.sz] : 1.0, m_c, false);
-    const double f_zp1 = limited_flux(tz[idx + P.sz], m_c, (k < P.nz - 1) ? mt[idx + P.sz] : 1.0, false);
+    const double f_z = limited_flux(Fz, m_km1, m_c, false);
+    const double f_zp1 = limited_flux(Fzp1, m_c, m_kp1, false);
     const double tend = flux_divergence(P, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, rdzk);
-    const int pf = P_TR0 + t;
-    const double m_in = mul_rn(prim_in[pf * P.prim_fs + o], rho_in);
+    const double m_in = mul_rn(q_in, rho_in);
     double m_0 = 0.0;
-    if (STAGE > 1) m_0 = mul_rn(prim0[pf * P.prim_fs + o], rho_0);
+    if (STAGE > 1) m_0 = mul_rn(q_0, rho_0);
     double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
     if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
     seed[(long long)t * P.ncell + idx] = next_seed<STAGE>(m_0, m_in, v);
@@ -941,8 +1009,8 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
 template <int STAGE>
 PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, const double *__restrict__ mult, double *__restrict__ seed,
-                               double dt_dyn, const CellId &c) {
+                               const double *__restrict__ fz, const double *__restrict__ mult, const FctRows &rows,
+                               double *__restrict__ seed, double dt_dyn, const CellId &c) {
   const long long c2 = (long long)c.j * P.sy + (long long)c.i * P.sx + c.e;
   const long long o = (long long)(c.k + HS) * P.sz + c2;
   const double rho_in = prim_in[P_RHO * P.prim_fs + o];
@@ -950,11 +1018,14 @@ PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_
   const double rho_new = prim_out[P_RHO * P.prim_fs + o];
   const double rrho = fast_rcp(rho_new);
   const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
-  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
   // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
-  // (theta is needed for the density/pressure ghosts only, i.e. on the two boundary levels)
+  // (theta is needed for the density/pressure ghosts only, i.e. on the two boundary levels).  Both are requested BEFORE the
+  // tracer update: its stores may alias prim_out, so the compiler would otherwise start these loads -- a second memory round
+  // trip in a kernel that is nothing but memory latency -- only after them.
   const double th = (c.k == 0 || c.k == P.nz - 1) ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
-  store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, prim_out[P_PRES * P.prim_fs + o], !P.grav_balance);
+  const double rho_theta = prim_out[P_PRES * P.prim_fs + o];
+  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
+  store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, rho_theta, !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -969,8 +1040,8 @@ PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_
 template <int STAGE>
 PAMA_D void update_body(const Params &P, const double *prim_in, const double *prim0,
                         double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
-                        const double *__restrict__ fz, const double *__restrict__ mult, double *__restrict__ seed,
-                        double dt_dyn, const CellId &c) {
+                        const double *__restrict__ fz, const double *__restrict__ mult, const FctRows &rows,
+                        double *__restrict__ seed, double dt_dyn, const CellId &c) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
@@ -1005,7 +1076,7 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   }
   const double rrho = fast_rcp(qs[0]);
   const double th = qs[4] * rrho;
-  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
+  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
   store_rho_pres(P, prim_out, k, c2, e, qs[0], th, qs[4], !P.grav_balance);
   store_adv(P, prim_out, P_U, k, c2, qs[1] * rrho, qs[1] * rrho);
   store_adv(P, prim_out, P_V, k, c2, qs[2] * rrho, qs[2] * rrho);

@@ -113,18 +113,18 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
 __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
-                                                       double dt) {
+                                                       FctRows rows, double dt) {
   CellId c;
-  if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, dt, c);
+  if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, rows, dt, c);
 }
 template <int STAGE>
 __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, const double *prim_in,
                                                           const double *prim0, double *prim_out,
                                                           const double *__restrict__ fx, const double *__restrict__ fy,
                                                           const double *__restrict__ fz, const double *__restrict__ mult,
-                                                          double *__restrict__ seed, double dt_dyn) {
+                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
   CellId c;
-  if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
+  if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c);
 }
 // Fused x-sweep + state update (flux_x_update_body): wave unit u -> (x line, member block, span of cells); the 64 lanes are
 // 64 consecutive members of ONE line, so every address is a wave-uniform base + member (scalar addressing).
@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(256) awfl_trupd_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ prim0, double *prim_out,
                                                          const double *__restrict__ fx, const double *__restrict__ fy,
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
-                                                         double *__restrict__ seed, double dt_dyn) {
+                                                         FctRows rows, double *__restrict__ seed, double dt_dyn) {
   CellId c;
-  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, seed, dt_dyn, c);
+  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c);
 }
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
@@ -310,6 +310,9 @@ struct pam_amd_awfl {
   double *act_grav_var = nullptr, *act_hy_dens = nullptr, *act_hy_pres = nullptr, *act_vert_s2c = nullptr, *act_vert_wrl = nullptr;
   size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
+  int *fct_flags = nullptr;     // row flags of the FCT multiplier (FctRows in awfl_device.h)
+  size_t n_fct_flags = 0;
+  int fct_seq = 0;              // launch number of the current stage's FCT kernel: the value a flag must hold to count
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
   int span_override = 0;       // 0: automatic flux-kernel span
@@ -475,10 +478,31 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   return PAM_AMD_OK;
 }
 
-int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s) {
+// Row flags of the stage that is being launched (FctRows).  next_fct_stage() is called ONCE per tendency stage, before the
+// stage's first FCT launch: every ensemble range of the stage then uses the same flag value.
+int next_fct_stage(pam_amd_awfl *h) {
+  if (h->fct_seq == 0x7fffffff) {   // wrap (once per 2^31 stages): drain everything, forget every flag
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(h->fct_flags, 0, h->n_fct_flags * sizeof(int)));
+    h->fct_seq = 0;
+  }
+  h->fct_seq++;
+  return PAM_AMD_OK;
+}
+// sparse_store: multipliers of unflagged rows are not stored (only the fused stage asks for it: the three-kernel stage
+// and the debug entries keep `mult` complete for the tests that read it); needs wavefront == row, i.e. a 64-aligned range
+FctRows fct_rows(const pam_amd_awfl *h, EnsRange r, bool sparse_store) {
+  FctRows rows;
+  rows.flags = h->fct_flags;
+  rows.seq = h->fct_seq;
+  rows.sparse_store = (sparse_store && r.e0 % 64 == 0 && r.ne % 64 == 0) ? 1 : 0;
+  return rows;
+}
+
+int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s, bool sparse_store = false) {
   ScopedTimer st(h, "fct_mult", s);
   hipLaunchKernelGGL(awfl_fct_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
-                     h->flux_z, h->seed, h->mult, dt);
+                     h->flux_z, h->seed, h->mult, fct_rows(h, r, sparse_store), dt);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -488,7 +512,7 @@ int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, d
                   hipStream_t s) {
   ScopedTimer st(h, "update", s);
   hipLaunchKernelGGL(awfl_update_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in,
-                     prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
+                     prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -529,7 +553,7 @@ int launch_trupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, do
                  hipStream_t s) {
   ScopedTimer st(h, "trupd", s);
   hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
-                     h->flux_x, h->flux_y, h->flux_z, h->mult, h->seed, dt_dyn);
+                     h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -633,6 +657,8 @@ void free_all(pam_amd_awfl *h) {
   }
   if (h->dt_bits) (void)hipFree(h->dt_bits);
   h->dt_bits = nullptr;
+  if (h->fct_flags) (void)hipFree(h->fct_flags);
+  h->fct_flags = nullptr;
 }
 
 }  // namespace
@@ -732,6 +758,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->flux_z, h->n_flux_z * 8));
   INIT_TRY(hipMalloc(&h->seed, h->n_seed * 8));
   INIT_TRY(hipMalloc(&h->mult, h->n_seed * 8));
+  h->n_fct_flags = (size_t)P.nt * (size_t)P.nz * P.ny * P.nx * (size_t)((P.nens + 63) / 64);   // FctRows: (nt, nz, ny, nx, blocks of 64 members)
+  INIT_TRY(hipMalloc(&h->fct_flags, h->n_fct_flags * sizeof(int)));
+  INIT_TRY(hipMemset(h->fct_flags, 0, h->n_fct_flags * sizeof(int)));
+  h->fct_seq = 0;
   INIT_TRY(hipMalloc(&h->dz, nzn * 8));
   INIT_TRY(hipMalloc(&h->grav_var, nzn * 8));
   INIT_TRY(hipMalloc(&h->hy_dens, nzn * 8));
@@ -951,7 +981,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
           HIP_TRY(hipEventRecord(c.flux_done, cs));
           HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
         }
-        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream))) return r2;
+        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream, true))) return r2;
         if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
         else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
         else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
@@ -981,20 +1011,26 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       double *A = h->prim0, *B = h->prim1, *C = h->prim2;
       if (h->fused) {
         // three rotating buffers: A (sub-step start) -> B -> C -> B; the new state B becomes prim0
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)   // stage 1 (Dycore.h:156-176)
           if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)   // stage 2 (Dycore.h:180-200)
           if ((rc = stage(c, 2, B, A, C, (1.0 / 4.0) * dt_dyn))) return rc;
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)   // stage 3 (Dycore.h:204-221)
           if ((rc = stage(c, 3, C, A, B, (2.0 / 3.0) * dt_dyn))) return rc;
         h->prim0 = B;
         h->prim1 = A;
       } else {
         // pointwise update kernel: stage 2 and 3 update in place
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)
           if ((rc = stage(c, 1, A, A, B, dt_dyn))) return rc;
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)
           if ((rc = stage(c, 2, B, A, B, (1.0 / 4.0) * dt_dyn))) return rc;
+        if ((rc = next_fct_stage(h))) return rc;
         for (auto &c : h->chunks)
           if ((rc = stage(c, 3, B, A, A, (2.0 / 3.0) * dt_dyn))) return rc;
       }
@@ -1164,7 +1200,8 @@ int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
   int rc;
   if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
   if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream))) return rc;
-  if ((rc = launch_fct(h, dt_dyn, r, h->stream))) return rc;
+  if ((rc = next_fct_stage(h))) return rc;
+  if ((rc = launch_fct(h, dt_dyn, r, h->stream, h->fused))) return rc;
   if (h->fused) rc = launch_trupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   else rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   if (rc) return rc;
@@ -1177,6 +1214,7 @@ int pam_amd_awfl_debug_flux_stage(pam_amd_awfl_t *h, double dt) {
   USE_DEVICE(h);
   int rc;
   if ((rc = launch_flux(h, h->prim0, full_range(h->P), h->stream))) return rc;
+  if ((rc = next_fct_stage(h))) return rc;
   return launch_fct(h, dt, full_range(h->P), h->stream);
 }
 

@@ -22,7 +22,15 @@ struct Emu {
   VerticalTables vt;
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
   int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
+  std::vector<int> fct_flags;   // row flags of the FCT multiplier (FctRows)
+  int fct_seq = 0;
 };
+
+static FctRows fct_rows(Emu *h) {
+  FctRows r;
+  r.flags = h->fct_flags.data(); r.seq = h->fct_seq; r.sparse_store = 0;
+  return r;
+}
 
 static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = false) {
   const Params &P = h->P;
@@ -56,15 +64,26 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
   }
 }
 
-static void fct_launch(Emu *h, double dt) {
-  for (long long idx = 0; idx < h->P.ncell; idx++)
-    fct_mult_body(h->P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), dt, cell_of(h->P, idx));
+// `sparse`: what the device does in the fused stage when a wavefront is a whole row -- the multipliers of a row no member of
+// which was limited are not stored.  Emulated by poisoning them: an update that loads one of them anyway produces NaN.
+static void fct_launch(Emu *h, double dt, bool sparse) {
+  const Params &P = h->P;
+  h->fct_seq++;
+  for (long long idx = 0; idx < P.ncell; idx++)
+    fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx));
+  if (!sparse) return;
+  const long long nrows = fct_rows_per_tracer(P);
+  for (int t = 0; t < P.nt; t++)
+    for (long long idx = 0; idx < P.ncell; idx++) {
+      const CellId c = cell_of(P, idx);
+      if (h->fct_flags[(size_t)t * nrows + fct_row(P, c.k, c.j, c.i, c.e)] != h->fct_seq) h->mult[(size_t)t * P.ncell + idx] = NAN;
+    }
 }
 
 template <int STAGE>
 static void update_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   for (long long idx = 0; idx < h->P.ncell; idx++)
-    update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt,
+    update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fct_rows(h), h->seed.data(), dt,
                        cell_of(h->P, idx));
 }
 
@@ -81,7 +100,7 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
 template <int STAGE>
 static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   for (long long idx = 0; idx < h->P.ncell; idx++)
-    tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), h->seed.data(), dt,
+    tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fct_rows(h), h->seed.data(), dt,
                               cell_of(h->P, idx));
 }
 
@@ -122,6 +141,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
   h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
   h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
+  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P), 0);
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();
@@ -181,7 +201,7 @@ void emu_convert_coupler_to_dynamics(Emu *h, double *rho_d, double *u, double *v
 
 void emu_flux_stage(Emu *h, double dt) {
   flux_launch(h, h->prim0.data());
-  fct_launch(h, dt);
+  fct_launch(h, dt, false);
 }
 
 int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers, double crm_dt,
@@ -197,18 +217,18 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     // poison the x fluxes of the state: the fused stage must not read them
     for (int ic = 0; ic < ncycles; ic++) {
       std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);   // (field 0 is re-used as the x-sweep's own scratch)
-      flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt); trupd_launch<1>(h, A, A, B, dt);
-      flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt); trupd_launch<2>(h, B, A, C, dt);
-      flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt); trupd_launch<3>(h, C, A, B, dt);
+      flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt, true); trupd_launch<1>(h, A, A, B, dt);
+      flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt, true); trupd_launch<2>(h, B, A, C, dt);
+      flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt, true); trupd_launch<3>(h, C, A, B, dt);
       std::swap(A, B);
     }
     if (A != h->prim0.data()) h->prim0.swap(h->prim1);   // an odd number of sub-steps: the state sits in prim1
     p0 = h->prim0.data();
   } else {
     for (int ic = 0; ic < ncycles; ic++) {
-      flux_launch(h, p0); fct_launch(h, dt); update_launch<1>(h, p0, p0, p1, dt);
-      flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt); update_launch<2>(h, p1, p0, p1, dt);
-      flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
+      flux_launch(h, p0); fct_launch(h, dt, false); update_launch<1>(h, p0, p0, p1, dt);
+      flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt, false); update_launch<2>(h, p1, p0, p1, dt);
+      flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt, false); update_launch<3>(h, p1, p0, p0, dt);
     }
   }
   TracerPtrs tp = tptrs(h, tracers);

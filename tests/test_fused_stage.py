@@ -20,6 +20,11 @@ CASES = {
     # >= 4096 (line, member block) wavefronts: the fused x-sweep keeps the tracer sweeps inline (smaller cases launch them apart)
     "3d_nt4_many_lines_inline_tracers": (140, 8, 32, 60, idz.TRACERS_KESSLER_SHOC, idz.l60_interfaces(), False, True, idz.CONSTS_DEFAULT),
     "3d_nx64_widest_fused_line": (2, 64, 3, 5, idz.TRACERS_NONE, idz.uniform_interfaces(5, 5000.0), False, True, idz.CONSTS_DEFAULT),
+    # member ranges aligned to 64: every wavefront of the pointwise kernels is one row of the FCT flags, and the multipliers
+    # of rows without a limited member are not even stored (FctRows, awfl_device.h); members differ (see _run), so flagged
+    # rows hold limited and unlimited members side by side
+    "3d_nt4_whole_flag_rows": (128, 6, 6, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, True, idz.CONSTS_DEFAULT),
+    "2d_nt10_whole_flag_rows": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), False, False, idz.CONSTS_P3),
 }
 
 
@@ -31,6 +36,13 @@ def _run(case, fused, chunks=0):
     ylen = ny * 500.0 if ny > 1 else xlen
     f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=0.5)
     idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if nens >= 64:      # every third member: blobs on a positive floor (the limiter stays idle there); every fifth: none at all
+        for t, (name, _, _) in enumerate(tr):
+            if name == "water_vapor":
+                continue
+            q = f["tracers"][t]
+            q[..., 1::3] = q[..., 1::3] + 2.0e-4 * f["density_dry"][..., 1::3]
+            q[..., 2::5] = 0.0
     zi = np.asarray(zint)[:, None] * np.ones((1, nens))
     if per_ens:
         zi = zi * (1 + 0.01 * np.arange(nens))[None, :]
@@ -69,6 +81,14 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
+def test_fct_flag_rows_are_chunking_invariant():
+    """ranges of 64 members each carry their own rows of FCT flags (awfl_kernels.hip: fct_rows) == one range"""
+    _, a = _run("3d_nt4_whole_flag_rows", fused=True, chunks=1)
+    _, b = _run("3d_nt4_whole_flag_rows", fused=True, chunks=2)
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.array_equal(a[k], b[k]), k
 
 
 def test_fused_stage_is_chunking_invariant():
