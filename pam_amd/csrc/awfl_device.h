@@ -863,8 +863,11 @@ PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, cons
 //   sparse_store   (FCT kernel) every wavefront of the launch IS one row (member range aligned to 64) and the caller does not
 //                  need a complete `mult`: an unflagged row's multipliers are not even stored.  Otherwise (ragged ranges, the
 //                  three-kernel stage, the host emulation) they are always stored.
+//   any            one more int: == seq when ANY row of any tracer was flagged in this stage (the fix-up launch of the NT=1
+//                  tail leaves at once when it is not)
 struct FctRows {
   int *flags;          // (nt, nz, ny, nx, ceil(nens/64)); nullptr: no flags, every multiplier is stored and loaded
+  int *any;
   int seq;
   int sparse_store;
 };
@@ -872,6 +875,8 @@ PAMA_D long long fct_rows_per_tracer(const Params &P) { return (long long)P.nz *
 PAMA_D long long fct_row(const Params &P, int k, int j, int i, int e) {
   return (((long long)k * P.ny + j) * P.nx + i) * ((P.nens + 63) >> 6) + (e >> 6);
 }
+// "some lane of this wavefront": for decisions to STORE something for the whole row (the host emulation, which runs lane by
+// lane, always stores) ...
 PAMA_D bool wave_any(bool x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __any(x) != 0;
@@ -879,33 +884,55 @@ PAMA_D bool wave_any(bool x) {
   return true;
 #endif
 }
+// ... and for decisions to SKIP work that is only needed by lanes with x (correct lane by lane, which is what the host
+// emulation does; the device takes one wave-uniform branch)
+PAMA_D bool wave_any_or_lane(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(x) != 0;
+#else
+  return x;
+#endif
+}
+
+// FCT multiplier of a positive-definite tracer in one cell (Dycore.h:533-540) from the mass seed and the six face fluxes:
+// 1 unless the fluxes leaving the cell in `dt` carry more than the mass available.
+PAMA_D double fct_multiplier(const Params &P, double seed_v, double xlo, double xhi, double ylo, double yhi, double zlo,
+                             double zhi, double dzk, double dt) {
+#pragma clang fp contract(off)
+  double mass_available = fmax(seed_v, 0.0) * P.dx * P.dy * dzk;
+  double flux_out_x = (fmax(xhi, 0.0) - fmin(xlo, 0.0)) / P.dx;
+  double flux_out_y = P.sim2d ? 0.0 : (fmax(yhi, 0.0) - fmin(ylo, 0.0)) / P.dy;
+  double flux_out_z = (fmax(zhi, 0.0) - fmin(zlo, 0.0)) / dzk;
+  double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
+  return (mass_out > mass_available) ? mass_available / mass_out : 1.0;
+}
 
 // FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
+//   t0   first tracer to do (1 when the fused x-sweep has already done tracer 0)
 PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const double *__restrict__ fy,
                           const double *__restrict__ fz, const double *__restrict__ seed, double *__restrict__ mult,
-                          const FctRows &rows, double dt, const CellId &c) {
+                          const FctRows &rows, double dt, const CellId &c, int t0 = 0) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const double dzk = P.dz[(long long)k * P.nens + e];
   const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
-  for (int t = 0; t < P.nt; t++) {
+  for (int t = t0; t < P.nt; t++) {
     double m = 1.0;
     if ((P.pos_mask >> t) & 1ull) {
       const double *tx = fx + (long long)(5 + t) * P.ncell;
       const double *ty = fy + (long long)(5 + t) * P.ncell;
       const double *tz = fz + (long long)(5 + t) * P.fz_fs;
-      double mass_available = fmax(seed[(long long)t * P.ncell + idx], 0.0) * P.dx * P.dy * dzk;
-      double flux_out_x = (fmax(tx[ip1], 0.0) - fmin(tx[idx], 0.0)) / P.dx;
-      double flux_out_y = P.sim2d ? 0.0 : (fmax(ty[jp1], 0.0) - fmin(ty[idx], 0.0)) / P.dy;
-      double flux_out_z = (fmax(tz[idx + P.sz], 0.0) - fmin(tz[idx], 0.0)) / dzk;
-      double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
-      if (mass_out > mass_available) m = mass_available / mass_out;
+      m = fct_multiplier(P, seed[(long long)t * P.ncell + idx], tx[idx], tx[ip1], P.sim2d ? 0.0 : ty[idx],
+                         P.sim2d ? 0.0 : ty[jp1], tz[idx], tz[idx + P.sz], dzk, dt);
     }
     bool store = true;
     if (rows.flags) {
       const bool limited = (m != 1.0);
-      if (limited) rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
+      if (limited) {
+        rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
+        *rows.any = rows.seq;
+      }
       if (rows.sparse_store) store = wave_any(limited);
     }
     if (store) mult[(long long)t * P.ncell + idx] = m;
@@ -923,6 +950,37 @@ PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
 
 
 
+// Is the cell's own flag row or one of its six neighbours' (tracer t) flagged by this stage's FCT pass?  All seven flags are
+// requested unconditionally (a guarded load is a branch with a full memory round trip behind it): in 2-D the y offsets are 0,
+// at the walls the z offsets are clamped to the cell itself.
+PAMA_D bool fct_flagged_near(const Params &P, const FctRows &rows, int t, int k, int j, int i, int e) {
+  const long long nblk = (P.nens + 63) >> 6;
+  const int *fl = rows.flags + (long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e);
+  const long long r_ip1 = (i == P.nx - 1) ? -(long long)(P.nx - 1) * nblk : nblk, r_im1 = (i == 0) ? (long long)(P.nx - 1) * nblk : -nblk;
+  const long long r_jp1 = ((j == P.ny - 1) ? -(long long)(P.ny - 1) : 1) * P.nx * nblk, r_jm1 = ((j == 0) ? (long long)(P.ny - 1) : -1) * P.nx * nblk;
+  const long long r_kz = (long long)P.ny * P.nx * nblk;
+  const bool zl = (k > 0), zh = (k < P.nz - 1);
+  const int sq = rows.seq;
+  const int a0 = fl[0], a1 = fl[r_im1], a2 = fl[r_ip1], a3 = fl[r_jm1], a4 = fl[r_jp1], a5 = fl[zl ? -r_kz : 0], a6 = fl[zh ? r_kz : 0];
+  return (a0 == sq) | (a1 == sq) | (a2 == sq) | (a3 == sq) | (a4 == sq) | (zl & (a5 == sq)) | (zh & (a6 == sq));
+}
+
+// New conserved value and next FCT seed of one tracer in one cell from its six (limited) face fluxes: divergence, SSPRK3
+// combine, clipping (Dycore.h:553-584, :162-221).  q_in / q_0: stage-input / sub-step-start mixing ratio (re-formed as (m/rho)*rho,
+// quirk Q5).
+template <int STAGE>
+PAMA_D void tracer_new_value(const Params &P, int t, double f_x, double f_xp1, double f_y, double f_yp1, double f_z, double f_zp1,
+                             double q_in, double q_0, double rho_in, double rho_0, double rdzk, double dt_dyn, double &v,
+                             double &new_seed) {
+  const double tend = flux_divergence(P, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, rdzk);
+  const double m_in = mul_rn(q_in, rho_in);
+  double m_0 = 0.0;
+  if (STAGE > 1) m_0 = mul_rn(q_0, rho_0);
+  v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+  if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
+  new_seed = next_seed<STAGE>(m_0, m_in, v);
+}
+
 // Tracer part of the stage update of one cell (Dycore.h:553-584 with the FCT-limited fluxes, :162-221): shared by the
 // one-kernel update (update_body) and by the tracer-only update that follows the fused x-sweep (tracer_update_body), so
 // that both paths perform the same arithmetic.  rho_in / rho_0: density of the stage input / sub-step start; rrho:
@@ -931,7 +989,7 @@ template <int STAGE>
 PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
                                const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
                                const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
-                               const CellId &c, double rho_in, double rho_0, double rrho, double rdzk) {
+                               const CellId &c, double rho_in, double rho_0, double rrho, double rdzk, bool tr0_done = false) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
@@ -949,6 +1007,12 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
     const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
     const double *tz = fz + (long long)(5 + t) * P.fz_fs;
     const double *mt = mult + (long long)t * P.ncell;
+    // Tracer 0 after the fused x-sweep: the sweep has already stored the update every cell gets when neither it nor a
+    // neighbour is limited (and the cell's own multiplier + row flag).  Only the neighbourhoods of flagged rows are redone here,
+    // with the complete arithmetic below; everywhere else nothing but the seven flags is read.
+    if (t == 0 && tr0_done && rows.flags) {
+      if (!wave_any_or_lane(fct_flagged_near(P, rows, 0, k, j, i, e))) continue;
+    }
     // Multipliers of the cell and its six neighbours: loaded only when one of their rows was flagged by this stage's FCT
     // kernel, else exactly 1.0.  ONE wave-uniform branch: the seven flags and every other input of the cell are requested
     // first and are in flight together; in the (rare) flagged case all seven multipliers are loaded unconditionally and the
@@ -992,13 +1056,9 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
     // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
     const double f_z = limited_flux(Fz, m_km1, m_c, false);
     const double f_zp1 = limited_flux(Fzp1, m_c, m_kp1, false);
-    const double tend = flux_divergence(P, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, rdzk);
-    const double m_in = mul_rn(q_in, rho_in);
-    double m_0 = 0.0;
-    if (STAGE > 1) m_0 = mul_rn(q_0, rho_0);
-    double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
-    if ((P.pos_mask >> t) & 1ull) v = fmax(0.0, v);
-    seed[(long long)t * P.ncell + idx] = next_seed<STAGE>(m_0, m_in, v);
+    double v, new_seed;
+    tracer_new_value<STAGE>(P, t, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, q_in, q_0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+    seed[(long long)t * P.ncell + idx] = new_seed;
     store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
   }
 }
@@ -1010,22 +1070,40 @@ template <int STAGE>
 PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
                                const double *__restrict__ fz, const double *__restrict__ mult, const FctRows &rows,
-                               double *__restrict__ seed, double dt_dyn, const CellId &c) {
+                               double *__restrict__ seed, double dt_dyn, const CellId &c, bool tr0_done = false,
+                               bool do_tracers = true, bool do_pressure = true) {
+  // do_tracers / do_pressure: with one tracer the tail runs as two launches -- a lean pressure pass (a pow per cell at full
+  // occupancy) and a fix-up pass of the tracer that leaves at once unless the limiter acted somewhere in this stage
   const long long c2 = (long long)c.j * P.sy + (long long)c.i * P.sx + c.e;
   const long long o = (long long)(c.k + HS) * P.sz + c2;
-  const double rho_in = prim_in[P_RHO * P.prim_fs + o];
-  const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
-  const double rho_new = prim_out[P_RHO * P.prim_fs + o];
-  const double rrho = fast_rcp(rho_new);
-  const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
   // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
-  // (theta is needed for the density/pressure ghosts only, i.e. on the two boundary levels).  Both are requested BEFORE the
-  // tracer update: its stores may alias prim_out, so the compiler would otherwise start these loads -- a second memory round
-  // trip in a kernel that is nothing but memory latency -- only after them.
-  const double th = (c.k == 0 || c.k == P.nz - 1) ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
-  const double rho_theta = prim_out[P_PRES * P.prim_fs + o];
-  tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk);
-  store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, rho_theta, !P.grav_balance);
+  // (theta and the new density are needed for the density/pressure ghosts only, i.e. on the two boundary levels).  Requested
+  // BEFORE the tracer update: its stores may alias prim_out, so the compiler would otherwise start these loads -- a second
+  // memory round trip in a kernel that is nothing but memory latency -- only after them.
+  const bool boundary = (c.k == 0 || c.k == P.nz - 1);
+  double th = 0.0, rho_theta = 0.0;
+  if (do_pressure) {
+    th = boundary ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
+    rho_theta = prim_out[P_PRES * P.prim_fs + o];
+  }
+  // With water vapour as the only tracer and the limiter idle around the cell there is no tracer work left at all (the
+  // x-sweep's update of tracer 0 stands): then not even the densities are read.
+  bool tracer_work = do_tracers;
+  if (do_tracers && tr0_done && P.nt == 1 && rows.flags) {
+    tracer_work = (*rows.any == rows.seq);
+    if (tracer_work) tracer_work = wave_any_or_lane(fct_flagged_near(P, rows, 0, c.k, c.j, c.i, c.e));
+  }
+  double rho_new = 0.0;
+  if (tracer_work || (do_pressure && boundary)) rho_new = prim_out[P_RHO * P.prim_fs + o];
+  if (tracer_work) {
+    const double rho_in = prim_in[P_RHO * P.prim_fs + o];
+    const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
+    const double rrho = fast_rcp(rho_new);
+    const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
+    tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk,
+                              tr0_done);
+  }
+  if (do_pressure) store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, rho_theta, !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -1176,7 +1254,8 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
 template <int STAGE>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, int line, int e, int c0, int span, double dt_dyn,
+                               const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
+                               const FctRows &rows, int line, int e, int c0, int span, double dt_dyn, double dt_stage,
                                bool tracers_inline) {
   const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
@@ -1188,9 +1267,13 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
   const long long fbase = (long long)k * P.sz + cu0;                   // cell / face i=0 inside an interior-sized field
   const long long jp1 = (j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy;   // offset of the (j+1) neighbour
   const long long ke = (long long)k * P.nens + e;
-  const double rdzk = fast_rcp(P.dz[ke]);
+  const double dzk = P.dz[ke];
+  const double rdzk = fast_rcp(dzk);
   const double gcoef = gravity_coef(P, ke);
   const bool have_y = !P.sim2d;
+  const bool pos0 = (P.pos_mask & 1ull) != 0;                          // tracer 0 is positive-definite: FCT applies
+  const long long frow0 = fct_row(P, k, j, 0, e);                      // FCT flag row of (cell i=0, this lane's member block)
+  const long long frow_sx = (P.nens + 63) >> 6;                        // ... and its stride along x
   double *ruf_line = fx + fbase;                                       // flux_x field 0 of this line: the mass flux
   // periodic wrap of c in [-3, nx+2] without a division (nx >= 3): stays on the scalar unit
   auto cell_off = [&](int c) -> long long { return pbase + (long long)(c < 0 ? c + nx : (c >= nx ? c - nx : c)) * P.sx; };
@@ -1244,12 +1327,15 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
-    double F_prev[1 + NQ];                                 // face fluxes of rho, rho u, rho v, rho w, rho theta
+    double F_prev[1 + NQ], Ft_prev = 0.0;                  // face fluxes of rho, rho u, rho v, rho w, rho theta; of tracer 0
 #pragma unroll
     for (int l = 0; l <= NQ; l++) F_prev[l] = 0.0;
     // everything cell cc needs besides its x fluxes
     // y0*/z0*: the two y / z faces of the mass flux; dy, dz: flux differences of the other variables (DIFF sweeps)
-    struct CellIn { double rho_in, rho_0, q0[NQ], y0l, y0h, z0l, z0h, dy[1 + NQ], dz[1 + NQ]; };
+    //   t*: tracer 0 -- its y/z face fluxes, FCT mass seed and sub-step-start mixing ratio
+    struct CellIn { double rho_in, rho_0, q0[NQ], y0l, y0h, z0l, z0h, dy[1 + NQ], dz[1 + NQ], tyl, tyh, tzl, tzh, tseed, tq0; };
+    const double *fyt = fy + (long long)5 * P.ncell, *fzt = fz + (long long)5 * P.fz_fs;
+    const double *pt0 = prim0 + (long long)P_TR0 * P.prim_fs;
     auto load_in = [&](int cc, CellIn &ci) {
       const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
       ci.rho_in = uni(pr + o)[eu];
@@ -1265,10 +1351,16 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         ci.dy[l] = have_y ? uni(fy + (long long)l * P.ncell + ix)[eu] : 0.0;
         ci.dz[l] = uni(fz + (long long)l * P.fz_fs + ix)[eu];
       }
+      ci.tyl = have_y ? uni(fyt + ix)[eu] : 0.0;
+      ci.tyh = have_y ? uni(fyt + ix + jp1)[eu] : 0.0;
+      ci.tzl = uni(fzt + ix)[eu];
+      ci.tzh = uni(fzt + ix + P.sz)[eu];
+      ci.tseed = uni(seed + ix)[eu];
+      ci.tq0 = (STAGE > 1) ? uni(pt0 + o)[eu] : 0.0;
     };
     // finish cell cc: F_lo/F_hi = its two x faces; m_in_u = rho*u of the stage input (the product window), q_in = v, w, theta
     auto finish = [&](int cc, const CellIn &ci, const double (&Flo)[1 + NQ], const double (&Fhi)[1 + NQ], double m_in_u,
-                      double v_in, double w_in, double th_in) {
+                      double v_in, double w_in, double th_in, double Ft_lo, double Ft_hi, double qt_in) {
       const long long o = pbase + (long long)cc * P.sx;
       const double q0 = rk_combine<STAGE>(ci.rho_0, ci.rho_in, dt_dyn,
                                           flux_divergence(P, Flo[0], Fhi[0], ci.y0l, ci.y0h, ci.z0l, ci.z0h, rdzk));
@@ -1288,6 +1380,28 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         // the new rho*theta goes where the pressure belongs: tracer_update_body turns it into the next stage's pressure
         // (a pow per cell, kept out of this register-critical loop)
         if (l == 4) uniw(out_rt + o)[eu] = v;
+      }
+      // Tracer 0 (Dycore.h:525-550, :572-584, :162-221).  All six face fluxes of the cell are at hand: the FCT multiplier of
+      // THIS cell is final (stored, with its row flag, only where it is not 1), and so is the cell's update unless the cell
+      // or a neighbour is limited -- tracer_update_part redoes exactly those neighbourhoods (flagged rows) afterwards.
+      {
+        const long long ix = fbase + (long long)cc * P.sx;
+        const double m_t = pos0 ? fct_multiplier(P, ci.tseed, Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, dzk, dt_stage) : 1.0;
+        const bool limited = (m_t != 1.0);
+        if (rows.flags) {
+          if (limited) {
+            rows.flags[frow0 + (long long)cc * frow_sx] = rows.seq;
+            *rows.any = rows.seq;
+          }
+          if (wave_any(limited)) uniw(mult + ix)[eu] = m_t;
+        } else {
+          uniw(mult + ix)[eu] = m_t;
+        }
+        double v, new_seed;
+        tracer_new_value<STAGE>(P, 0, Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, qt_in, ci.tq0, ci.rho_in, ci.rho_0, rdzk,
+                                dt_dyn, v, new_seed);
+        uniw(seed + ix)[eu] = new_seed;
+        store_adv_u(P, prim_out, P_TR0, k, cu0 + (long long)cc * P.sx, eu, v * rrho, v * rrho);
       }
     };
     // Faces c0 .. c1: the last one closes the last cell.  It belongs to the next span (or is the periodic face nx == face 0)
@@ -1314,17 +1428,19 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       double ruf, ppf, F[1 + NQ];
       acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
       const bool up = ruf > 0.0;                             // upwind (Dycore.h:368)
+      const double Ft = mul_rn(ruf, up ? prevR_t : Lt);      // x flux of tracer 0 (Dycore.h:367-385)
       if (c < c1) {                                          // the faces this span owns
         if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
-        uniw(flt + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR_t : Lt);
+        uniw(flt + (long long)c * P.sx)[eu] = Ft;            // (read again where the limiter acts: tracer_update_part)
       }
       F[0] = ruf;
       F[1] = fma(ruf, up ? prevR_q[0] : Lq[0], ppf);
 #pragma unroll
       for (int n = 1; n < NQ; n++) F[1 + n] = mul_rn(ruf, up ? prevR_q[n] : Lq[n]);
-      if (c > c0) finish(c - 1, ci, F_prev, F, wm[1], wq[1][1], wq[2][1], wq[3][1]);   // window element 1 is cell c-1
+      if (c > c0) finish(c - 1, ci, F_prev, F, wm[1], wq[1][1], wq[2][1], wq[3][1], Ft_prev, Ft, wt[1]);   // window element 1 is cell c-1
 #pragma unroll
       for (int l = 0; l <= NQ; l++) F_prev[l] = F[l];
+      Ft_prev = Ft;
       prevR_m = Rm; prevR_p = Rp; prevR_t = Rt;
 #pragma unroll
       for (int n = 0; n < NQ; n++) prevR_q[n] = Rq[n];

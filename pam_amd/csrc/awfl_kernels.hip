@@ -113,9 +113,9 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
 __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
-                                                       FctRows rows, double dt) {
+                                                       FctRows rows, double dt, int t0) {
   CellId c;
-  if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, rows, dt, c);
+  if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, rows, dt, c, t0);
 }
 template <int STAGE>
 __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, const double *prim_in,
@@ -133,16 +133,17 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
                                                                      const double *__restrict__ prim0,
                                                                      double *__restrict__ prim_out, double *__restrict__ fx,
                                                                      const double *__restrict__ fy,
-                                                                     const double *__restrict__ fz, double dt_dyn,
-                                                                     int tracers_inline, int span, int nspan) {
+                                                                     const double *__restrict__ fz, double *__restrict__ seed,
+                                                                     double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                                     double dt_stage, int tracers_inline, int span, int nspan) {
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int grp = uni_int(u / nspan), sp = u - grp * nspan;
   const int line = uni_int(grp / nblk), blk = grp - line * nblk;
   const int el = blk * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne)
-    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, line, R.e0 + el, sp * span, span, dt_dyn,
-                              tracers_inline != 0);
+    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span,
+                              dt_dyn, dt_stage, tracers_inline != 0);
 }
 // x fluxes of tracers 1.. for small ensembles: wave unit u -> (x line, member block, span, pair of tracers); after
 // awfl_xupd_kernel.
@@ -167,8 +168,30 @@ __global__ void __launch_bounds__(256) awfl_trupd_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ fx, const double *__restrict__ fy,
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  CellId c;   // after the fused x-sweep: tracer 0 is redone only where the limiter acted
+  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, true);
+}
+// One tracer (water vapour only): the tail as two launches.  (1) next stage's pressure + density/pressure ghosts: a pow per cell
+// and nothing else, so few registers and full occupancy (the general kernel above runs at 4 waves/SIMD and is pure latency);
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *prim_out) {
   CellId c;
-  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c);
+  if (grid_cell(P, R, c))
+    tracer_update_body<STAGE>(P, nullptr, nullptr, prim_out, nullptr, nullptr, nullptr, nullptr, FctRows{nullptr, nullptr, 0, 0},
+                              nullptr, 0.0, c, true, false, true);
+}
+// (2) the tracer's fix-up where the limiter acted: every wavefront leaves after ONE scalar load unless some row was flagged in
+// this stage.
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                         const double *__restrict__ prim0, double *prim_out,
+                                                         const double *__restrict__ fx, const double *__restrict__ fy,
+                                                         const double *__restrict__ fz, const double *__restrict__ mult,
+                                                         FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  if (*rows.any != rows.seq) return;
+  CellId c;
+  if (grid_cell(P, R, c))
+    tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, true, true, false);
 }
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
@@ -483,7 +506,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
 int next_fct_stage(pam_amd_awfl *h) {
   if (h->fct_seq == 0x7fffffff) {   // wrap (once per 2^31 stages): drain everything, forget every flag
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(h->fct_flags, 0, h->n_fct_flags * sizeof(int)));
+    HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1) * sizeof(int)));
     h->fct_seq = 0;
   }
   h->fct_seq++;
@@ -494,15 +517,18 @@ int next_fct_stage(pam_amd_awfl *h) {
 FctRows fct_rows(const pam_amd_awfl *h, EnsRange r, bool sparse_store) {
   FctRows rows;
   rows.flags = h->fct_flags;
+  rows.any = h->fct_flags + h->n_fct_flags;   // one int behind the rows
   rows.seq = h->fct_seq;
   rows.sparse_store = (sparse_store && r.e0 % 64 == 0 && r.ne % 64 == 0) ? 1 : 0;
   return rows;
 }
 
-int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s, bool sparse_store = false) {
+// t0: first tracer (the fused x-sweep has already produced tracer 0's multiplier: t0 = 1)
+int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s, bool sparse_store = false, int t0 = 0) {
+  if (t0 >= h->P.nt) return PAM_AMD_OK;
   ScopedTimer st(h, "fct_mult", s);
   hipLaunchKernelGGL(awfl_fct_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
-                     h->flux_z, h->seed, h->mult, fct_rows(h, r, sparse_store), dt);
+                     h->flux_z, h->seed, h->mult, fct_rows(h, r, sparse_store), dt, t0);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -518,8 +544,8 @@ int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, d
 }
 
 template <int STAGE>
-int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
-                hipStream_t s) {
+int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, double dt_stage,
+                EnsRange r, hipStream_t s) {
   const Params &P = h->P;
   // wavefronts: (x line, block of 64 members, span of cells).  Normally a wavefront owns a whole line; when the ensemble alone
   // does not fill the chip the lines are cut into spans (each recomputes its closing face) as choose_span decides from the
@@ -536,7 +562,8 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   {
     ScopedTimer st(h, "xupd", s);
     hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
-                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, dt_dyn, split ? 0 : 1, span, nspan);
+                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn,
+                       dt_stage, split ? 0 : 1, span, nspan);
     HIP_TRY(hipGetLastError());
   }
   if (split) {
@@ -552,8 +579,14 @@ template <int STAGE>
 int launch_trupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
                  hipStream_t s) {
   ScopedTimer st(h, "trupd", s);
-  hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
-                     h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+  if (h->P.nt == 1) {   // water vapour only: lean pressure pass + fix-up pass (see the kernels)
+    hipLaunchKernelGGL(awfl_ptail_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_out);
+    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+  } else {
+    hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+  }
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -759,8 +792,8 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->seed, h->n_seed * 8));
   INIT_TRY(hipMalloc(&h->mult, h->n_seed * 8));
   h->n_fct_flags = (size_t)P.nt * (size_t)P.nz * P.ny * P.nx * (size_t)((P.nens + 63) / 64);   // FctRows: (nt, nz, ny, nx, blocks of 64 members)
-  INIT_TRY(hipMalloc(&h->fct_flags, h->n_fct_flags * sizeof(int)));
-  INIT_TRY(hipMemset(h->fct_flags, 0, h->n_fct_flags * sizeof(int)));
+  INIT_TRY(hipMalloc(&h->fct_flags, (h->n_fct_flags + 1) * sizeof(int)));   // + the "any row flagged in this stage" word
+  INIT_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1) * sizeof(int)));
   h->fct_seq = 0;
   INIT_TRY(hipMalloc(&h->dz, nzn * 8));
   INIT_TRY(hipMalloc(&h->grav_var, nzn * 8));
@@ -973,15 +1006,15 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
         hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
         if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
         if ((r2 = launch_flux(h, pin, c.r, cs, 6, true))) return r2;
-        if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, c.r, cs);
-        else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, c.r, cs);
-        else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, c.r, cs);
+        if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
+        else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
+        else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
         if (r2) return r2;
         if (forked) {
           HIP_TRY(hipEventRecord(c.flux_done, cs));
           HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
         }
-        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream, true))) return r2;
+        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream, true, 1))) return r2;   // tracer 0: done by the x-sweep
         if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
         else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
         else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
@@ -1198,10 +1231,10 @@ int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
   USE_DEVICE(h);
   const EnsRange r = full_range(h->P);
   int rc;
-  if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
-  if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream))) return rc;
   if ((rc = next_fct_stage(h))) return rc;
-  if ((rc = launch_fct(h, dt_dyn, r, h->stream, h->fused))) return rc;
+  if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
+  if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, dt_dyn, r, h->stream))) return rc;
+  if ((rc = launch_fct(h, dt_dyn, r, h->stream, h->fused, h->fused ? 1 : 0))) return rc;
   if (h->fused) rc = launch_trupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   else rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   if (rc) return rc;

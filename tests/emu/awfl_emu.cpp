@@ -28,7 +28,7 @@ struct Emu {
 
 static FctRows fct_rows(Emu *h) {
   FctRows r;
-  r.flags = h->fct_flags.data(); r.seq = h->fct_seq; r.sparse_store = 0;
+  r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + (h->fct_flags.size() - 1); r.seq = h->fct_seq; r.sparse_store = 0;
   return r;
 }
 
@@ -66,11 +66,13 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
 
 // `sparse`: what the device does in the fused stage when a wavefront is a whole row -- the multipliers of a row no member of
 // which was limited are not stored.  Emulated by poisoning them: an update that loads one of them anyway produces NaN.
+// the stage's flag value is drawn by the caller BEFORE the stage (h->fct_seq++), as next_fct_stage() does on the device: in
+// the fused stage the x-sweep already flags tracer 0, and this pass starts at tracer 1.
 static void fct_launch(Emu *h, double dt, bool sparse) {
   const Params &P = h->P;
-  h->fct_seq++;
   for (long long idx = 0; idx < P.ncell; idx++)
-    fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx));
+    fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx),
+                  sparse ? 1 : 0);
   if (!sparse) return;
   const long long nrows = fct_rows_per_tracer(P);
   for (int t = 0; t < P.nt; t++)
@@ -89,19 +91,23 @@ static void update_launch(Emu *h, const double *in, const double *p0, double *ou
 
 // launch geometry of awfl_xupd_kernel: one wavefront per (x line, block of 64 members); lanes = members
 template <int STAGE>
-static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
+static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt, double dt_stage) {
   const Params &P = h->P;
   const int span = h->span > 0 ? h->span : P.nx, nspan = (P.nx + span - 1) / span;   // emu_set_span cuts the x lines too
   for (int line = 0; line < P.nz * P.ny; line++)
     for (int sp = 0; sp < nspan; sp++)
       for (int e = 0; e < P.nens; e++)
-        flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), line, e, sp * span, span, dt, true);
+        flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(),
+                                  fct_rows(h), line, e, sp * span, span, dt, dt_stage, true);
 }
 template <int STAGE>
 static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
-  for (long long idx = 0; idx < h->P.ncell; idx++)
-    tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fct_rows(h), h->seed.data(), dt,
-                              cell_of(h->P, idx));
+  // one tracer: two passes, as the device launches them (awfl_ptail_kernel, awfl_trfix_kernel)
+  const bool two = (h->P.nt == 1);
+  for (int pass = 0; pass < (two ? 2 : 1); pass++)
+    for (long long idx = 0; idx < h->P.ncell; idx++)
+      tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fct_rows(h), h->seed.data(), dt,
+                                cell_of(h->P, idx), true, two ? pass == 1 : true, two ? pass == 0 : true);
 }
 
 static TracerPtrs tptrs(const Emu *h, double *tracers) {
@@ -141,7 +147,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
   h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
   h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
-  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P), 0);
+  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P) + 1, 0);   // + the "any row flagged" word
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();
@@ -200,6 +206,7 @@ void emu_convert_coupler_to_dynamics(Emu *h, double *rho_d, double *u, double *v
 }
 
 void emu_flux_stage(Emu *h, double dt) {
+  h->fct_seq++;
   flux_launch(h, h->prim0.data());
   fct_launch(h, dt, false);
 }
@@ -217,18 +224,18 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     // poison the x fluxes of the state: the fused stage must not read them
     for (int ic = 0; ic < ncycles; ic++) {
       std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);   // (field 0 is re-used as the x-sweep's own scratch)
-      flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt); fct_launch(h, dt, true); trupd_launch<1>(h, A, A, B, dt);
-      flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt); fct_launch(h, (1.0 / 4.0) * dt, true); trupd_launch<2>(h, B, A, C, dt);
-      flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt); fct_launch(h, (2.0 / 3.0) * dt, true); trupd_launch<3>(h, C, A, B, dt);
+      h->fct_seq++; flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt, dt); fct_launch(h, dt, true); trupd_launch<1>(h, A, A, B, dt);
+      h->fct_seq++; flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt, (1.0 / 4.0) * dt); fct_launch(h, (1.0 / 4.0) * dt, true); trupd_launch<2>(h, B, A, C, dt);
+      h->fct_seq++; flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt, (2.0 / 3.0) * dt); fct_launch(h, (2.0 / 3.0) * dt, true); trupd_launch<3>(h, C, A, B, dt);
       std::swap(A, B);
     }
     if (A != h->prim0.data()) h->prim0.swap(h->prim1);   // an odd number of sub-steps: the state sits in prim1
     p0 = h->prim0.data();
   } else {
     for (int ic = 0; ic < ncycles; ic++) {
-      flux_launch(h, p0); fct_launch(h, dt, false); update_launch<1>(h, p0, p0, p1, dt);
-      flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt, false); update_launch<2>(h, p1, p0, p1, dt);
-      flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt, false); update_launch<3>(h, p1, p0, p0, dt);
+      h->fct_seq++; flux_launch(h, p0); fct_launch(h, dt, false); update_launch<1>(h, p0, p0, p1, dt);
+      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt, false); update_launch<2>(h, p1, p0, p1, dt);
+      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt, false); update_launch<3>(h, p1, p0, p0, dt);
     }
   }
   TracerPtrs tp = tptrs(h, tracers);
