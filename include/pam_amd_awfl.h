@@ -145,9 +145,10 @@ int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
  * blocks can co-reside; default 0 = no cap).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
 
-/* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + state update -> FCT multiplier -> tracer update +
- * pressure; the state's x fluxes never reach HBM.  0: flux(x,y,z) -> FCT multiplier ->
- * update, every face flux stored.  Both produce the same bits (tests/test_fused_stage.py). */
+/* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + update of the state and of the first tracer (incl.
+ * its FCT multiplier) -> [FCT multiplier of further tracers] -> pointwise tail (further tracers, the first tracer where the
+ * limiter acted, next stage's pressure); the state's x fluxes never reach HBM.  0: flux(x,y,z) ->
+ * FCT multiplier -> update, every face flux and multiplier stored.  Both produce the same bits (tests/test_fused_stage.py). */
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
 
 /* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
