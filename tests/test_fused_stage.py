@@ -28,7 +28,7 @@ CASES = {
 }
 
 
-def _run(case, fused, chunks=0):
+def _run(case, fused, chunks=0, want_mult=False):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts = CASES[case]
@@ -69,6 +69,8 @@ def _run(case, fused, chunks=0):
         ncyc.append(dycore.timeStep(coupler))
     torch.cuda.synchronize()
     out = coupler.dump_fields()
+    if want_mult:       # FCT multipliers of the last stage (complete only in the three-kernel stage)
+        out["mult"] = dycore.debug_buffer("mult").cpu().numpy().reshape(len(tr), nz, ny, nx, nens)
     dycore.finalize(coupler)
     return ncyc, out
 
@@ -81,6 +83,19 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
+@pytest.mark.parametrize("case", ["3d_nt4_whole_flag_rows", "2d_nt10_whole_flag_rows"])
+def test_flag_row_cases_exercise_the_limiter(case):
+    """the cases above are only worth something if rows ARE flagged, and if flagged rows mix limited and unlimited members"""
+    _, a = _run(case, fused=False, want_mult=True)
+    m = a["mult"]
+    nt, nz, ny, nx, nens = m.shape
+    assert np.isfinite(m).all() and (m < 1.0).any() and (m == 1.0).any()
+    rows = m.reshape(nt, nz, ny, nx, nens // 64, 64)
+    lim = (rows < 1.0).sum(axis=-1)
+    assert ((lim > 0) & (lim < 64)).any(), "no row holds limited and unlimited members side by side"
+    assert (lim == 0).any(), "rows without any limited member must exist too (they are the ones that are skipped)"
 
 
 def test_fct_flag_rows_are_chunking_invariant():
