@@ -53,7 +53,8 @@ int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, const double
  *             gcm_num_liq, gcm_num_ice, gcm_num_rain
  *   tend[14]  (nz,nens): gcm_forcing_tend_{rho_d,uvel,vvel,temp,qtot,qv,ql,qi,rho_v,rho_l,rho_i,nc,ni,nr}
  * Writes every tend entry except rho_v, rho_l, rho_i (those are diagnostics of the apply step).  Horizontal means are summed
- * in the reference's serial order (deterministic; the reference uses atomicAdd). */
+ * deterministically (strips of cells in the reference's serial order, strips added in ascending order; the reference uses
+ * atomicAdd in no particular order); stream-ordered scratch for the strips' partial sums is taken with hipMallocAsync. */
 int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
                                 double *const *tend, double gcm_physics_dt, void *stream);
 

@@ -188,8 +188,9 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
 
 // ---------------------------------------------------------------------------------------------------------------
 // GCM forcing of the CRM mean state (pam_core/modules/gcm_forcing.h).  The reference accumulates its horizontal means
-// and hole-filling masses with atomicAdd; here one thread owns one (level, member) pair and walks its ny*nx cells in the
-// reference's serial order (j outer, i inner), so every sum is deterministic and equal to the serial reference's.
+// and hole-filling masses with atomicAdd, in no particular order; here every sum is deterministic: a thread walks a strip of
+// consecutive cells of one (level, member) pair in the reference's serial order (j outer, i inner), and the strips of a pair
+// are added in ascending order (GcmStrips below; with one strip the sums equal the serial reference's bit for bit).
 // Consecutive lanes are consecutive members: each step of the walk is one coalesced row per field.
 struct Gcm10 { double *p[10]; };
 struct Gcm14 { double *p[14]; };
@@ -198,31 +199,9 @@ enum { GT_RHOD, GT_U, GT_V, GT_T, GT_QTOT, GT_QV, GT_QL, GT_QI, GT_RV, GT_RL, GT
 
 __device__ __forceinline__ double yakl_max(double a, double b) { return a > b ? a : b; }   // NaN in b propagates, as yakl::max
 
-// compute_gcm_forcing_tendencies (gcm_forcing.h:17-210)
-__global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
-                                                                 double r_dt_gcm) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)nz * nens) return;
-  const int e = (int)(t % nens), k = (int)(t / nens);
-  const double r_nx_ny = 1.0 / (nx * ny);
-  double ca[10];
-#pragma unroll
-  for (int f = 0; f < 10; f++) ca[f] = 0;
-  const long long base = (long long)k * ny * nx * nens + e;
-  for (int c = 0; c < ny * nx; c++) {
-    const long long o = base + (long long)c * nens;
-    const double rd = crm.p[GF_RHOD][o], rv = crm.p[GF_RV][o];
-    ca[GF_RHOD] += rd * r_nx_ny;
-    ca[GF_U] += crm.p[GF_U][o] * r_nx_ny;
-    ca[GF_V] += crm.p[GF_V][o] * r_nx_ny;
-    ca[GF_T] += crm.p[GF_T][o] * r_nx_ny;
-    ca[GF_RV] += (rv / (rd + rv)) * r_nx_ny;
-    ca[GF_RL] += (crm.p[GF_RL][o] / (rd + rv)) * r_nx_ny;
-    ca[GF_RI] += (crm.p[GF_RI][o] / (rd + rv)) * r_nx_ny;
-    ca[GF_NC] += crm.p[GF_NC][o] * r_nx_ny;
-    ca[GF_NI] += crm.p[GF_NI][o] * r_nx_ny;
-    ca[GF_NR] += crm.p[GF_NR][o] * r_nx_ny;
-  }
+// tendencies of one (level, member) pair from its column averages (gcm_forcing.h:176-208)
+__device__ __forceinline__ void gcm_forcing_compute_finish(const Gcm10 &gcm, const Gcm14 &tend, const double (&ca)[10], long long t,
+                                                           double r_dt_gcm) {
   tend.p[GT_RHOD][t] = (gcm.p[GF_RHOD][t] - ca[GF_RHOD]) * r_dt_gcm;
   tend.p[GT_U][t] = (gcm.p[GF_U][t] - ca[GF_U]) * r_dt_gcm;
   tend.p[GT_V][t] = (gcm.p[GF_V][t] - ca[GF_V]) * r_dt_gcm;
@@ -238,16 +217,95 @@ __global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int n
   tend.p[GT_QTOT][t] = tqv + tql + tqi;
 }
 
+// Strips.  A (level, member) pair's walk over its ny*nx cells is cut into `nstrip` strips of `cpt` consecutive cells, one thread
+// each, when one thread per pair would leave the chip mostly empty (nz*nens threads: 960 wavefronts at 1024 x 60, 1 at nens = 1);
+// every strip sums its cells in the reference's serial order and a second, tiny kernel adds the strips in ascending order.
+// With one strip the sums are those of the serial reference bit for bit; with more they differ by re-association only (the
+// reference itself accumulates with atomicAdd in no particular order).
+//   thread t -> (level k, strip s, member e), e fastest: consecutive lanes are consecutive members of the same cell.
+//   part     (nsum, nz, nstrip, nens) partial sums (only when nstrip > 1)
+struct GcmStrips { int cpt, nstrip; };
+__device__ __forceinline__ bool gcm_strip_of(long long t, int nens, int nz, GcmStrips S, int &k, int &sidx, int &e) {
+  if (t >= (long long)nz * S.nstrip * nens) return false;
+  e = (int)(t % nens);
+  const long long r = t / nens;
+  sidx = (int)(r % S.nstrip);
+  k = (int)(r / S.nstrip);
+  return true;
+}
+
+// compute_gcm_forcing_tendencies (gcm_forcing.h:17-210): column averages
+__global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+                                                                 double r_dt_gcm, GcmStrips S, double *__restrict__ part) {
+  int k, sidx, e;
+  if (!gcm_strip_of((long long)blockIdx.x * blockDim.x + threadIdx.x, nens, nz, S, k, sidx, e)) return;
+  const long long t = (long long)k * nens + e;
+  const double r_nx_ny = 1.0 / (nx * ny);
+  double ca[10];
+#pragma unroll
+  for (int f = 0; f < 10; f++) ca[f] = 0;
+  const long long base = (long long)k * ny * nx * nens + e;
+  const int c_end = (sidx + 1) * S.cpt < ny * nx ? (sidx + 1) * S.cpt : ny * nx;
+  for (int c = sidx * S.cpt; c < c_end; c++) {
+    const long long o = base + (long long)c * nens;
+    const double rd = crm.p[GF_RHOD][o], rv = crm.p[GF_RV][o];
+    ca[GF_RHOD] += rd * r_nx_ny;
+    ca[GF_U] += crm.p[GF_U][o] * r_nx_ny;
+    ca[GF_V] += crm.p[GF_V][o] * r_nx_ny;
+    ca[GF_T] += crm.p[GF_T][o] * r_nx_ny;
+    ca[GF_RV] += (rv / (rd + rv)) * r_nx_ny;
+    ca[GF_RL] += (crm.p[GF_RL][o] / (rd + rv)) * r_nx_ny;
+    ca[GF_RI] += (crm.p[GF_RI][o] / (rd + rv)) * r_nx_ny;
+    ca[GF_NC] += crm.p[GF_NC][o] * r_nx_ny;
+    ca[GF_NI] += crm.p[GF_NI][o] * r_nx_ny;
+    ca[GF_NR] += crm.p[GF_NR][o] * r_nx_ny;
+  }
+  if (S.nstrip > 1) {
+#pragma unroll
+    for (int f = 0; f < 10; f++) part[(((long long)f * nz + k) * S.nstrip + sidx) * nens + e] = ca[f];
+    return;
+  }
+  gcm_forcing_compute_finish(gcm, tend, ca, t, r_dt_gcm);
+}
+__global__ void __launch_bounds__(64) gcm_forcing_compute_finish_kernel(int nens, int nz, Gcm10 gcm, Gcm14 tend, double r_dt_gcm,
+                                                                        GcmStrips S, const double *__restrict__ part) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nz * nens) return;
+  const int e = (int)(t % nens), k = (int)(t / nens);
+  double ca[10];
+#pragma unroll
+  for (int f = 0; f < 10; f++) {
+    double a = 0;
+    for (int q = 0; q < S.nstrip; q++) a += part[(((long long)f * nz + k) * S.nstrip + q) * nens + e];
+    ca[f] = a;
+  }
+  gcm_forcing_compute_finish(gcm, tend, ca, t, r_dt_gcm);
+}
+
 // apply_gcm_forcing_tendencies, main kernel + diagnostics (gcm_forcing.h:361-429) fused with the first two kernels of
 // fill_holes (positive mass per level, "negative too large" test; :236-250).
 //   work: neg[3], pos[3] (nz,nens) ; flags[0..2] = some negative mass for species s, flags[3..5] = negative > positive somewhere
+__device__ __forceinline__ void gcm_forcing_apply_finish(const Gcm10 &gcm, const Gcm14 &tend, const double (&colavg)[3],
+                                                         const double (&neg)[3], const double (&pos)[3], long long t, long long n2,
+                                                         double r_dt_gcm, double *__restrict__ work, int *__restrict__ flags) {
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    tend.p[GT_RV + s][t] = (gcm.p[GF_RV + s][t] - colavg[s]) * r_dt_gcm;
+    work[(long long)s * n2 + t] = neg[s];
+    work[(long long)(3 + s) * n2 + t] = pos[s];
+    if (neg[s] > 0) atomicOr(&flags[s], 1);
+    if (neg[s] > pos[s]) atomicOr(&flags[3 + s], 1);
+  }
+}
+// strips as in gcm_forcing_compute_kernel; part: (9, nz, nstrip, nens) = colavg[3], neg[3], pos[3]
 __global__ void __launch_bounds__(64) gcm_forcing_apply_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
                                                                const double *__restrict__ dz, double dt, double r_dt_gcm,
-                                                               double *__restrict__ work, int *__restrict__ flags) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                               double *__restrict__ work, int *__restrict__ flags, GcmStrips S,
+                                                               double *__restrict__ part) {
+  int k, sidx, e;
+  if (!gcm_strip_of((long long)blockIdx.x * blockDim.x + threadIdx.x, nens, nz, S, k, sidx, e)) return;
+  const long long t = (long long)k * nens + e;
   const long long n2 = (long long)nz * nens;
-  if (t >= n2) return;
-  const int e = (int)(t % nens), k = (int)(t / nens);
   const double r_nx_ny = 1.0 / (nx * ny);
   const double dzk = dz[t];
   const double t_rd = tend.p[GT_RHOD][t] * dt, t_u = tend.p[GT_U][t] * dt, t_v = tend.p[GT_V][t] * dt, t_t = tend.p[GT_T][t] * dt;
@@ -255,7 +313,8 @@ __global__ void __launch_bounds__(64) gcm_forcing_apply_kernel(int nens, int nx,
   const double t_nc = tend.p[GT_NC][t] * dt, t_ni = tend.p[GT_NI][t] * dt, t_nr = tend.p[GT_NR][t] * dt;
   double colavg[3] = {0, 0, 0}, neg[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
   const long long base = (long long)k * ny * nx * nens + e;
-  for (int c = 0; c < ny * nx; c++) {
+  const int c_end = (sidx + 1) * S.cpt < ny * nx ? (sidx + 1) * S.cpt : ny * nx;
+  for (int c = sidx * S.cpt; c < c_end; c++) {
     const long long o = base + (long long)c * nens;
     const double rho_d_old = crm.p[GF_RHOD][o];
     const double rho_d = rho_d_old + t_rd;
@@ -284,14 +343,33 @@ __global__ void __launch_bounds__(64) gcm_forcing_apply_kernel(int nens, int nx,
       crm.p[GF_RV + s][o] = w[s];
     }
   }
+  if (S.nstrip > 1) {
 #pragma unroll
-  for (int s = 0; s < 3; s++) {
-    tend.p[GT_RV + s][t] = (gcm.p[GF_RV + s][t] - colavg[s]) * r_dt_gcm;
-    work[(long long)s * n2 + t] = neg[s];
-    work[(long long)(3 + s) * n2 + t] = pos[s];
-    if (neg[s] > 0) atomicOr(&flags[s], 1);
-    if (neg[s] > pos[s]) atomicOr(&flags[3 + s], 1);
+    for (int s = 0; s < 3; s++) {
+      part[(((long long)s * nz + k) * S.nstrip + sidx) * nens + e] = colavg[s];
+      part[(((long long)(3 + s) * nz + k) * S.nstrip + sidx) * nens + e] = neg[s];
+      part[(((long long)(6 + s) * nz + k) * S.nstrip + sidx) * nens + e] = pos[s];
+    }
+    return;
   }
+  gcm_forcing_apply_finish(gcm, tend, colavg, neg, pos, t, n2, r_dt_gcm, work, flags);
+}
+__global__ void __launch_bounds__(64) gcm_forcing_apply_finish_kernel(int nens, int nz, Gcm10 gcm, Gcm14 tend, double r_dt_gcm,
+                                                                      double *__restrict__ work, int *__restrict__ flags,
+                                                                      GcmStrips S, const double *__restrict__ part) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n2 = (long long)nz * nens;
+  if (t >= n2) return;
+  const int e = (int)(t % nens), k = (int)(t / nens);
+  double a[9];
+#pragma unroll
+  for (int f = 0; f < 9; f++) {
+    double x = 0;
+    for (int q = 0; q < S.nstrip; q++) x += part[(((long long)f * nz + k) * S.nstrip + q) * nens + e];
+    a[f] = x;
+  }
+  const double colavg[3] = {a[0], a[1], a[2]}, neg[3] = {a[3], a[4], a[5]}, pos[3] = {a[6], a[7], a[8]};
+  gcm_forcing_apply_finish(gcm, tend, colavg, neg, pos, t, n2, r_dt_gcm, work, flags);
 }
 
 // fill_holes, level pass (:243-250)
@@ -506,6 +584,20 @@ int gcm_check(const char *who, int nens, int nx, int ny, int nz, const void *con
 }
 }  // namespace
 
+namespace {
+// strips of the per-(level, member) walks (GcmStrips): enough threads for ~4 wavefronts per SIMD, never fewer than 8 cells each
+GcmStrips gcm_strips(int nens, int nx, int ny, int nz) {
+  const long long pairs = (long long)nz * nens, cells = (long long)ny * nx;
+  long long want = (262144 + pairs - 1) / pairs;
+  if (want > cells / 8) want = cells / 8;
+  if (want < 1) want = 1;
+  GcmStrips S;
+  S.cpt = (int)((cells + want - 1) / want);
+  S.nstrip = (int)((cells + S.cpt - 1) / S.cpt);
+  return S;
+}
+}  // namespace
+
 extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
                                            double *const *tend, double gcm_physics_dt, void *stream) {
   if (int rc = gcm_check("compute_gcm_forcing_tendencies", nens, nx, ny, nz, (const void *const *)crm, 10,
@@ -515,8 +607,18 @@ extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, con
   for (int i = 0; i < 10; i++) { C.p[i] = const_cast<double *>(crm[i]); G.p[i] = const_cast<double *>(gcm[i]); }
   for (int i = 0; i < 14; i++) T.p[i] = tend[i];
   const long long n2 = (long long)nz * nens;
-  hipLaunchKernelGGL(gcm_forcing_compute_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, (hipStream_t)stream, nens, nx, ny, nz,
-                     C, G, T, 1.0 / gcm_physics_dt);
+  hipStream_t s = (hipStream_t)stream;
+  const GcmStrips S = gcm_strips(nens, nx, ny, nz);
+  double *part = nullptr;     // partial sums of the strips: stream-ordered scratch, gone when the kernels are
+  if (S.nstrip > 1 && hipMallocAsync((void **)&part, (size_t)10 * n2 * S.nstrip * sizeof(double), s) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "compute_gcm_forcing_tendencies: no memory for the partial sums");
+  hipLaunchKernelGGL(gcm_forcing_compute_kernel, dim3((unsigned)((n2 * S.nstrip + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz,
+                     C, G, T, 1.0 / gcm_physics_dt, S, part);
+  if (S.nstrip > 1) {
+    hipLaunchKernelGGL(gcm_forcing_compute_finish_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nz, G, T,
+                       1.0 / gcm_physics_dt, S, part);
+    (void)hipFreeAsync(part, s);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
@@ -537,8 +639,17 @@ extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, doubl
   double *glob = workspace + 6 * n2;
   int *flags = (int *)(glob + 2 * (long long)nens);
   hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
-  hipLaunchKernelGGL(gcm_forcing_apply_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz, C, G, T, dz,
-                     crm_dt, 1.0 / gcm_physics_dt, workspace, flags);
+  const GcmStrips S = gcm_strips(nens, nx, ny, nz);
+  double *part = nullptr;
+  if (S.nstrip > 1 && hipMallocAsync((void **)&part, (size_t)9 * n2 * S.nstrip * sizeof(double), s) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "apply_gcm_forcing_tendencies: no memory for the partial sums");
+  hipLaunchKernelGGL(gcm_forcing_apply_kernel, dim3((unsigned)((n2 * S.nstrip + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz, C, G, T,
+                     dz, crm_dt, 1.0 / gcm_physics_dt, workspace, flags, S, part);
+  if (S.nstrip > 1) {
+    hipLaunchKernelGGL(gcm_forcing_apply_finish_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nz, G, T,
+                       1.0 / gcm_physics_dt, workspace, flags, S, part);
+    (void)hipFreeAsync(part, s);
+  }
   // "Only do the hole filling if there's negative mass" (:432-436) and ScalarLiveOut neg_too_large (:241,:252): one read-back
   int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
