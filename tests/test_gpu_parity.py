@@ -312,6 +312,72 @@ def test_full_baseline_size_c2_properties():
         assert torch.equal(results[0][k], results[1][k]), k
 
 
+@pytest.mark.parametrize("cfg", ["c3_nens4096_kessler_shoc", "c4_shard512_p3_shoc"])
+def test_full_baseline_size_c3_c4_properties(cfg):
+    """BASELINE.json configs[2] (nens=4096, 2-D 32x1x60, 4 tracers) and one GPU's shard of configs[3] (512 of 4096 members, 10
+    tracers, P3 constants) at full size: too large for the oracle, so size-independent properties.  Tracers carry blobs with exact
+    zeros around them, so the FCT limiter is active and its row flags are set (the fused stage's sparse path).  (i) total mass
+    (dry + every mass-adding tracer) and vapour mass of every member conserved to 1e-10 per timeStep (Dycore.h:224-251);
+    (ii) positive-definite tracers stay non-negative, everything finite; (iii) members that start identical stay bit-identical
+    (16 distinct members tiled); (iv) the fused stage equals the three-kernel stage bit for bit at this size too."""
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, tr, consts = (4096, idz.TRACERS_KESSLER_SHOC, idz.CONSTS_DEFAULT) if cfg.startswith("c3") else (512, idz.TRACERS_P3_SHOC, idz.CONSTS_P3)
+    nx, ny, nz, ngen = 32, 1, 60, 16
+    zint = idz.l60_interfaces()
+    xlen = nx * 1000.0
+    f = idz.supercell_fields(ngen, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=0.1)
+    idz.add_tracer_blobs(f, tr, xlen, xlen, zint)
+    dz = torch.from_numpy(np.diff(zint)).to("cuda:0")[:, None, None, None]
+    results = []
+    for fused in (True, False):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 2.0)
+        for k, v in consts.items():
+            coupler.set_option(k, v)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        coupler.set_grid(xlen, xlen, zint)
+        for n, p, m in tr:
+            coupler.add_tracer(n, "", p, m)
+        dycore = Dycore()
+        dycore.init(coupler)
+        dycore.set_fused_stage(fused)
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            coupler.dm.get(k).copy_(torch.from_numpy(f[k]).to("cuda:0").repeat(1, 1, 1, nens // ngen))
+        for t, (n, p, m) in enumerate(tr):
+            coupler.dm.get(n).copy_(torch.from_numpy(f["tracers"][t]).to("cuda:0").repeat(1, 1, 1, nens // ngen))
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+
+        def totals():
+            rho = coupler.dm.get("density_dry", readonly=True).clone()
+            for n, p, m in tr:
+                if m:
+                    rho = rho + coupler.dm.get(n, readonly=True)
+            return (rho * dz).sum(dim=(0, 1, 2)), (coupler.dm.get("water_vapor", readonly=True) * dz).sum(dim=(0, 1, 2))
+        m0, v0 = totals()
+        nsub = dycore.timeStep(coupler)
+        torch.cuda.synchronize()
+        m1, v1 = totals()
+        assert nsub >= 3
+        assert torch.all((m1 - m0).abs() <= 1e-10 * m0.abs())
+        assert torch.all((v1 - v0).abs() <= 1e-10 * v0.abs())
+        out = {}
+        for k in ["density_dry", "uvel", "wvel", "temp"] + [n for n, p, m in tr]:
+            t = coupler.dm.get(k, readonly=True)
+            assert torch.isfinite(t).all(), k
+            assert torch.equal(t[..., :ngen], t[..., nens - ngen:]), k
+            out[k] = t[..., ::29].clone()
+        for n, p, m in tr:
+            if p:
+                assert (coupler.dm.get(n, readonly=True) >= 0).all(), n
+        results.append(out)
+        dycore.finalize(coupler)
+        del coupler, dycore
+        torch.cuda.empty_cache()
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
+
+
 def test_long_run_parity_120_substeps():
     """north_star: "prognostic state after N steps matches the reference ... rtol 1e-12".  20 timeSteps = 120 SSPRK3
     sub-steps of a 3-D moist-tracer supercell case; measured drift HIP vs oracle: 1e-14 (rho, T), 1e-13 (u), 1e-12 (w)."""
