@@ -173,12 +173,19 @@ __global__ void __launch_bounds__(256) awfl_trupd_kernel(Params P, EnsRange R, c
 }
 // One tracer (water vapour only): the tail as two launches.  (1) next stage's pressure + density/pressure ghosts: a pow per cell
 // and nothing else, so few registers and full occupancy (the general kernel above runs at 4 waves/SIMD and is pure latency);
+constexpr int TRFIX_LEVELS = 6;   // levels per thread in the two NT=1 tail kernels: a quarter of the wavefronts, index arithmetic once
 template <int STAGE>
-__global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *prim_out) {
+__global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *__restrict__ prim_out) {
   CellId c;
-  if (grid_cell(P, R, c))
+  if (!grid_cell(P, R, c)) return;
+#pragma unroll
+  for (int kk = 0; kk < TRFIX_LEVELS; kk++) {
+    c.k = (int)blockIdx.z * TRFIX_LEVELS + kk;
+    if (c.k >= P.nz) return;
+    c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
     tracer_update_body<STAGE>(P, nullptr, nullptr, prim_out, nullptr, nullptr, nullptr, nullptr, FctRows{nullptr, nullptr, 0, 0},
                               nullptr, 0.0, c, true, false, true);
+  }
 }
 // (2) the tracer's fix-up where the limiter acted: every wavefront leaves after ONE scalar load unless some row was flagged in
 // this stage.
@@ -189,9 +196,15 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
   if (*rows.any != rows.seq) return;
+  // TRFIX_LEVELS levels per thread: a quarter of the wavefronts to launch (and to retire at once in the common case)
   CellId c;
-  if (grid_cell(P, R, c))
+  if (!grid_cell(P, R, c)) return;
+  for (int kk = 0; kk < TRFIX_LEVELS; kk++) {
+    c.k = (int)blockIdx.z * TRFIX_LEVELS + kk;
+    if (c.k >= P.nz) return;
+    c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
     tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, true, true, false);
+  }
 }
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
@@ -580,8 +593,10 @@ int launch_trupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, do
                  hipStream_t s) {
   ScopedTimer st(h, "trupd", s);
   if (h->P.nt == 1) {   // water vapour only: lean pressure pass + fix-up pass (see the kernels)
-    hipLaunchKernelGGL(awfl_ptail_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_out);
-    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+    dim3 g = cell_grid(h->P, r);
+    g.z = (g.z + TRFIX_LEVELS - 1) / TRFIX_LEVELS;
+    hipLaunchKernelGGL(awfl_ptail_kernel<STAGE>, g, dim3(256), 0, s, h->P, r, prim_out);
+    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, g, dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
                        h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
   } else {
     hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
