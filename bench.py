@@ -196,6 +196,8 @@ class Job:
                                  magnitude=0.1, id0=rank * 1000)
         if self.nt > 1:
             idz.add_tracer_blobs(f, self.tracers, self.xlen, self.ylen, self.zint)
+        if args.limiter:   # exact zeros in the vapour beside moist air: the FCT limiter acts on water_vapor in every stage
+            idz.carve_dry_air(f, self.tracers, spread=args.limiter > 1)
         reps = (nens_pg + nens_gen - 1) // nens_gen
         # members differ between tiles by a small smooth temperature offset so no two CRMs are identical
         off = (torch.arange(nens_pg, device=dev, dtype=torch.float64) // nens_gen) * 1.0e-3
@@ -365,6 +367,7 @@ def worker(args):
     job.sharded = dd is not None
     updates, elapsed, substeps = job.timed(args.steps, args.warmup, dd, backend, dev)
     value = updates / elapsed
+    fct_rows = job.dycore.debug_fct_rows()      # rows the LAST stage's limiter flagged / all rows
     cells = job.nens * job.nz * job.ny * job.nx
     nt = job.nt
 
@@ -431,7 +434,7 @@ def worker(args):
 
     # ---- the other single-GPU configurations, same procedure, fewer steps (default N=1 run only)
     others = None
-    if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs:
+    if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs and not args.limiter:
         others = {}
         for c in ("c3", "c4"):
             try:
@@ -453,6 +456,7 @@ def worker(args):
                "config": {"workload": desc, "nens_per_gpu": nens_pg, "nens_total": nens_total, "nx": nx, "ny": ny,
                           "nz": nz, "num_tracers": nt, "crm_dt": crm_dt, "substeps_per_step": substeps / args.steps,
                           "parallelism": "nens-shard x%d" % world,
+                          "limiter_input": args.limiter, "fct_rows_flagged_last_stage": fct_rows[0], "fct_rows": fct_rows[1],
                           "collective": None if world == 1 else "all-reduce(MIN) of dt, 8 B per timeStep, backend %s%s" % (
                               backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev))},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
@@ -476,6 +480,11 @@ def main():
     ap.add_argument("--chunks", type=int, default=-1, help="internal ensemble chunks / HIP streams (default: automatic)")
     ap.add_argument("--fused", type=int, default=-1, help="1/0: fused x-sweep stage / three-kernel stage (default: library default)")
     ap.add_argument("--lds-floor", type=int, default=0, help="tuning: LDS request per flux workgroup when chunks > 1 (residency cap)")
+    ap.add_argument("--limiter", type=int, default=0,
+                    help="1: input with dry slabs in the water vapour (same place in every member), so that the FCT limiter acts on "
+                         "water_vapor itself in every stage along the slab edges (with one tracer: times the flagged path of the NT=1 "
+                         "tail); 2: slabs at member-dependent places (nearly every row of 64 members flagged: worst case of the "
+                         "sparse multiplier); default 0: smooth vapour")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")

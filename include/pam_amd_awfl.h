@@ -154,6 +154,10 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
 /* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
 /* name: "prim0","prim1","prim2","flux_x","flux_y","flux_z","seed","mult". */
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem);
+/* Row flags of the FCT limiter (a row = (tracer, cell, 64 consecutive members)) as the MOST RECENT tendency
+ * stage left them: rows in which some member was limited in that stage, all rows, and the "some row was flagged" word.
+ * Synchronises the handle's stream.  Tests use it to prove that a case exercises the limiter's sparse paths. */
+int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long long *rows_total, int *any_flagged);
 /* The device WENO reconstruction on n stencils of 5 values (DEVICE, (n,5)): left[i]/right[i] = value at the left/right edge
  * of the centre cell (Dycore.h:591-604 with ind = 0/1).  level < 0: the constant uniform-grid matrices (x, y sweeps);
  * 0 <= level <= nz+1: this handle's vertical matrices of that index, member 0 (z sweep, Dycore.h:454-469). */

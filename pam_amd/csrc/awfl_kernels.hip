@@ -1228,6 +1228,20 @@ int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **
   return PAM_AMD_OK;
 }
 
+int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long long *rows_total, int *any_flagged) {
+  if (!h || !rows_flagged || !rows_total || !any_flagged) return fail(PAM_AMD_EINVAL, "debug_fct_rows: null argument");
+  USE_DEVICE(h);
+  std::vector<int> flags(h->n_fct_flags + 1);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(flags.data(), h->fct_flags, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
+  long long n = 0;
+  for (size_t i = 0; i < h->n_fct_flags; i++) n += (flags[i] == h->fct_seq) ? 1 : 0;
+  *rows_flagged = n;
+  *rows_total = (long long)h->n_fct_flags;
+  *any_flagged = (flags[h->n_fct_flags] == h->fct_seq) ? 1 : 0;
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_debug_weno(pam_amd_awfl_t *h, int level, const double *stencils, int n, double *left, double *right) {
   if (!h || !stencils || !left || !right || n < 0) return fail(PAM_AMD_EINVAL, "debug_weno: bad argument");
   if (level > h->P.nz + 1) return fail(PAM_AMD_EINVAL, "debug_weno: level must be < nz+2 (negative = uniform-grid constants)");

@@ -224,6 +224,12 @@ class Dycore:
         check(self._lib.pam_amd_awfl_debug_get_buffer(self._h, name.encode(), C.byref(ptr), C.byref(n)))
         return _device_view(ptr.value, (n.value,), self._device)
 
+    def debug_fct_rows(self):
+        """(rows flagged by the most recent stage's limiter, rows in all, the "some row was flagged" word) -- test hook"""
+        n, tot, anyw = C.c_longlong(), C.c_longlong(), C.c_int()
+        check(self._lib.pam_amd_awfl_debug_fct_rows(self._h, C.byref(n), C.byref(tot), C.byref(anyw)))
+        return n.value, tot.value, bool(anyw.value)
+
     def debug_weno(self, stencils, level=-1):
         """stencils: (n,5) float64 CUDA tensor -> (left, right) edge values (test hook)"""
         st = stencils.contiguous()

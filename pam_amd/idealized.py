@@ -273,3 +273,28 @@ def add_tracer_blobs(f, tracers, xlen, ylen, zint, rel=1.0e-3):
 def tracer_flags(tracers):
     names = [t[0] for t in tracers]
     return names, [t[1] for t in tracers], [t[2] for t in tracers], names.index("water_vapor")
+
+
+def carve_dry_air(f, tracers, moist_every=4, spread=True):
+    """Exact zeros in the water vapour: per member a dry slab in x, a dry layer in z and (3-D) a dry row in y, at member-dependent
+    places, with every `moist_every`-th member left untouched.  Under the supercell wind the cells on both sides of every
+    moist/dry edge lose more vapour per stage than they hold, so the FCT positivity limiter (Dycore.h:525-550) acts on
+    water_vapor itself in every stage -- the reference limits EVERY positive tracer, vapour included (Dycore.h:533;
+    physics/micro/none/Microphysics.h:61 registers it positive).  Rows of 64 members then hold limited and unlimited members
+    side by side.  spread=False puts the slabs at the same place in every member (edges of one "air mass": rows are flagged
+    along those edges only).  An input choice for tests and for bench.py --limiter; nothing of the reference is restated here."""
+    names = [t[0] for t in tracers]
+    wv = f["tracers"][names.index("water_vapor")]
+    nz, ny, nx, nens = wv.shape
+    for e in range(nens):
+        if moist_every and e % moist_every == moist_every - 1:
+            continue
+        s = e if spread else 0
+        i0, w = (3 * s) % nx, max(1, nx // 3)
+        ii = [(i0 + d) % nx for d in range(w)]
+        wv[:, :, ii, e] = 0.0
+        k0 = nz // 3 + (s % 3)
+        wv[k0:k0 + 2, :, :, e] = 0.0
+        if ny > 1:
+            wv[:, s % ny, :, e] = 0.0
+    return f

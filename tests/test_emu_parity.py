@@ -24,7 +24,22 @@ CASES = {
     "3d_nt4_stretched_B": (2, 6, 6, 8, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(8, 12000.0), {}, False, 8),
     "3d_nt10_perens_A_p3": (3, 6, 4, 8, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(8, 12000.0),
                             dict(per_ens=True, consts=idz.CONSTS_P3), True, 5),
+    # one tracer (water_vapor) limited in every stage: the NT=1 tail's fix-up branch (tracer_update_body with do_tracers only),
+    # mode A and mode B; and mode B with one smooth tracer
+    "3d_nt1_vapour_limited_A": (6, 8, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), dict(dry_air=True), True, 8),
+    "3d_nt1_vapour_limited_B": (5, 6, 4, 8, idz.TRACERS_NONE, idz.stretched_interfaces(8, 12000.0), dict(dry_air=True), False, 3),
+    "3d_nt1_stretched_B": (2, 7, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), {}, False, 8),
 }
+
+
+def _inputs(nens, nx, ny, nz, tr, zint, kw, consts, xlen, ylen):
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=1.0)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if kw.get("dry_air"):
+        f["uvel"] -= 25.0
+        f["vvel"] += 7.0
+        idz.carve_dry_air(f, tr)
+    return f
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["three_kernel_stage", "fused_x_stage"])
@@ -35,8 +50,7 @@ def test_emulated_kernels_match_oracle(case, fused):
     names, pos, mass, idwv = idz.tracer_flags(tr)
     xlen = nx * 500.0
     ylen = ny * 500.0 if ny > 1 else xlen
-    f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=1.0)
-    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    f = _inputs(nens, nx, ny, nz, tr, zint, kw, consts, xlen, ylen)
     dz = np.diff(zint)[:, None] * np.ones((1, nens))
     if kw.get("per_ens"):
         dz = dz * (1 + 0.01 * np.arange(nens))[None, :]
@@ -63,6 +77,9 @@ def test_emulated_kernels_match_oracle(case, fused):
     assert _rel(f2["vvel"], f1["vvel"]) < 1e-9
     for t in range(len(tr)):
         assert _rel(f2["tracers"][t], f1["tracers"][t]) < 1e-11
+    if kw.get("dry_air"):      # the last stage limited vapour: multipliers < 1 exist (unflagged rows are NaN-poisoned when fused)
+        m = g.buffer("mult", (len(tr), nz, ny, nx, nens))
+        assert np.nansum(m < 1.0) > 0 and (f1["tracers"] == 0.0).any()
 
 
 @pytest.mark.parametrize("span", [0, 3], ids=["whole_lines", "spans_of_3"])
@@ -76,8 +93,7 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span):
     names, pos, mass, idwv = idz.tracer_flags(tr)
     xlen = nx * 500.0
     ylen = ny * 500.0 if ny > 1 else xlen
-    f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=1.0)
-    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    f = _inputs(nens, nx, ny, nz, tr, zint, kw, consts, xlen, ylen)
     dz = np.diff(zint)[:, None] * np.ones((1, nens))
     if kw.get("per_ens"):
         dz = dz * (1 + 0.01 * np.arange(nens))[None, :]

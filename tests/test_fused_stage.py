@@ -24,6 +24,10 @@ CASES = {
     # of rows without a limited member are not even stored (FctRows, awfl_device.h); members differ (see _run), so flagged
     # rows hold limited and unlimited members side by side
     "3d_nt4_whole_flag_rows": (128, 6, 6, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, True, idz.CONSTS_DEFAULT),
+    # water_vapor as the only tracer, limited (exact zeros beside moist air): the NT=1 tail (awfl_ptail_kernel + awfl_trfix_kernel)
+    # against the three-kernel stage, whole flag rows (128 = 2 x 64) and a ragged member count
+    "3d_nt1_vapour_limited_rows": (128, 6, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT),
+    "3d_nt1_vapour_limited_ragged_B": (70, 6, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, False, idz.CONSTS_DEFAULT),
     "2d_nt10_whole_flag_rows": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), False, False, idz.CONSTS_P3),
 }
 
@@ -36,6 +40,10 @@ def _run(case, fused, chunks=0, want_mult=False):
     ylen = ny * 500.0 if ny > 1 else xlen
     f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=0.5)
     idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if "vapour_limited" in case:
+        f["uvel"] -= 25.0
+        f["vvel"] += 7.0
+        idz.carve_dry_air(f, tr)
     if nens >= 64:      # every third member: blobs on a positive floor (the limiter stays idle there); every fifth: none at all
         for t, (name, _, _) in enumerate(tr):
             if name == "water_vapor":
@@ -85,7 +93,7 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case):
         assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
 
 
-@pytest.mark.parametrize("case", ["3d_nt4_whole_flag_rows", "2d_nt10_whole_flag_rows"])
+@pytest.mark.parametrize("case", ["3d_nt4_whole_flag_rows", "2d_nt10_whole_flag_rows", "3d_nt1_vapour_limited_rows"])
 def test_flag_row_cases_exercise_the_limiter(case):
     """the cases above are only worth something if rows ARE flagged, and if flagged rows mix limited and unlimited members"""
     _, a = _run(case, fused=False, want_mult=True)
@@ -102,6 +110,14 @@ def test_fct_flag_rows_are_chunking_invariant():
     """ranges of 64 members each carry their own rows of FCT flags (awfl_kernels.hip: fct_rows) == one range"""
     _, a = _run("3d_nt4_whole_flag_rows", fused=True, chunks=1)
     _, b = _run("3d_nt4_whole_flag_rows", fused=True, chunks=2)
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_fused_nt1_limiter_path_is_chunking_invariant():
+    """the NT=1 fix-up pass with two member ranges (each range's wavefronts are whole flag rows) == one range"""
+    _, a = _run("3d_nt1_vapour_limited_rows", fused=True, chunks=1)
+    _, b = _run("3d_nt1_vapour_limited_rows", fused=True, chunks=2)
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.array_equal(a[k], b[k]), k
 

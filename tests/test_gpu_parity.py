@@ -23,7 +23,7 @@ TOL_LOOSE = 1e-9
 
 
 def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True, per_ens=False, mag=0.5, crm_dt=2.0,
-           dxy=500.0):
+           dxy=500.0, dry_air=False):
     import torch
     from pam_amd import Dycore, PamCoupler
     from oracle import awfl_oracle as ao
@@ -33,6 +33,10 @@ def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True
     if supercell:
         f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=mag)
         idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+        if dry_air:      # exact zeros in the vapour beside moist air + a mean wind across the edges: the limiter acts on water_vapor
+            f["uvel"] -= 25.0
+            f["vvel"] += 7.0 if ny > 1 else 0.0
+            idz.carve_dry_air(f, tr)
     else:
         f = idz.dry_bubble_fields(nens, nx, ny, nz, xlen, ylen, zint, consts=consts, tracers=tr)
     zi = np.asarray(zint)[:, None] * np.ones((1, nens))
@@ -74,6 +78,15 @@ CASES = {
     "2d_nt4_stretched_A": (2, 9, 1, 11, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(11, 12000.0), {}, True, 2),
     "3d_nt1_stretched_A": (2, 7, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), {}, True, 2),
     "3d_nt4_stretched_B": (2, 6, 6, 8, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(8, 12000.0), {}, False, 2),
+    # mode B (balance_hydrostasis_with_gravity = false, Dycore.h:313-314,562,678-681) with ONE tracer: the NT=1 tail kernels
+    "3d_nt1_stretched_B": (2, 7, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), {}, False, 2),
+    # water_vapor as the only tracer AND limited in every stage (exact zeros beside moist air, wind across the edges): the
+    # x-sweep's own-multiplier store + row flags and the work branch of awfl_trfix_kernel over several timeSteps, with a member
+    # count that makes every wavefront one whole flag row (64) and a ragged one (70); mode A and mode B
+    "3d_nt1_vapour_limited_nens64": (64, 6, 4, 8, idz.TRACERS_NONE, idz.stretched_interfaces(8, 12000.0), dict(dry_air=True), True, 2),
+    "3d_nt1_vapour_limited_nens70_ragged": (70, 6, 4, 8, idz.TRACERS_NONE, idz.stretched_interfaces(8, 12000.0), dict(dry_air=True), True, 2),
+    "3d_nt1_vapour_limited_B": (5, 6, 4, 8, idz.TRACERS_NONE, idz.stretched_interfaces(8, 12000.0), dict(dry_air=True), False, 2),
+    "2d_nt1_vapour_limited": (66, 9, 1, 10, idz.TRACERS_NONE, idz.stretched_interfaces(10, 12000.0), dict(dry_air=True), True, 2),
     "3d_nt10_perens_A_p3": (3, 6, 4, 8, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(8, 12000.0),
                             dict(per_ens=True, consts=idz.CONSTS_P3), True, 2),
     "2d_bubble_A": (2, 16, 1, 20, idz.TRACERS_NONE, idz.uniform_interfaces(20, 10000.0),
@@ -116,6 +129,9 @@ def test_time_step_matches_oracle(case):
         n_cpu, dt_cpu = oracle.time_step(fo, coupler.get_option("crm_dt"))
         assert n_gpu == n_cpu
         assert abs(dycore.last_dt_dyn - dt_cpu) <= 1e-15 * dt_cpu
+        if kw.get("dry_air"):
+            flagged, total, any_word = dycore.debug_fct_rows()      # the last stage of this timeStep limited vapour somewhere
+            assert 0 < flagged < total and any_word, (flagged, total)
     torch.cuda.synchronize()
     _compare(coupler.dump_fields(), fo, names)
     dycore.finalize(coupler)

@@ -89,6 +89,37 @@ def _fct_case():
     return coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, len(tr))
 
 
+def _nt1_limiter_case(nens=5):
+    """3-D, water_vapor as the ONLY tracer (micro `none`, physics/micro/none/Microphysics.h:60-61: positive, adds mass) with exact
+    zeros: dry slabs in x, y and z at member-dependent places beside moist air, and a mean wind across them.  The limiter then
+    acts on vapour itself in every stage (Dycore.h:533 limits every positive tracer), which on the HIP side is the x-sweep's
+    "own multiplier != 1" store + row flag and the work branch of awfl_trfix_kernel -- the headline config's kernels."""
+    nx, ny, nz = 8, 5, 9
+    tr = idz.TRACERS_NONE
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, zint, mag=1.0)
+    fo["uvel"] -= 25.0
+    fo["vvel"] += 7.0
+    idz.carve_dry_air(fo, tr)
+    coupler.load_fields(fo)
+    return coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, len(tr))
+
+
+LIMITER_CASES = {"nt4_blobs": (_fct_case, idz.TRACERS_KESSLER_SHOC), "nt1_vapour_limited": (_nt1_limiter_case, idz.TRACERS_NONE)}
+
+
+def _assert_limiter_ran(dycore, fused, nt, shape):
+    """the stage that just ran must have limited something: rows flagged in THAT stage (both stage structures set the row
+    flags); with the three-kernel stage the complete multiplier field is there to look at as well"""
+    flagged, total, any_word = dycore.debug_fct_rows()
+    assert flagged > 0 and any_word, (flagged, total, any_word)
+    assert flagged < total, "rows without any limited member must exist too (they are the ones that are skipped)"
+    if not fused:
+        mult = dycore.debug_buffer("mult").cpu().numpy().reshape((nt,) + shape)
+        assert (mult < 1.0).any() and (mult == 1.0).any()
+    return flagged, total
+
+
 def test_fct_limited_fluxes_of_all_fields_and_seed_match_oracle():
     import torch
     coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, nt) = _fct_case()
@@ -144,11 +175,15 @@ def test_fct_limited_fluxes_of_all_fields_and_seed_match_oracle():
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_x_stage", "three_kernel_stage"])
 @pytest.mark.parametrize("mode_a", [True, False], ids=["modeA", "modeB"])
-def test_single_stage_every_prognostic_field_1e12(fused, mode_a):
+@pytest.mark.parametrize("case", sorted(LIMITER_CASES))
+def test_single_stage_every_prognostic_field_1e12(case, fused, mode_a):
     """ONE compute_tendencies + forward-Euler combine (Dycore.h:156-176) from identical inputs: rho, u, v, w, theta, every
-    tracer mixing ratio, the next stage's pressure and the FCT seed, each within 1e-12 * max|field| of the oracle."""
+    tracer mixing ratio, the next stage's pressure and the FCT seed, each within 1e-12 * max|field| of the oracle.  Both cases
+    have the limiter active (asserted): blobs of the non-vapour tracers (NT=4) and vapour itself as the only tracer (NT=1: the
+    x-sweep's own-multiplier store and awfl_trfix_kernel's work branch, in mode A and in mode B)."""
     import torch
-    coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, nt) = _fct_case()
+    mk, trset = LIMITER_CASES[case]
+    coupler, dycore, oracle, fo, names, (nens, nx, ny, nz, nt) = mk()
     if not mode_a:
         coupler.set_option("balance_hydrostasis_with_gravity", False)
         oracle.set_grav_balance(False)
@@ -159,7 +194,7 @@ def test_single_stage_every_prognostic_field_1e12(fused, mode_a):
     seed0 = trc[:, 3:-3, 3:-3, 3:-3, :].copy()
     stend, ttend = oracle.compute_tendencies(st, trc, seed0, dt)                              # st, trc now hold q' (Q5)
     q = st[:, 3:-3, 3:-3, 3:-3, :] + dt * stend
-    pos = np.array([p for _, p, _ in idz.TRACERS_KESSLER_SHOC])
+    pos = np.array([p for _, p, _ in trset])
     tin = trc[:, 3:-3, 3:-3, 3:-3, :]
     t1 = tin + dt * ttend
     t1[pos] = np.maximum(0.0, t1[pos])                                                        # Dycore.h:168-171
@@ -171,6 +206,7 @@ def test_single_stage_every_prognostic_field_1e12(fused, mode_a):
     dycore.convert_coupler_to_dynamics(coupler)
     dycore.debug_stage(dt)
     torch.cuda.synchronize()
+    flagged, total = _assert_limiter_ran(dycore, fused, nt, (nz, ny, nx, nens))
     got = dycore.debug_buffer("prim0").cpu().numpy().reshape(6 + nt, nz + 6, ny, nx, nens)[:, 3:-3]
     gseed = dycore.debug_buffer("seed").cpu().numpy().reshape(nt, nz, ny, nx, nens)
     label = ["rho", "pressure", "u", "v", "w", "theta"] + ["q_" + n for n in names]
@@ -179,13 +215,13 @@ def test_single_stage_every_prognostic_field_1e12(fused, mode_a):
         errs[label[i]] = np.abs(got[i] - e).max() / max(np.abs(e).max(), 1e-300)
     for t in range(nt):
         errs["seed_" + names[t]] = np.abs(gseed[t] - seed1[t]).max() / max(np.abs(seed1[t]).max(), 1e-300)
-    print("single stage, relative to max|field|:", {k: "%.1e" % v for k, v in errs.items()})
+    print("single stage (%d of %d FCT rows flagged), relative to max|field|:" % (flagged, total), {k: "%.1e" % v for k, v in errs.items()})
     for k, v in errs.items():
         assert v <= TOL, (k, v, errs)
     dycore.finalize(coupler)
 
 
-@pytest.mark.parametrize("case", ["3d_nt4_fct", "2d_nt10_p3"])
+@pytest.mark.parametrize("case", ["3d_nt4_fct", "2d_nt10_p3", "3d_nt1_vapour_limited", "3d_nt1_vapour_limited_modeB"])
 def test_single_substep_every_prognostic_field_1e12(case):
     """ONE SSPRK3 sub-step (crm_dt just below the CFL step -> ncycles = 1) through Dycore::timeStep: every coupler field,
     every tracer, gated at the north_star tolerance.  Multi-step runs amplify last-bit differences of the small, noisy
@@ -193,6 +229,11 @@ def test_single_substep_every_prognostic_field_1e12(case):
     import torch
     if case == "3d_nt4_fct":
         coupler, dycore, oracle, fo, names, dims = _fct_case()
+    elif case.startswith("3d_nt1_vapour_limited"):
+        coupler, dycore, oracle, fo, names, dims = _nt1_limiter_case()
+        if case.endswith("modeB"):
+            coupler.set_option("balance_hydrostasis_with_gravity", False)
+            oracle.set_grav_balance(False)
     else:
         coupler, dycore, oracle, fo, names = _setup(5, 16, 1, 20, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(20, 14000.0),
                                                      consts=idz.CONSTS_P3)
@@ -204,6 +245,8 @@ def test_single_substep_every_prognostic_field_1e12(case):
     n2, _ = oracle.time_step(fo, crm_dt)
     assert n == n2 == 1
     torch.cuda.synchronize()
+    if "nt1" in case:
+        assert dycore.debug_fct_rows()[0] > 0, "stage 3 of the sub-step must have limited vapour somewhere"
     got = coupler.dump_fields()
     errs = {k: np.abs(got[k] - fo[k]).max() / max(np.abs(fo[k]).max(), 1e-300) for k in ("density_dry", "uvel", "vvel", "wvel", "temp")}
     for t, nme in enumerate(names):

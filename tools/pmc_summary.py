@@ -8,6 +8,7 @@ load 8 B per lane (512 B per wavefront instruction), an access width the guide c
 the x2 figure are printed.
 """
 import csv
+import os
 import sys
 from collections import defaultdict
 
@@ -79,7 +80,7 @@ def main():
                          "write_bytes_per_stage": write / nstage}
         i = sys.argv.index("--traffic-json")
         print(json.dumps({"csrc_hash": sys.argv[i + 1], "kernels": res,
-                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --chunks 1, config c2"}))
+                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py, config %s" % os.environ.get("PMC_SOURCE_CONFIG", "c2")}))
 
 
 if __name__ == "__main__":
