@@ -55,7 +55,7 @@ CONFIGS = {
     "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
     "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
 }
-STAGE_KERNELS = ("flux", "xupd", "xtr", "fct_mult", "trupd", "update")
+STAGE_KERNELS = ("flux", "xupd", "xtr1", "xtr2", "ptail", "trfix", "fct_mult", "update")
 
 
 def csrc_hash():
@@ -286,15 +286,24 @@ def stage_rooflines(job, alone):
     if fused:
         nyz = nall - 1                     # the flux kernel sweeps y (3-D only) and z: mass + tracers as faces, the rest as differences
         acct["flux"] = (nyz * (6 + nt) * pb + nyz * (5 + nt) * fb, cells * nyz * (6 + nt) * poly)
-        # fused x-sweep: the state and tracer 0 complete (stage input 6+nt fields, sub-step start 6, y/z flux differences 5 and
-        # tracer-0 faces 1 per direction, FCT seed; writes rho, u, v, w, theta, rho*theta, tracer 0, its seed, the tracer x fluxes
-        # (+ the face mass flux when further tracers follow))
-        acct["xupd"] = ((6 + nt) * pb + (2.0 / 3.0) * 6 * pb + nyz * 6 * fb + fb + 7 * pb + fb + (nt + (1 if nt > 1 else 0)) * fb,
-                        cells * ((6 + nt) * poly + 6 * 60.0 + 40.0))
-        ntr = nt - 1                       # tracers left to the pointwise tail (tracer 0 only where the limiter acted)
-        acct["fct_mult"] = (ntr * (nall + 2) * fb, cells * ntr * 20.0)
-        acct["trupd"] = (ntr * (nall + 1) * fb + ntr * pb * (1 + 2.0 / 3.0) + (pb * (2 + 2.0 / 3.0) if ntr else 0.0) + 2 * pb
-                         + ntr * pb + ntr * fb, cells * (ntr * 60.0 + 250.0))
+        # fused x-sweep: the state and tracer 0 complete (stage input 7 fields, sub-step start 6, y/z flux differences 5 and
+        # tracer-0 faces 1 per direction, FCT seed; writes rho, u, v, w, theta, rho*theta, tracer 0, its seed, its x flux (+ the face
+        # mass flux when further tracers follow))
+        state = (7 * pb + (2.0 / 3.0) * 6 * pb + nyz * 6 * fb + fb + 7 * pb + 2 * fb + (fb if nt > 1 else 0), cells * (7 * poly + 6 * 60.0 + 40.0))
+        # sweeps of the further tracers.  Phase 1 (FCT multipliers): per tracer the stage input, its y/z faces and seed, per pair
+        # the face mass flux; writes only multipliers of limited rows.  Phase 2 (complete update): per tracer the stage input, the
+        # sub-step start, its y/z faces (+ multipliers in flagged neighbourhoods), per pair the mass flux and the three densities;
+        # writes the new value and seed
+        ntr, npair = nt - 1, nt // 2
+        ph1 = (ntr * (pb + nyz * fb + fb) + npair * fb, cells * ntr * (poly + 20.0))
+        ph2 = (ntr * (pb + (2.0 / 3.0) * pb + nyz * fb + pb + fb) + npair * (fb + (2 + 2.0 / 3.0) * pb), cells * ntr * (poly + 60.0))
+        if "xtr1" in alone:
+            acct["xupd"], acct["xtr1"] = state, ph1
+        else:
+            acct["xupd"] = (state[0] + ph1[0], state[1] + ph1[1])
+        acct["xtr2"] = ph2
+        acct["ptail"] = (2 * fb, cells * 250.0)
+        acct["trfix"] = (0.0, 0.0)         # only where the limiter acted
     else:
         acct["flux"] = (nall * (6 + nt) * pb + nall * (5 + nt) * fb, cells * nall * (6 + nt) * poly)
         acct["fct_mult"] = (nt * (nall + 2) * fb, cells * nt * 20.0)
@@ -307,12 +316,12 @@ def stage_rooflines(job, alone):
             continue
         s = alone[name]["total_ms"] / nstage * 1e-3
         kname = "awfl_%s_kernel" % name.replace("fct_mult", "fct")
-        if name == "trupd" and nt == 1:    # one tracer: the tail is two launches under one timer (awfl_kernels.hip: launch_trupd)
-            kname = "awfl_ptail_kernel+awfl_trfix_kernel"
+        if name.startswith("xtr"):
+            kname = "awfl_xtr_kernel<%s>" % name[3:]
         out.append({"kernel": kname, "ms_per_stage": alone[name]["total_ms"] / nstage,
                     "launches_per_stage": alone[name]["launches"] / nstage,
-                    "own_bytes_per_launch": nbytes, "own_GBps": nbytes / s / 1e9, "hbm_frac": nbytes / s / 1e9 / HBM_PEAK_GBS,
-                    "fp64_flops_per_launch": flops, "fp64_TFLOPs": flops / s / 1e12,
+                    "own_bytes_per_stage": nbytes, "own_GBps": nbytes / s / 1e9, "hbm_frac": nbytes / s / 1e9 / HBM_PEAK_GBS,
+                    "fp64_flops_per_stage": flops, "fp64_TFLOPs": flops / s / 1e12,
                     "valu_frac": flops / s / 1e12 / FP64_VALU_PEAK_TFLOPS})
     return out
 

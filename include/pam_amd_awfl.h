@@ -129,7 +129,7 @@ int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_aw
 /* Enable HIP-event timing of every kernel launch on the handle's stream (off by default: zero overhead). */
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
 /* Accumulated device time (ms) and launch count of kernel `name` ("flux","fct_mult","update","init_prim",
- * "finalize","cfl","hydro","xupd","xtr","trupd") since the last reset; synchronises the stream. */
+ * "finalize","cfl","hydro","xupd","xtr1","xtr2","ptail","trfix") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 /* Sweep-kernel tuning knobs; results do not depend on them (bit for bit).
@@ -155,7 +155,8 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
 /* name: "prim0","prim1","prim2","flux_x","flux_y","flux_z","seed","mult". */
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem);
 /* Row flags of the FCT limiter (a row = (tracer, cell, 64 consecutive members)) as the MOST RECENT tendency
- * stage left them: rows in which some member was limited in that stage, all rows, and the "some row was flagged" word.
+ * stage left them: rows in which some member was limited in that stage, all rows, and the "some row was flagged" word (fused
+ * stage: some row of the FIRST tracer -- the word the fix-up pass looks at; three-kernel stage: of any tracer).
  * Synchronises the handle's stream.  Tests use it to prove that a case exercises the limiter's sparse paths. */
 int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long long *rows_total, int *any_flagged);
 /* The device WENO reconstruction on n stencils of 5 values (DEVICE, (n,5)): left[i]/right[i] = value at the left/right edge

@@ -488,6 +488,18 @@ PAMA_D int wrap(int c, int n) {
   return c < 0 ? c + n : c;
 }
 
+// 2-D (ny == 1): the v tendency is zero whatever the fluxes are (Dycore.h:559 `if (sim2d) ... = 0`), so the fused stage (DIFF
+// sweeps + x-sweep) neither reconstructs v nor stores / loads its flux differences.  The three-kernel stage keeps every face
+// flux (the kernel-level parity tests compare them all with the oracle).
+#if defined(__HIPCC__)
+#define PAMA_HD __host__ __device__ inline
+#else
+#define PAMA_HD inline
+#endif
+PAMA_HD bool skip_advected_v(const Params &P, bool diff) { return diff && P.sim2d; }
+// advected fields a sweep visits after pass 1 (everything but the normal velocity; see above), in pairs (host: launch geometry)
+PAMA_HD int flux_sweep_pairs(const Params &P, bool diff) { return (3 + P.nt - (skip_advected_v(P, diff) ? 1 : 0) + 1) / 2; }
+
 // Body of the reconstruction + flux kernel for one lane.
 //   DIR      sweep direction
 //   line     wave-uniform index of the line: x: k*ny + j, y: k*nx + i, z: j*nx + i        e   ensemble member of this lane
@@ -690,6 +702,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   int fa[FLUX_NF], nfa = 0, ipair = 0;
   for (int a = 0; a < nadv; a++) {
     if (P_U + a == ncomp) continue;
+    if (skip_advected_v(P, DIFF) && a == 1) continue;
     fa[nfa++] = a;
     if (nfa == FLUX_NF) {
       ipair++;
@@ -865,16 +878,24 @@ PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, cons
 //                  three-kernel stage, the host emulation) they are always stored.
 //   any            one more int: == seq when ANY row of any tracer was flagged in this stage (the fix-up launch of the NT=1
 //                  tail leaves at once when it is not)
+//   lines          (nt, nz, ny, ceil(nens/64)) ints, same convention: == seq when some row of the x line (k, j) of that tracer and
+//                  member block was flagged in this stage.  The fix-up pass of the fused stage (tracer_fixup_line_body) is driven by
+//                  them: a wavefront per (tracer, x line, member block) looks at its own line flag and those of the four
+//                  neighbouring lines and leaves unless one of them is set.
 struct FctRows {
-  int *flags;          // (nt, nz, ny, nx, ceil(nens/64)); nullptr: no flags, every multiplier is stored and loaded
+  int *flags;          // (nt, nz, ny, ceil(nens/64), nx); nullptr: no flags, every multiplier is stored and loaded
   int *any;
+  int *lines;          // (nt, nz, ny, ceil(nens/64)); nullptr where the stage structure has no use for them
   int seq;
   int sparse_store;
 };
 PAMA_D long long fct_rows_per_tracer(const Params &P) { return (long long)P.nz * P.ny * P.nx * ((P.nens + 63) >> 6); }
+// layout (tracer, level, y, member block, x)
 PAMA_D long long fct_row(const Params &P, int k, int j, int i, int e) {
-  return (((long long)k * P.ny + j) * P.nx + i) * ((P.nens + 63) >> 6) + (e >> 6);
+  return (((long long)k * P.ny + j) * ((P.nens + 63) >> 6) + (e >> 6)) * P.nx + i;
 }
+PAMA_D long long fct_lines_per_tracer(const Params &P) { return (long long)P.nz * P.ny * ((P.nens + 63) >> 6); }
+PAMA_D long long fct_line(const Params &P, int k, int j, int e) { return ((long long)k * P.ny + j) * ((P.nens + 63) >> 6) + (e >> 6); }
 // "some lane of this wavefront": for decisions to STORE something for the whole row (the host emulation, which runs lane by
 // lane, always stores) ...
 PAMA_D bool wave_any(bool x) {
@@ -896,15 +917,20 @@ PAMA_D bool wave_any_or_lane(bool x) {
 
 // FCT multiplier of a positive-definite tracer in one cell (Dycore.h:533-540) from the mass seed and the six face fluxes:
 // 1 unless the fluxes leaving the cell in `dt` carry more than the mass available.
+//   rdzk = fast_rcp(dzk).  The three divisions by the grid spacings are reciprocal multiplies (<= 1 ulp each, as in
+//   flux_divergence); the one true division -- the multiplier itself -- is executed only by wavefronts with a limited member.
 PAMA_D double fct_multiplier(const Params &P, double seed_v, double xlo, double xhi, double ylo, double yhi, double zlo,
-                             double zhi, double dzk, double dt) {
+                             double zhi, double dzk, double rdzk, double dt) {
 #pragma clang fp contract(off)
-  double mass_available = fmax(seed_v, 0.0) * P.dx * P.dy * dzk;
-  double flux_out_x = (fmax(xhi, 0.0) - fmin(xlo, 0.0)) / P.dx;
-  double flux_out_y = P.sim2d ? 0.0 : (fmax(yhi, 0.0) - fmin(ylo, 0.0)) / P.dy;
-  double flux_out_z = (fmax(zhi, 0.0) - fmin(zlo, 0.0)) / dzk;
-  double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
-  return (mass_out > mass_available) ? mass_available / mass_out : 1.0;
+  const double mass_available = fmax(seed_v, 0.0) * P.dx * P.dy * dzk;
+  const double flux_out_x = (fmax(xhi, 0.0) - fmin(xlo, 0.0)) * P.rdx;
+  const double flux_out_y = P.sim2d ? 0.0 : (fmax(yhi, 0.0) - fmin(ylo, 0.0)) * P.rdy;
+  const double flux_out_z = (fmax(zhi, 0.0) - fmin(zlo, 0.0)) * rdzk;
+  const double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * P.dx * P.dy * dzk;
+  const bool limited = mass_out > mass_available;
+  double m = 1.0;
+  if (wave_any_or_lane(limited)) m = limited ? mass_available / mass_out : 1.0;
+  return m;
 }
 
 // FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
@@ -915,6 +941,7 @@ PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const 
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const double dzk = P.dz[(long long)k * P.nens + e];
+  const double rdzk = fast_rcp(dzk);
   const long long ip1 = idx + ((i == P.nx - 1) ? -(long long)(P.nx - 1) * P.sx : P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
   for (int t = t0; t < P.nt; t++) {
@@ -924,7 +951,7 @@ PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const 
       const double *ty = fy + (long long)(5 + t) * P.ncell;
       const double *tz = fz + (long long)(5 + t) * P.fz_fs;
       m = fct_multiplier(P, seed[(long long)t * P.ncell + idx], tx[idx], tx[ip1], P.sim2d ? 0.0 : ty[idx],
-                         P.sim2d ? 0.0 : ty[jp1], tz[idx], tz[idx + P.sz], dzk, dt);
+                         P.sim2d ? 0.0 : ty[jp1], tz[idx], tz[idx + P.sz], dzk, rdzk, dt);
     }
     bool store = true;
     if (rows.flags) {
@@ -950,19 +977,27 @@ PAMA_D double limited_flux(double F, double ml, double mh, bool seam) {
 
 
 
-// Is the cell's own flag row or one of its six neighbours' (tracer t) flagged by this stage's FCT pass?  All seven flags are
-// requested unconditionally (a guarded load is a branch with a full memory round trip behind it): in 2-D the y offsets are 0,
-// at the walls the z offsets are clamped to the cell itself.
-PAMA_D bool fct_flagged_near(const Params &P, const FctRows &rows, int t, int k, int j, int i, int e) {
-  const long long nblk = (P.nens + 63) >> 6;
+// The flags of the cell's own row and of its six neighbours' (tracer t): was the row flagged by this stage's limiter?  All seven
+// are requested unconditionally (a guarded load is a branch with a full memory round trip behind it): in 2-D the y offsets are
+// 0, at the walls the z offsets are clamped to the cell itself (and the answer forced to false).
+struct NearFlags { bool c, im1, ip1, jm1, jp1, km1, kp1; };
+PAMA_D bool any_of(const NearFlags &g) { return g.c | g.im1 | g.ip1 | g.jm1 | g.jp1 | g.km1 | g.kp1; }
+PAMA_D NearFlags fct_near_flags(const Params &P, const FctRows &rows, int t, int k, int j, int i, int e) {
+  const long long lstride = (long long)((P.nens + 63) >> 6) * P.nx;     // from one x line to the next in y (same member block)
   const int *fl = rows.flags + (long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e);
-  const long long r_ip1 = (i == P.nx - 1) ? -(long long)(P.nx - 1) * nblk : nblk, r_im1 = (i == 0) ? (long long)(P.nx - 1) * nblk : -nblk;
-  const long long r_jp1 = ((j == P.ny - 1) ? -(long long)(P.ny - 1) : 1) * P.nx * nblk, r_jm1 = ((j == 0) ? (long long)(P.ny - 1) : -1) * P.nx * nblk;
-  const long long r_kz = (long long)P.ny * P.nx * nblk;
+  const long long r_ip1 = (i == P.nx - 1) ? -(long long)(P.nx - 1) : 1, r_im1 = (i == 0) ? (long long)(P.nx - 1) : -1;
+  const long long r_jp1 = ((j == P.ny - 1) ? -(long long)(P.ny - 1) : 1) * lstride, r_jm1 = ((j == 0) ? (long long)(P.ny - 1) : -1) * lstride;
+  const long long r_kz = (long long)P.ny * lstride;
   const bool zl = (k > 0), zh = (k < P.nz - 1);
   const int sq = rows.seq;
   const int a0 = fl[0], a1 = fl[r_im1], a2 = fl[r_ip1], a3 = fl[r_jm1], a4 = fl[r_jp1], a5 = fl[zl ? -r_kz : 0], a6 = fl[zh ? r_kz : 0];
-  return (a0 == sq) | (a1 == sq) | (a2 == sq) | (a3 == sq) | (a4 == sq) | (zl & (a5 == sq)) | (zh & (a6 == sq));
+  NearFlags g;
+  g.c = (a0 == sq); g.im1 = (a1 == sq); g.ip1 = (a2 == sq); g.jm1 = (a3 == sq); g.jp1 = (a4 == sq);
+  g.km1 = zl & (a5 == sq); g.kp1 = zh & (a6 == sq);
+  return g;
+}
+PAMA_D bool fct_flagged_near(const Params &P, const FctRows &rows, int t, int k, int j, int i, int e) {
+  return any_of(fct_near_flags(P, rows, t, k, j, i, e));
 }
 
 // New conserved value and next FCT seed of one tracer in one cell from its six (limited) face fluxes: divergence, SSPRK3
@@ -981,15 +1016,17 @@ PAMA_D void tracer_new_value(const Params &P, int t, double f_x, double f_xp1, d
   new_seed = next_seed<STAGE>(m_0, m_in, v);
 }
 
-// Tracer part of the stage update of one cell (Dycore.h:553-584 with the FCT-limited fluxes, :162-221): shared by the
-// one-kernel update (update_body) and by the tracer-only update that follows the fused x-sweep (tracer_update_body), so
-// that both paths perform the same arithmetic.  rho_in / rho_0: density of the stage input / sub-step start; rrho:
-// reciprocal of the NEW density.  Loads of prim_in/prim0 for tracer t happen before the store of tracer t (alias-safe).
+// Stage update of ONE tracer in one cell (Dycore.h:553-584 with the FCT-limited fluxes, :162-221): shared by the one-kernel
+// update (update_body) and by the fix-up pass that follows the fused x-sweeps (tracer_fixup_line_body), so that both paths
+// perform the same arithmetic.  rho_in / rho_0: density of the stage input / sub-step start; rrho: reciprocal of the NEW
+// density.  Loads of prim_in/prim0 happen before the store (alias-safe).
+//   only_near_flagged   (fix-up) the sweep has already stored the update the cell gets when neither it nor a neighbour is
+//                       limited (and the cell's own multiplier + row flag): redo the cell only where one of the seven rows is flagged
 template <int STAGE>
-PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
-                               const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
-                               const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
-                               const CellId &c, double rho_in, double rho_0, double rrho, double rdzk, bool tr0_done = false) {
+PAMA_D void tracer_update_one(const Params &P, int t, const double *prim_in, const double *prim0, double *prim_out,
+                              const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                              const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
+                              const CellId &c, double rho_in, double rho_0, double rrho, double rdzk, bool only_near_flagged) {
   const int k = c.k, j = c.j, i = c.i, e = c.e;
   const long long idx = c.idx;
   const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
@@ -998,112 +1035,114 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
   const long long im1 = idx + ((i == 0) ? (long long)(P.nx - 1) * P.sx : -P.sx);
   const long long jp1 = idx + ((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy);
   const long long jm1 = idx + ((j == 0) ? (long long)(P.ny - 1) * P.sy : -P.sy);
-  // the same neighbours in units of flag rows (fct_row)
-  const long long nblk = (P.nens + 63) >> 6, row_c = fct_row(P, k, j, i, e);
-  const long long r_ip1 = (i == P.nx - 1) ? -(long long)(P.nx - 1) * nblk : nblk, r_im1 = (i == 0) ? (long long)(P.nx - 1) * nblk : -nblk;
-  const long long r_jp1 = ((j == P.ny - 1) ? -(long long)(P.ny - 1) : 1) * P.nx * nblk, r_jm1 = ((j == 0) ? (long long)(P.ny - 1) : -1) * P.nx * nblk;
-  const long long r_kz = (long long)P.ny * P.nx * nblk;
-  for (int t = 0; t < P.nt; t++) {
-    const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
-    const double *tz = fz + (long long)(5 + t) * P.fz_fs;
-    const double *mt = mult + (long long)t * P.ncell;
-    // Tracer 0 after the fused x-sweep: the sweep has already stored the update every cell gets when neither it nor a
-    // neighbour is limited (and the cell's own multiplier + row flag).  Only the neighbourhoods of flagged rows are redone here,
-    // with the complete arithmetic below; everywhere else nothing but the seven flags is read.
-    if (t == 0 && tr0_done && rows.flags) {
-      if (!wave_any_or_lane(fct_flagged_near(P, rows, 0, k, j, i, e))) continue;
+  const double *tx = fx + (long long)(5 + t) * P.ncell, *ty = fy + (long long)(5 + t) * P.ncell;
+  const double *tz = fz + (long long)(5 + t) * P.fz_fs;
+  const double *mt = mult + (long long)t * P.ncell;
+  if (only_near_flagged && rows.flags) {
+    if (!wave_any_or_lane(fct_flagged_near(P, rows, t, k, j, i, e))) return;
+  }
+  // Multipliers of the cell and its six neighbours: loaded only when one of their rows was flagged by this stage's limiter,
+  // else exactly 1.0.  ONE wave-uniform branch: the seven flags and every other input of the cell are requested first and are
+  // in flight together; in the (rare) flagged case all seven multipliers are loaded unconditionally and the ones from unflagged
+  // rows (possibly never written) are discarded by the select.
+  const bool zlo = (k > 0), zhi = (k < P.nz - 1);
+  double m_c = 1.0, m_im1 = 1.0, m_ip1 = 1.0, m_jm1 = 1.0, m_jp1 = 1.0, m_km1 = 1.0, m_kp1 = 1.0;
+  const double Fx = tx[idx], Fxp1 = tx[ip1], Fz = tz[idx], Fzp1 = tz[idx + P.sz];
+  const double Fy = P.sim2d ? 0.0 : ty[idx], Fyp1 = P.sim2d ? 0.0 : ty[jp1];
+  const int pf = P_TR0 + t;
+  const double q_in = prim_in[pf * P.prim_fs + o];
+  const double q_0 = (STAGE > 1) ? prim0[pf * P.prim_fs + o] : 0.0;
+  if (rows.flags) {
+    const NearFlags g = fct_near_flags(P, rows, t, k, j, i, e);
+    if (wave_any(any_of(g))) {
+      const double l_c = mt[idx], l_im1 = mt[im1], l_ip1 = mt[ip1], l_jm1 = mt[jm1], l_jp1 = mt[jp1];
+      const double l_km1 = mt[zlo ? idx - P.sz : idx], l_kp1 = mt[zhi ? idx + P.sz : idx];
+      m_c = g.c ? l_c : 1.0; m_im1 = g.im1 ? l_im1 : 1.0; m_ip1 = g.ip1 ? l_ip1 : 1.0;
+      m_jm1 = g.jm1 ? l_jm1 : 1.0; m_jp1 = g.jp1 ? l_jp1 : 1.0;
+      m_km1 = g.km1 ? l_km1 : 1.0; m_kp1 = g.kp1 ? l_kp1 : 1.0;
     }
-    // Multipliers of the cell and its six neighbours: loaded only when one of their rows was flagged by this stage's FCT
-    // kernel, else exactly 1.0.  ONE wave-uniform branch: the seven flags and every other input of the cell are requested
-    // first and are in flight together; in the (rare) flagged case all seven multipliers are loaded unconditionally and the
-    // ones from unflagged rows (possibly never written) are discarded by the select.
-    const bool zlo = (k > 0), zhi = (k < P.nz - 1);
-    double m_c = 1.0, m_im1 = 1.0, m_ip1 = 1.0, m_jm1 = 1.0, m_jp1 = 1.0, m_km1 = 1.0, m_kp1 = 1.0;
-    const double Fx = tx[idx], Fxp1 = tx[ip1], Fz = tz[idx], Fzp1 = tz[idx + P.sz];
-    const double Fy = P.sim2d ? 0.0 : ty[idx], Fyp1 = P.sim2d ? 0.0 : ty[jp1];
-    const int pf = P_TR0 + t;
-    const double q_in = prim_in[pf * P.prim_fs + o];
-    const double q_0 = (STAGE > 1) ? prim0[pf * P.prim_fs + o] : 0.0;
-    if (rows.flags) {
-      const int *fl = rows.flags + (long long)t * fct_rows_per_tracer(P) + row_c;
-      const int sq = rows.seq;
-      // all seven flags are requested unconditionally (no short-circuit: a guarded load is a branch with a full memory round
-      // trip behind it); in 2-D the y offsets are 0, at the walls the z offsets are clamped to the cell itself
-      const int a_c = fl[0], a_im1 = fl[r_im1], a_ip1 = fl[r_ip1], a_jm1 = fl[r_jm1], a_jp1 = fl[r_jp1];
-      const int a_km1 = fl[zlo ? -r_kz : 0], a_kp1 = fl[zhi ? r_kz : 0];
-      const bool g_c = (a_c == sq), g_im1 = (a_im1 == sq), g_ip1 = (a_ip1 == sq), g_jm1 = (a_jm1 == sq), g_jp1 = (a_jp1 == sq);
-      const bool g_km1 = zlo & (a_km1 == sq), g_kp1 = zhi & (a_kp1 == sq);
-      if (wave_any(g_c | g_im1 | g_ip1 | g_jm1 | g_jp1 | g_km1 | g_kp1)) {
-        const double l_c = mt[idx], l_im1 = mt[im1], l_ip1 = mt[ip1], l_jm1 = mt[jm1], l_jp1 = mt[jp1];
-        const double l_km1 = mt[zlo ? idx - P.sz : idx], l_kp1 = mt[zhi ? idx + P.sz : idx];
-        m_c = g_c ? l_c : 1.0; m_im1 = g_im1 ? l_im1 : 1.0; m_ip1 = g_ip1 ? l_ip1 : 1.0;
-        m_jm1 = g_jm1 ? l_jm1 : 1.0; m_jp1 = g_jp1 ? l_jp1 : 1.0;
-        m_km1 = g_km1 ? l_km1 : 1.0; m_kp1 = g_kp1 ? l_kp1 : 1.0;
-      }
-    } else {
-      m_c = mt[idx]; m_im1 = mt[im1]; m_ip1 = mt[ip1];
-      if (!P.sim2d) { m_jm1 = mt[jm1]; m_jp1 = mt[jp1]; }
-      if (zlo) m_km1 = mt[idx - P.sz];
-      if (zhi) m_kp1 = mt[idx + P.sz];
-    }
-    double f_x = limited_flux(Fx, m_im1, m_c, i == 0);
-    double f_xp1 = limited_flux(Fxp1, m_c, m_ip1, i == P.nx - 1);
-    double f_y = 0.0, f_yp1 = 0.0;
-    if (!P.sim2d) {
-      f_y = limited_flux(Fy, m_jm1, m_c, j == 0);
-      f_yp1 = limited_flux(Fyp1, m_c, m_jp1, j == P.ny - 1);
-    }
-    // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
-    const double f_z = limited_flux(Fz, m_km1, m_c, false);
-    const double f_zp1 = limited_flux(Fzp1, m_c, m_kp1, false);
-    double v, new_seed;
-    tracer_new_value<STAGE>(P, t, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, q_in, q_0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
-    seed[(long long)t * P.ncell + idx] = new_seed;
-    store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
+  } else {
+    m_c = mt[idx]; m_im1 = mt[im1]; m_ip1 = mt[ip1];
+    if (!P.sim2d) { m_jm1 = mt[jm1]; m_jp1 = mt[jp1]; }
+    if (zlo) m_km1 = mt[idx - P.sz];
+    if (zhi) m_kp1 = mt[idx + P.sz];
+  }
+  double f_x = limited_flux(Fx, m_im1, m_c, i == 0);
+  double f_xp1 = limited_flux(Fxp1, m_c, m_ip1, i == P.nx - 1);
+  double f_y = 0.0, f_yp1 = 0.0;
+  if (!P.sim2d) {
+    f_y = limited_flux(Fy, m_jm1, m_c, j == 0);
+    f_yp1 = limited_flux(Fyp1, m_c, m_jp1, j == P.ny - 1);
+  }
+  // vertical: wall faces carry zero flux; interior faces are shared with the cell below / above
+  const double f_z = limited_flux(Fz, m_km1, m_c, false);
+  const double f_zp1 = limited_flux(Fzp1, m_c, m_kp1, false);
+  double v, new_seed;
+  tracer_new_value<STAGE>(P, t, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, q_in, q_0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+  seed[(long long)t * P.ncell + idx] = new_seed;
+  store_adv(P, prim_out, pf, k, c2, v * rrho, v * rrho);
+}
+
+// every tracer of the cell (the one-kernel update of the three-kernel stage)
+template <int STAGE>
+PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
+                               const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                               const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
+                               const CellId &c, double rho_in, double rho_0, double rrho, double rdzk) {
+  for (int t = 0; t < P.nt; t++)
+    tracer_update_one<STAGE>(P, t, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk, false);
+}
+
+// Fix-up pass of the fused stage.  Every tracer has been advanced by its x-sweep (tracer 0 in the state pass of
+// flux_x_update_body, the others in x_tracer_sweep) with the update a cell gets when neither it nor one of its six neighbours is
+// limited, and the sweeps have stored the multipliers of limited cells, their row flags and -- per tracer, x line and member
+// block -- a line flag.  This pass redoes, with the complete arithmetic (tracer_update_one), exactly the neighbourhoods of flagged
+// rows.  Work unit: (tracer t, x line (k, j), block of 64 members), lanes = members: five line flags (the line itself and its
+// four neighbours in y and z; the x neighbours of a cell are on the line) decide whether the wavefront has anything to do at
+// all -- where the limiter is idle (a smooth positive field such as water vapour) it leaves after one round of loads -- and on
+// the lines that do, each cell looks at its seven row flags (Dycore.h:525-550, :572-584, :162-221).
+template <int STAGE>
+PAMA_D void tracer_fixup_line_body(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
+                                   const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                                   const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
+                                   int t, int k, int j, int e) {
+  {
+    const int *ln = rows.lines + (long long)t * fct_lines_per_tracer(P);
+    const int sq = rows.seq;
+    const bool zl = (k > 0), zh = (k < P.nz - 1);
+    const int jm = (j == 0) ? P.ny - 1 : j - 1, jp = (j == P.ny - 1) ? 0 : j + 1;
+    const int a0 = ln[fct_line(P, k, j, e)], a1 = ln[fct_line(P, k, jm, e)], a2 = ln[fct_line(P, k, jp, e)];
+    const int a3 = ln[fct_line(P, zl ? k - 1 : k, j, e)], a4 = ln[fct_line(P, zh ? k + 1 : k, j, e)];
+    if (!wave_any_or_lane((a0 == sq) | (a1 == sq) | (a2 == sq) | (a3 == sq) | (a4 == sq))) return;
+  }
+  const double rdzk = fast_rcp(P.dz[(long long)k * P.nens + e]);
+  for (int i = 0; i < P.nx; i++) {
+    if (!wave_any_or_lane(fct_flagged_near(P, rows, t, k, j, i, e))) continue;
+    CellId c;
+    c.k = k; c.j = j; c.i = i; c.e = e;
+    c.idx = (((long long)k * P.ny + j) * P.nx + i) * P.nens + e;
+    const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
+    const double rho_new = prim_out[P_RHO * P.prim_fs + o];
+    const double rho_in = prim_in[P_RHO * P.prim_fs + o];
+    const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
+    tracer_update_one<STAGE>(P, t, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0,
+                             fast_rcp(rho_new), rdzk, false);   // (the seven flags were just looked at)
   }
 }
 
-// Pointwise remainder of the fused stage: tracer update + next stage's pressure.  The state variables were advanced by the
-// fused x-sweep (flux_x_update_body), which left the new density, the new theta and -- in the pressure slot -- the new
-// rho*theta in prim_out.  rrho = fast_rcp(new density) is bitwise what update_body derives from its own qs[0].
-template <int STAGE>
-PAMA_D void tracer_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
-                               double *prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
-                               const double *__restrict__ fz, const double *__restrict__ mult, const FctRows &rows,
-                               double *__restrict__ seed, double dt_dyn, const CellId &c, bool tr0_done = false,
-                               bool do_tracers = true, bool do_pressure = true) {
-  // do_tracers / do_pressure: with one tracer the tail runs as two launches -- a lean pressure pass (a pow per cell at full
-  // occupancy) and a fix-up pass of the tracer that leaves at once unless the limiter acted somewhere in this stage
+// Pointwise remainder of the fused stage: the next stage's pressure (Dycore.h:310-321) and the density / pressure ghosts
+// (:682-709).  The state variables and every tracer were advanced by the fused x-sweeps (flux_x_update_body), which left the
+// new density, the new theta and -- in the pressure slot -- the new rho*theta in prim_out: a pow per cell and nothing else, so
+// few registers and full occupancy (kept out of the register-critical sweep loop; VALU-bound on the pow).
+PAMA_D void pressure_tail_body(const Params &P, double *prim_out, const CellId &c) {
   const long long c2 = (long long)c.j * P.sy + (long long)c.i * P.sx + c.e;
   const long long o = (long long)(c.k + HS) * P.sz + c2;
-  // the fused x-sweep left the new rho*theta where the pressure belongs (Dycore.h:310-321, :682-709)
-  // (theta and the new density are needed for the density/pressure ghosts only, i.e. on the two boundary levels).  Requested
-  // BEFORE the tracer update: its stores may alias prim_out, so the compiler would otherwise start these loads -- a second
-  // memory round trip in a kernel that is nothing but memory latency -- only after them.
+  // theta and the new density are needed for the density/pressure ghosts only, i.e. on the two boundary levels
   const bool boundary = (c.k == 0 || c.k == P.nz - 1);
-  double th = 0.0, rho_theta = 0.0;
-  if (do_pressure) {
-    th = boundary ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
-    rho_theta = prim_out[P_PRES * P.prim_fs + o];
-  }
-  // With water vapour as the only tracer and the limiter idle around the cell there is no tracer work left at all (the
-  // x-sweep's update of tracer 0 stands): then not even the densities are read.
-  bool tracer_work = do_tracers;
-  if (do_tracers && tr0_done && P.nt == 1 && rows.flags) {
-    tracer_work = (*rows.any == rows.seq);
-    if (tracer_work) tracer_work = wave_any_or_lane(fct_flagged_near(P, rows, 0, c.k, c.j, c.i, c.e));
-  }
-  double rho_new = 0.0;
-  if (tracer_work || (do_pressure && boundary)) rho_new = prim_out[P_RHO * P.prim_fs + o];
-  if (tracer_work) {
-    const double rho_in = prim_in[P_RHO * P.prim_fs + o];
-    const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
-    const double rrho = fast_rcp(rho_new);
-    const double rdzk = fast_rcp(P.dz[(long long)c.k * P.nens + c.e]);
-    tracer_update_part<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk,
-                              tr0_done);
-  }
-  if (do_pressure) store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, rho_theta, !P.grav_balance);
+  const double th = boundary ? prim_out[P_THETA * P.prim_fs + o] : 0.0;
+  const double rho_theta = prim_out[P_PRES * P.prim_fs + o];
+  const double rho_new = boundary ? prim_out[P_RHO * P.prim_fs + o] : 0.0;
+  store_rho_pres<false>(P, prim_out, c.k, c2, c.e, rho_new, th, rho_theta, !P.grav_balance);
 }
 
 // Flux divergence + gravity (Dycore.h:553-584), SSPRK3 combine of this stage (Dycore.h:162-221), clipping, next
@@ -1162,28 +1201,112 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   store_adv(P, prim_out, P_THETA, k, c2, th, th);
 }
 
-// x flux of NF tracers (advected-field indices fa[0..NF): 4 = tracer 0, 5 = tracer 1, ...) at the faces c0..c0+span-1 of one periodic x line,
-// upwinded by the face mass flux the fused state pass left in flux_x field 0 (Dycore.h:367-385).  One polynomial per cell.
-template <int NF>
-PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, double *__restrict__ fx, int line, int e,
-                           int c0, int span, const int *fa) {
-  static_assert(FLUX_NF == 2, "tracers are swept in pairs");
+// FCT multiplier of one tracer in one cell, formed inside an x-sweep with all six face fluxes of the cell at hand (Dycore.h:525-540):
+// final for THIS cell.  Row flag set where it is not 1.
+//   DENSE   false (tracer 0, state pass): stored only in rows with a limited member, and the line flag and the "any" word are set
+//           (the fix-up pass reads multipliers through the flags);  true (further tracers, phase 1): always stored -- phase 2 reads
+//           it without looking at flags
+//   ix: offset of the cell inside an interior-sized field (wave-uniform)
+template <bool DENSE>
+PAMA_D void own_multiplier_cell(const Params &P, int t, double *__restrict__ mult, const FctRows &rows, int k, int j, int i, int e,
+                                unsigned eu, long long ix, double F_lo, double F_hi, double yl, double yh, double zl, double zh,
+                                double seed_v, double dzk, double rdzk, double dt_stage) {
+  const bool pos = ((P.pos_mask >> t) & 1ull) != 0;
+  const double m_t = pos ? fct_multiplier(P, seed_v, F_lo, F_hi, yl, yh, zl, zh, dzk, rdzk, dt_stage) : 1.0;
+  const bool limited = (m_t != 1.0);
+  double *mt = mult + (long long)t * P.ncell + ix;
+  if (rows.flags) {
+    if (limited) {
+      rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
+      if (!DENSE && rows.lines) rows.lines[(long long)t * fct_lines_per_tracer(P) + fct_line(P, k, j, e)] = rows.seq;
+      if (!DENSE) *rows.any = rows.seq;       // ("some row of tracer 0": the fix-up pass has work)
+    }
+    if (DENSE || wave_any(limited)) uniw(mt)[eu] = m_t;
+  } else {
+    uniw(mt)[eu] = m_t;
+  }
+}
+
+// Tracer 0 of one cell finished inside the state pass of the fused x-sweep (Dycore.h:525-550, :572-584, :162-221): its own
+// multiplier (above), and the cell's update as it is unless the cell or a neighbour is limited -- tracer_fixup_line_body redoes
+// exactly those neighbourhoods afterwards.  (Water vapour: a smooth positive field, the limiter is idle almost everywhere.)
+//   cu: offset of (j, i, member 0) inside a level
+template <int STAGE>
+PAMA_D void finish_tracer_cell(const Params &P, int t, double *prim_out, double *__restrict__ seed, double *__restrict__ mult,
+                               const FctRows &rows, int k, int j, int i, int e, unsigned eu, long long cu, long long ix,
+                               double F_lo, double F_hi, double yl, double yh, double zl, double zh, double seed_v, double q_in,
+                               double q_0, double rho_in, double rho_0, double rrho, double dzk, double rdzk, double dt_dyn,
+                               double dt_stage) {
+  own_multiplier_cell<false>(P, t, mult, rows, k, j, i, e, eu, ix, F_lo, F_hi, yl, yh, zl, zh, seed_v, dzk, rdzk, dt_stage);
+  double v, new_seed;
+  tracer_new_value<STAGE>(P, t, F_lo, F_hi, yl, yh, zl, zh, q_in, q_0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+  uniw(seed + (long long)t * P.ncell + ix)[eu] = new_seed;
+  store_adv_u(P, prim_out, P_TR0 + t, k, cu, eu, v * rrho, v * rrho);
+}
+
+// x sweeps of the further tracers in the fused stage (advected-field indices fa[0..NF): 5 = tracer 1, ...), NF at a time, over the
+// cells c0..c0+span-1 of one periodic x line; upwinded by the face mass flux the state pass left in flux_x field 0 (Dycore.h:367-385).
+// These tracers (cloud, rain, ice ...: blobs with exact zeros around them) are limited in a large part of their cells, stage after
+// stage, so the "finish in the sweep, redo the few limited neighbourhoods" scheme of tracer 0 would redo most cells.  Instead the
+// line is swept TWICE and the x fluxes never reach memory:
+//   PHASE 1   x fluxes -> with the y/z faces and the mass seed of the cell: its FCT multiplier (own_multiplier_cell; Dycore.h:525-540),
+//             stored for EVERY cell (a complete field: no flags to consult in phase 2).  Nothing else is written.
+//   PHASE 2   (a later launch: the multipliers of the neighbouring lines must be complete) the same x fluxes again -- same inputs,
+//             same code, same bits -- and the complete update of every cell: the six faces limited by the multipliers of the cell
+//             and its six neighbours (Dycore.h:541-548, :572-579), divergence, SSPRK3 combine, clipping, next seed (:553-584, :162-221;
+//             the arithmetic of tracer_update_one).  The multipliers along the line slide through registers (one load per cell),
+//             those of the y/z neighbours are loaded (two / four per cell, shared with the neighbouring lines' sweeps through L2).
+// Against "x faces -> FCT kernel -> pointwise update" this trades one more polynomial per tracer and cell (the sweeps are
+// HBM-bound) for ~4 of 14 field passes per tracer and stage, and two launches for none of the flag traffic.  One polynomial
+// per cell and phase.
+//   have_close / ruf_close   the mass flux through the face that closes the span's last cell (face c1; it belongs to the next span, or
+//                            is the periodic face nx == face 0), handed over in a register when this sweep runs inline after the state
+//                            pass of the same wavefront -- another wavefront of the SAME launch may still be writing it to flux_x.  In
+//                            a launch of its own (awfl_xtr_kernel) it is read from flux_x like the others.
+template <int NF, int STAGE, int PHASE>
+PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                           double *__restrict__ prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
+                           const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
+                           const FctRows &rows, int line, int e, int c0, int span, const int *fa, double dt_dyn, double dt_stage,
+                           bool have_close, double ruf_close) {
   const unsigned eu = member_offset(e);
   const WenoConsts wc = weno_consts();
   const int nx = P.nx;
-  const int c1 = (c0 + span < nx) ? c0 + span : nx;      // faces c0 .. c1-1
+  const int c1 = (c0 + span < nx) ? c0 + span : nx;      // cells c0 .. c1-1, faces c0 .. c1
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
   const long long cu0 = (long long)j * P.sy;
   const long long pbase = (long long)(k + HS) * P.sz + cu0, fbase = (long long)k * P.sz + cu0;
+  const long long jp1 = (j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy;
+  const long long jm1 = (j == 0) ? (long long)(P.ny - 1) * P.sy : -P.sy;
+  const long long ke = (long long)k * P.nens + e;
+  const double dzk = P.dz[ke];
+  const double rdzk = fast_rcp(dzk);
+  const bool have_y = !P.sim2d;
+  const bool zlo = (k > 0), zhi = (k < P.nz - 1);
   const double *ruf_line = fx + fbase;
   auto cell_off = [&](int c) -> long long { return pbase + (long long)(c < 0 ? c + nx : (c >= nx ? c - nx : c)) * P.sx; };
-  const double *q[NF];
-  double *fl[NF];
-  double w[NF][5], prevR[NF];
+  const double *q[NF], *q0p[NF], *fyt[NF], *fzt[NF];
+  int tt[NF];
+  double w[NF][5], prevR[NF], F_prev[NF];
 #pragma unroll
   for (int n = 0; n < NF; n++) {
+    tt[n] = fa[n] - 4;                                   // tracer index
     q[n] = prim_in + (long long)(P_U + fa[n]) * P.prim_fs;
-    fl[n] = fx + (long long)(1 + fa[n]) * P.ncell + fbase;
+    q0p[n] = prim0 + (long long)(P_U + fa[n]) * P.prim_fs;
+    fyt[n] = fy + (long long)(1 + fa[n]) * P.ncell;
+    fzt[n] = fz + (long long)(1 + fa[n]) * P.fz_fs;
+    F_prev[n] = 0.0;
+  }
+  const double *pr = prim_in + (long long)P_RHO * P.prim_fs, *r0 = prim0 + (long long)P_RHO * P.prim_fs;
+  const double *rn = prim_out + (long long)P_RHO * P.prim_fs;   // the new density: written by the state pass (an earlier launch)
+  // PHASE 2: multipliers of the line's cells, sliding: before trip c (mA, mB) = cells (c-2, c-1); the trip loads cell c
+  const double *mline[NF];
+  double mA[NF], mB[NF];
+#pragma unroll
+  for (int n = 0; n < NF; n++) {
+    mline[n] = mult + (long long)tt[n] * P.ncell + fbase;
+    mA[n] = mB[n] = 1.0;
+    if (PHASE == 2) mB[n] = uni(mline[n] + (long long)(c0 == 0 ? nx - 1 : c0 - 1) * P.sx)[eu];
   }
 #pragma unroll
   for (int s = 0; s < 5; s++) {                          // cells c0-3..c0+1: the window of cell c0-1
@@ -1203,19 +1326,71 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
     }
   }
 #pragma clang loop unroll(disable)
-  for (int c = c0; c < c1; c++) {                        // window = cells c-2..c+2
+  for (int c = c0; c <= c1; c++) {                       // window = cells c-2..c+2; face c1 closes the last cell
     const long long on = cell_off(c + 3);
     double nq[NF], L[NF], R[NF];
 #pragma unroll
     for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
-    const double ruf = uni(ruf_line + (long long)c * P.sx)[eu];
+    double ruf = uni(ruf_line + (long long)(c == nx ? 0 : c) * P.sx)[eu];
+    if (have_close && c == c1) ruf = ruf_close;
+    // everything the cell this trip completes needs besides its x fluxes; loaded on EVERY trip, also the first one, which
+    // completes no cell (see flux_x_update_body: s_waitcnt counts are a static minimum over all paths)
+    const int cc = c > c0 ? c - 1 : c0;
+    const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
+    double rho_in = 0.0, rho_0 = 0.0, rho_new = 1.0;
+    if (PHASE == 2) {
+      rho_in = uni(pr + o)[eu];
+      rho_0 = (STAGE > 1) ? uni(r0 + o)[eu] : 0.0;
+      rho_new = uni(rn + o)[eu];
+    }
+    double yl[NF], yh[NF], zl[NF], zh[NF], sd[NF], q_0[NF];
+    double m_new[NF], m_jm1[NF], m_jp1[NF], m_km1[NF], m_kp1[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+      yl[n] = have_y ? uni(fyt[n] + ix)[eu] : 0.0;
+      yh[n] = have_y ? uni(fyt[n] + ix + jp1)[eu] : 0.0;
+      zl[n] = uni(fzt[n] + ix)[eu];
+      zh[n] = uni(fzt[n] + ix + P.sz)[eu];
+      sd[n] = (PHASE == 1) ? uni(seed + (long long)tt[n] * P.ncell + ix)[eu] : 0.0;
+      q_0[n] = (PHASE == 2 && STAGE > 1) ? uni(q0p[n] + o)[eu] : 0.0;
+      m_jm1[n] = m_jp1[n] = m_km1[n] = m_kp1[n] = m_new[n] = 1.0;
+      if (PHASE == 2) {
+        m_new[n] = uni(mline[n] + (long long)(c == nx ? 0 : c) * P.sx)[eu];                       // cell c: the x neighbour of cell cc
+        if (have_y) { m_jm1[n] = uni(mline[n] + (long long)cc * P.sx + jm1)[eu]; m_jp1[n] = uni(mline[n] + (long long)cc * P.sx + jp1)[eu]; }
+        if (zlo) m_km1[n] = uni(mline[n] + (long long)cc * P.sx - P.sz)[eu];
+        if (zhi) m_kp1[n] = uni(mline[n] + (long long)cc * P.sx + P.sz)[eu];
+      }
+    }
 #pragma unroll
     for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
     const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
+    const double rrho = (PHASE == 2) ? fast_rcp(rho_new) : 0.0;
 #pragma unroll
     for (int n = 0; n < NF; n++) {
-      uniw(fl[n] + (long long)c * P.sx)[eu] = mul_rn(ruf, up ? prevR[n] : L[n]);
+      const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
+      if (c > c0) {                                         // cell cc = c-1 is complete; window element 1 is its stage-input value
+        if (PHASE == 1) {
+          own_multiplier_cell<true>(P, tt[n], mult, rows, k, j, cc, e, eu, ix, F_prev[n], F, yl[n], yh[n], zl[n], zh[n], sd[n], dzk, rdzk, dt_stage);
+        } else {                                            // multipliers of cells cc-1, cc, cc+1: mA, mB, m_new
+          const double f_x = limited_flux(F_prev[n], mA[n], mB[n], cc == 0);
+          const double f_xp1 = limited_flux(F, mB[n], m_new[n], cc == nx - 1);
+          double f_y = 0.0, f_yp1 = 0.0;
+          if (have_y) {
+            f_y = limited_flux(yl[n], m_jm1[n], mB[n], j == 0);
+            f_yp1 = limited_flux(yh[n], mB[n], m_jp1[n], j == P.ny - 1);
+          }
+          const double f_z = limited_flux(zl[n], m_km1[n], mB[n], false);
+          const double f_zp1 = limited_flux(zh[n], mB[n], m_kp1[n], false);
+          double v, new_seed;
+          tracer_new_value<STAGE>(P, tt[n], f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, w[n][1], q_0[n], rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+          uniw(seed + (long long)tt[n] * P.ncell + ix)[eu] = new_seed;
+          store_adv_u(P, prim_out, P_TR0 + tt[n], k, cu0 + (long long)cc * P.sx, eu, v * rrho, v * rrho);
+        }
+      }
+      F_prev[n] = F;
       prevR[n] = R[n];
+      mA[n] = mB[n];
+      mB[n] = m_new[n];
 #pragma unroll
       for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
       w[n][4] = nq[n];
@@ -1271,9 +1446,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
   const double rdzk = fast_rcp(dzk);
   const double gcoef = gravity_coef(P, ke);
   const bool have_y = !P.sim2d;
-  const bool pos0 = (P.pos_mask & 1ull) != 0;                          // tracer 0 is positive-definite: FCT applies
-  const long long frow0 = fct_row(P, k, j, 0, e);                      // FCT flag row of (cell i=0, this lane's member block)
-  const long long frow_sx = (P.nens + 63) >> 6;                        // ... and its stride along x
+  double ruf_close = 0.0;                                              // mass flux through the face that closes the span (face c1)
   double *ruf_line = fx + fbase;                                       // flux_x field 0 of this line: the mass flux
   // periodic wrap of c in [-3, nx+2] without a division (nx >= 3): stays on the scalar unit
   auto cell_off = [&](int c) -> long long { return pbase + (long long)(c < 0 ? c + nx : (c >= nx ? c - nx : c)) * P.sx; };
@@ -1313,7 +1486,10 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       weno5_const(wp, wc, L, prevR_p);
       weno5_const(wt, wc, L, prevR_t);
 #pragma unroll
-      for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, L, prevR_q[n]);
+      for (int n = 0; n < NQ; n++) {
+        if (n == 1 && !have_y) { prevR_q[n] = 0.0; continue; }
+        weno5_const(wq[n], wc, L, prevR_q[n]);
+      }
       double nm, np_, nq[NQ];
       load_cell(cell_off(c0 + 2), nm, np_, nq);
       const double nt0 = uni(pt + cell_off(c0 + 2))[eu];
@@ -1349,7 +1525,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int l = 1; l <= NQ; l++) {
         ci.dy[l] = have_y ? uni(fy + (long long)l * P.ncell + ix)[eu] : 0.0;
-        ci.dz[l] = uni(fz + (long long)l * P.fz_fs + ix)[eu];
+        ci.dz[l] = (l == 2 && !have_y) ? 0.0 : uni(fz + (long long)l * P.fz_fs + ix)[eu];   // 2-D: no v tendency, nothing stored
       }
       ci.tyl = have_y ? uni(fyt + ix)[eu] : 0.0;
       ci.tyh = have_y ? uni(fyt + ix + jp1)[eu] : 0.0;
@@ -1381,28 +1557,10 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         // (a pow per cell, kept out of this register-critical loop)
         if (l == 4) uniw(out_rt + o)[eu] = v;
       }
-      // Tracer 0 (Dycore.h:525-550, :572-584, :162-221).  All six face fluxes of the cell are at hand: the FCT multiplier of
-      // THIS cell is final (stored, with its row flag, only where it is not 1), and so is the cell's update unless the cell
-      // or a neighbour is limited -- tracer_update_part redoes exactly those neighbourhoods (flagged rows) afterwards.
-      {
-        const long long ix = fbase + (long long)cc * P.sx;
-        const double m_t = pos0 ? fct_multiplier(P, ci.tseed, Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, dzk, dt_stage) : 1.0;
-        const bool limited = (m_t != 1.0);
-        if (rows.flags) {
-          if (limited) {
-            rows.flags[frow0 + (long long)cc * frow_sx] = rows.seq;
-            *rows.any = rows.seq;
-          }
-          if (wave_any(limited)) uniw(mult + ix)[eu] = m_t;
-        } else {
-          uniw(mult + ix)[eu] = m_t;
-        }
-        double v, new_seed;
-        tracer_new_value<STAGE>(P, 0, Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, qt_in, ci.tq0, ci.rho_in, ci.rho_0, rdzk,
-                                dt_dyn, v, new_seed);
-        uniw(seed + ix)[eu] = new_seed;
-        store_adv_u(P, prim_out, P_TR0, k, cu0 + (long long)cc * P.sx, eu, v * rrho, v * rrho);
-      }
+      // Tracer 0 (Dycore.h:525-550, :572-584, :162-221): finished here like the further tracers in x_tracer_sweep
+      finish_tracer_cell<STAGE>(P, 0, prim_out, seed, mult, rows, k, j, cc, e, eu, cu0 + (long long)cc * P.sx, fbase + (long long)cc * P.sx,
+                                Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, ci.tseed, qt_in, ci.tq0, ci.rho_in, ci.rho_0, rrho, dzk,
+                                rdzk, dt_dyn, dt_stage);
     };
     // Faces c0 .. c1: the last one closes the last cell.  It belongs to the next span (or is the periodic face nx == face 0)
     // and is computed here a second time, with the same bits -- one polynomial set per span instead of a dependency.
@@ -1422,7 +1580,10 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       weno5_const(wm, wc, Lm, Rm);
       weno5_const(wp, wc, Lp, Rp);
 #pragma unroll
-      for (int n = 0; n < NQ; n++) weno5_const(wq[n], wc, Lq[n], Rq[n]);
+      for (int n = 0; n < NQ; n++) {
+        if (n == 1 && !have_y) { Lq[n] = Rq[n] = 0.0; continue; }   // 2-D: the v flux is never used (skip_advected_v)
+        weno5_const(wq[n], wc, Lq[n], Rq[n]);
+      }
       double Lt, Rt;
       weno5_const(wt, wc, Lt, Rt);
       double ruf, ppf, F[1 + NQ];
@@ -1433,6 +1594,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
         uniw(flt + (long long)c * P.sx)[eu] = Ft;            // (read again where the limiter acts: tracer_update_part)
       }
+      ruf_close = ruf;                                       // (after the last trip: face c1)
       F[0] = ruf;
       F[1] = fma(ruf, up ? prevR_q[0] : Lq[0], ppf);
 #pragma unroll
@@ -1462,8 +1624,8 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     const int nadv = 4 + P.nt;
     for (int a = 5; a < nadv; a += FLUX_NF) {              // tracer 0 went with the state pass
       const int fa[2] = {a, a + 1};
-      if (a + 1 < nadv) x_tracer_sweep<2>(P, prim_in, fx, line, e, c0, span, fa);
-      else x_tracer_sweep<1>(P, prim_in, fx, line, e, c0, span, fa);
+      if (a + 1 < nadv) x_tracer_sweep<2, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
+      else x_tracer_sweep<1, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
     }
   }
 }

@@ -6,10 +6,15 @@
 //
 // Launch structure of one SSPRK3 sub-step (reference: 3 x Dycore::compute_tendencies + 3 combines, Dycore.h:147-222;
 // ~18 launches and ~13 allocations there):
-//     per stage:  awfl_flux_kernel   (x, y and z sweeps in ONE launch; Dycore.h:334-519)
-//                 awfl_fct_kernel    (FCT multiplier; Dycore.h:525-550)
-//                 awfl_update_kernel (divergence+gravity+RK combine+next stage's pressure/divide/ghosts;
-//                                     Dycore.h:553-584,162-221,310-321,662-710)
+//     fused stage (default), per stage:
+//                 awfl_flux_kernel<.,DIFF>  y and z sweeps in ONE launch (Dycore.h:387-519)
+//                 awfl_xupd_kernel          x sweep + update of the state and of EVERY tracer (own FCT multiplier + the update an
+//                                           unlimited neighbourhood gets; Dycore.h:334-386,525-584,162-221, next stage's :310-321 divide,
+//                                           :662-710 ghosts) [+ awfl_xtr_kernel: the further tracers' sweeps for small ensembles]
+//                 awfl_ptail_kernel         next stage's pressure + density/pressure ghosts (Dycore.h:310-321,:682-709)
+//                 awfl_trfix_kernel         tracers redone where the limiter acted (driven by line flags; leaves at once elsewhere)
+//     three-kernel stage (cross-check, every face flux and multiplier stored):
+//                 awfl_flux_kernel (x, y, z) -> awfl_fct_kernel (Dycore.h:525-550) -> awfl_update_kernel
 // All scratch is allocated once in init.
 #include <hip/hip_runtime.h>
 
@@ -145,10 +150,16 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
     flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span,
                               dt_dyn, dt_stage, tracers_inline != 0);
 }
-// x fluxes of tracers 1.. for small ensembles: wave unit u -> (x line, member block, span, pair of tracers); after
-// awfl_xupd_kernel.
+// x sweeps of tracers 1.. (x_tracer_sweep): wave unit u -> (x line, member block, span, pair of tracers).  PHASE 1 (the cells' FCT
+// multipliers; only for small ensembles -- otherwise it runs inline in awfl_xupd_kernel) and PHASE 2 (the cells' complete update)
+// both follow awfl_xupd_kernel (they need the face mass flux; phase 2 also the new density and every line's multipliers).
+template <int STAGE, int PHASE>
 __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                               double *__restrict__ fx, int npairs, int span, int nspan) {
+                                                               const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                               const double *__restrict__ fx, const double *__restrict__ fy,
+                                                               const double *__restrict__ fz, double *__restrict__ seed,
+                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                               double dt_stage, int npairs, int span, int nspan) {
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int g2 = uni_int(u / npairs), pair = u - g2 * npairs;
@@ -157,38 +168,29 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
   if (line < P.nz * P.ny && el < R.ne) {
     const int a = 5 + 2 * pair;                 // advected-field index of the pair's first tracer (tracer 0 rides with the state)
     const int fa[2] = {a, a + 1};
-    if (a + 1 < 4 + P.nt) x_tracer_sweep<2>(P, prim_in, fx, line, R.e0 + el, sp * span, span, fa);
-    else x_tracer_sweep<1>(P, prim_in, fx, line, R.e0 + el, sp * span, span, fa);
+    if (a + 1 < 4 + P.nt)
+      x_tracer_sweep<2, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+    else
+      x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
-// Tracer-only update after the fused x-sweep and the FCT multiplier (tracer_update_body).
-template <int STAGE>
-__global__ void __launch_bounds__(256) awfl_trupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                         const double *__restrict__ prim0, double *prim_out,
-                                                         const double *__restrict__ fx, const double *__restrict__ fy,
-                                                         const double *__restrict__ fz, const double *__restrict__ mult,
-                                                         FctRows rows, double *__restrict__ seed, double dt_dyn) {
-  CellId c;   // after the fused x-sweep: tracer 0 is redone only where the limiter acted
-  if (grid_cell(P, R, c)) tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, true);
-}
-// One tracer (water vapour only): the tail as two launches.  (1) next stage's pressure + density/pressure ghosts: a pow per cell
-// and nothing else, so few registers and full occupancy (the general kernel above runs at 4 waves/SIMD and is pure latency);
-constexpr int TRFIX_LEVELS = 6;   // levels per thread in the two NT=1 tail kernels: a quarter of the wavefronts, index arithmetic once
-template <int STAGE>
+// Pointwise tail of the fused stage, (1): next stage's pressure + density/pressure ghosts: a pow per cell and nothing else, so few
+// registers and full occupancy; TAIL_LEVELS levels per thread (a sixth of the wavefronts, the (i, member) split once).
+constexpr int TAIL_LEVELS = 6;
 __global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *__restrict__ prim_out) {
   CellId c;
   if (!grid_cell(P, R, c)) return;
 #pragma unroll
-  for (int kk = 0; kk < TRFIX_LEVELS; kk++) {
-    c.k = (int)blockIdx.z * TRFIX_LEVELS + kk;
+  for (int kk = 0; kk < TAIL_LEVELS; kk++) {
+    c.k = (int)blockIdx.z * TAIL_LEVELS + kk;
     if (c.k >= P.nz) return;
     c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
-    tracer_update_body<STAGE>(P, nullptr, nullptr, prim_out, nullptr, nullptr, nullptr, nullptr, FctRows{nullptr, nullptr, 0, 0},
-                              nullptr, 0.0, c, true, false, true);
+    pressure_tail_body(P, prim_out, c);
   }
 }
-// (2) the tracer's fix-up where the limiter acted: every wavefront leaves after ONE scalar load unless some row was flagged in
-// this stage.
+// (2) the fix-up of tracer 0 where the limiter acted (tracer_fixup_line_body): wave unit u -> (x line, member block).  Every
+// wavefront leaves after ONE scalar load unless some row (of any tracer) was flagged in this stage, and after its five line flags
+// unless a row of its own or of a neighbouring line was.
 template <int STAGE>
 __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
                                                          const double *__restrict__ prim0, double *prim_out,
@@ -196,15 +198,12 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
   if (*rows.any != rows.seq) return;
-  // TRFIX_LEVELS levels per thread: a quarter of the wavefronts to launch (and to retire at once in the common case)
-  CellId c;
-  if (!grid_cell(P, R, c)) return;
-  for (int kk = 0; kk < TRFIX_LEVELS; kk++) {
-    c.k = (int)blockIdx.z * TRFIX_LEVELS + kk;
-    if (c.k >= P.nz) return;
-    c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
-    tracer_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, true, true, false);
-  }
+  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nblk = (R.ne + 63) >> 6;
+  const int line = uni_int(u / nblk), el = (u - line * nblk) * 64 + (int)(threadIdx.x & 63);
+  if (line >= P.nz * P.ny || el >= R.ne) return;
+  const int k = uni_int(line / P.ny), j = line - k * P.ny;
+  tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, 0, k, j, R.e0 + el);
 }
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
@@ -347,7 +346,7 @@ struct pam_amd_awfl {
   size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
   int *fct_flags = nullptr;     // row flags of the FCT multiplier (FctRows in awfl_device.h)
-  size_t n_fct_flags = 0;
+  size_t n_fct_flags = 0, n_fct_lines = 0;
   int fct_seq = 0;              // launch number of the current stage's FCT kernel: the value a flag must hold to count
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
@@ -481,7 +480,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // Small ensembles: a wavefront that sweeps its span for pass 1 and then for every pair of advected fields, one after the
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
-  const int npairs = (3 + P.nt + 1) / 2;       // advected fields besides the normal velocity: 3 + NT, two per sweep
+  const int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
   const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < 8192;
   const int nphase = two_phase ? 2 : 1;
   if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
@@ -519,7 +518,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
 int next_fct_stage(pam_amd_awfl *h) {
   if (h->fct_seq == 0x7fffffff) {   // wrap (once per 2^31 stages): drain everything, forget every flag
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1) * sizeof(int)));
+    HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));
     h->fct_seq = 0;
   }
   h->fct_seq++;
@@ -531,17 +530,17 @@ FctRows fct_rows(const pam_amd_awfl *h, EnsRange r, bool sparse_store) {
   FctRows rows;
   rows.flags = h->fct_flags;
   rows.any = h->fct_flags + h->n_fct_flags;   // one int behind the rows
+  rows.lines = h->fct_flags + h->n_fct_flags + 1;   // ... and the line flags behind that
   rows.seq = h->fct_seq;
   rows.sparse_store = (sparse_store && r.e0 % 64 == 0 && r.ne % 64 == 0) ? 1 : 0;
   return rows;
 }
 
-// t0: first tracer (the fused x-sweep has already produced tracer 0's multiplier: t0 = 1)
-int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s, bool sparse_store = false, int t0 = 0) {
-  if (t0 >= h->P.nt) return PAM_AMD_OK;
+// (three-kernel stage only: in the fused stage every tracer's multiplier comes out of its x-sweep)
+int launch_fct(pam_amd_awfl *h, double dt, EnsRange r, hipStream_t s) {
   ScopedTimer st(h, "fct_mult", s);
   hipLaunchKernelGGL(awfl_fct_kernel, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, h->flux_x, h->flux_y,
-                     h->flux_z, h->seed, h->mult, fct_rows(h, r, sparse_store), dt, t0);
+                     h->flux_z, h->seed, h->mult, fct_rows(h, r, false), dt, 0);
   HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
@@ -571,7 +570,8 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   // are fewer wavefronts than the chip has slots, the tracer sweeps go to their own launch, one wavefront per pair
   const int npairs = (P.nt - 1 + 1) / 2;
   const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < 8192;
-  if (nunits * (split ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
+  if (nunits * (npairs > 0 ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
+  if (r.e0 % 64) return fail(PAM_AMD_EINVAL, "x-sweep launch: member ranges of the fused stage start at multiples of 64 (a wavefront is one row of FCT flags)");
   {
     ScopedTimer st(h, "xupd", s);
     hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
@@ -579,30 +579,46 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
                        dt_stage, split ? 0 : 1, span, nspan);
     HIP_TRY(hipGetLastError());
   }
-  if (split) {
-    ScopedTimer st(h, "xtr", s);
-    hipLaunchKernelGGL(awfl_xtr_kernel, dim3(nblocks(nunits * npairs, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
-                       h->flux_x, npairs, span, nspan);
+  // the tracer launches have npairs wavefronts per (line, member block, span): their lines are cut less (or not at all)
+  int tspan = span, tnspan = nspan;
+  if (npairs > 0) choose_span(P.nx, (long long)P.nz * P.ny * npairs, P.nens, P.seg, h->span_override, tspan, tnspan);
+  const long long tunits = nlb * tnspan * npairs;
+  if (split) {     // phase 1 of the further tracers (their FCT multipliers) in a launch of its own
+    ScopedTimer st(h, "xtr1", s);
+    hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                       prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                       npairs, tspan, tnspan);
+    HIP_TRY(hipGetLastError());
+  }
+  if (npairs > 0) {   // phase 2: their complete update, one wavefront per (line, member block, span, pair)
+    ScopedTimer st(h, "xtr2", s);
+    hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                       prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                       npairs, tspan, tnspan);
     HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;
 }
 
+// the pointwise tail of the fused stage: pressure pass, then the tracers' fix-up pass
 template <int STAGE>
-int launch_trupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
-                 hipStream_t s) {
-  ScopedTimer st(h, "trupd", s);
-  if (h->P.nt == 1) {   // water vapour only: lean pressure pass + fix-up pass (see the kernels)
+int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
+                hipStream_t s) {
+  {
+    ScopedTimer st(h, "ptail", s);
     dim3 g = cell_grid(h->P, r);
-    g.z = (g.z + TRFIX_LEVELS - 1) / TRFIX_LEVELS;
-    hipLaunchKernelGGL(awfl_ptail_kernel<STAGE>, g, dim3(256), 0, s, h->P, r, prim_out);
-    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, g, dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
-                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
-  } else {
-    hipLaunchKernelGGL(awfl_trupd_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
-                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+    g.z = (g.z + TAIL_LEVELS - 1) / TAIL_LEVELS;
+    hipLaunchKernelGGL(awfl_ptail_kernel, g, dim3(256), 0, s, h->P, r, prim_out);
+    HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipGetLastError());
+  {
+    ScopedTimer st(h, "trfix", s);
+    const long long units = (long long)h->P.nz * h->P.ny * ((r.ne + 63) / 64);   // tracer 0 only (the others are complete)
+    if (units > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "fix-up launch: more than 2^30 wavefronts");
+    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, dim3(nblocks(units, 4)), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+    HIP_TRY(hipGetLastError());
+  }
   return PAM_AMD_OK;
 }
 
@@ -807,8 +823,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->seed, h->n_seed * 8));
   INIT_TRY(hipMalloc(&h->mult, h->n_seed * 8));
   h->n_fct_flags = (size_t)P.nt * (size_t)P.nz * P.ny * P.nx * (size_t)((P.nens + 63) / 64);   // FctRows: (nt, nz, ny, nx, blocks of 64 members)
-  INIT_TRY(hipMalloc(&h->fct_flags, (h->n_fct_flags + 1) * sizeof(int)));   // + the "any row flagged in this stage" word
-  INIT_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1) * sizeof(int)));
+  h->n_fct_lines = (size_t)P.nt * (size_t)P.nz * P.ny * (size_t)((P.nens + 63) / 64);          // (nt, nz, ny, blocks): line flags
+  INIT_TRY(hipMalloc(&h->fct_flags, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));   // rows, the "any row flagged in this stage" word, lines
+  INIT_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));
   h->fct_seq = 0;
   INIT_TRY(hipMalloc(&h->dz, nzn * 8));
   INIT_TRY(hipMalloc(&h->grav_var, nzn * 8));
@@ -1009,13 +1026,13 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     //    (A1 -> B1 -> C1 -> A2 ...): two VALU-bound flux kernels never share the chip;
     //  * a chunk's HBM-bound FCT/update kernels run on its normal-priority stream beside the NEXT chunk's flux kernel.
     hipEvent_t prev_flux = nullptr;
-    // One tendency stage of one chunk.  Unfused: flux (x,y,z) -> FCT -> update.  Fused: flux (y,z) -> x-sweep + state update
-    // -> FCT -> tracer update + pressure (pout differs from pin and p0).
+    // One tendency stage of one chunk.  Unfused: flux (x,y,z) -> FCT -> update.  Fused: flux (y,z) -> x-sweeps + update of the
+    // state and of every tracer -> pressure pass + tracer fix-up pass (pout differs from pin and p0).
     auto stage = [&](Chunk &c, int st, const double *pin, const double *p0, double *pout, double dt_stage) -> int {
       int r2;
       if (h->fused) {
         // Fused stage.  The two polynomial kernels (flux y,z and the fused x-sweep) of ALL chunks run back to back on ONE
-        // high-priority compute stream, chunk after chunk; a chunk's HBM-bound tail (FCT multiplier, tracer update + pressure)
+        // high-priority compute stream, chunk after chunk; a chunk's tail (pressure pass, tracer fix-up)
         // runs on the chunk's own stream beside the NEXT chunk's flux kernel.  The x-sweep is both VALU- and HBM-heavy and
         // gets the chip to itself.
         hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
@@ -1029,10 +1046,9 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
           HIP_TRY(hipEventRecord(c.flux_done, cs));
           HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
         }
-        if ((r2 = launch_fct(h, dt_stage, c.r, c.stream, true, 1))) return r2;   // tracer 0: done by the x-sweep
-        if (st == 1) r2 = launch_trupd<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-        else if (st == 2) r2 = launch_trupd<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-        else r2 = launch_trupd<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        if (st == 1) r2 = launch_tail<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        else if (st == 2) r2 = launch_tail<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+        else r2 = launch_tail<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
         if (r2) return r2;
         if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
         return PAM_AMD_OK;
@@ -1263,8 +1279,8 @@ int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
   if ((rc = next_fct_stage(h))) return rc;
   if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
   if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, dt_dyn, r, h->stream))) return rc;
-  if ((rc = launch_fct(h, dt_dyn, r, h->stream, h->fused, h->fused ? 1 : 0))) return rc;
-  if (h->fused) rc = launch_trupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
+  if (!h->fused && (rc = launch_fct(h, dt_dyn, r, h->stream))) return rc;
+  if (h->fused) rc = launch_tail<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   else rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   if (rc) return rc;
   std::swap(h->prim0, h->prim1);

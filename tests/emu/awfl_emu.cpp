@@ -21,14 +21,17 @@ struct Emu {
   std::vector<double> prim0, prim1, prim2, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
   VerticalTables vt;
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
+  int xtr_split = 0;   // fused stage: tracers 1.. swept in a launch of their own (awfl_xtr_kernel) instead of inline
   int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
   std::vector<int> fct_flags;   // row flags of the FCT multiplier (FctRows)
   int fct_seq = 0;
 };
 
-static FctRows fct_rows(Emu *h) {
+static FctRows fct_rows(Emu *h) {   // layout as on the device: rows, the "any" word, line flags
   FctRows r;
-  r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + (h->fct_flags.size() - 1); r.seq = h->fct_seq; r.sparse_store = 0;
+  const size_t nrows = (size_t)h->P.nt * fct_rows_per_tracer(h->P);
+  r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + nrows; r.lines = h->fct_flags.data() + nrows + 1;
+  r.seq = h->fct_seq; r.sparse_store = 0;
   return r;
 }
 
@@ -64,18 +67,18 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
   }
 }
 
-// `sparse`: what the device does in the fused stage when a wavefront is a whole row -- the multipliers of a row no member of
-// which was limited are not stored.  Emulated by poisoning them: an update that loads one of them anyway produces NaN.
-// the stage's flag value is drawn by the caller BEFORE the stage (h->fct_seq++), as next_fct_stage() does on the device: in
-// the fused stage the x-sweep already flags tracer 0, and this pass starts at tracer 1.
-static void fct_launch(Emu *h, double dt, bool sparse) {
+// the stage's flag value is drawn by the caller BEFORE the stage (h->fct_seq++), as next_fct_stage() does on the device
+static void fct_launch(Emu *h, double dt) {
   const Params &P = h->P;
   for (long long idx = 0; idx < P.ncell; idx++)
-    fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx),
-                  sparse ? 1 : 0);
-  if (!sparse) return;
+    fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx), 0);
+}
+// What the device does in the fused stage: tracer 0's multipliers of a row no member of which was limited are not stored by the
+// state pass.  Emulated by poisoning them after the sweeps: a fix-up that loads one of them anyway produces NaN.
+static void poison_unflagged_mult(Emu *h) {
+  const Params &P = h->P;
   const long long nrows = fct_rows_per_tracer(P);
-  for (int t = 0; t < P.nt; t++)
+  for (int t = 0; t < 1; t++)     // tracer 0 only: the further tracers' multipliers are a complete field (own_multiplier_cell<true>)
     for (long long idx = 0; idx < P.ncell; idx++) {
       const CellId c = cell_of(P, idx);
       if (h->fct_flags[(size_t)t * nrows + fct_row(P, c.k, c.j, c.i, c.e)] != h->fct_seq) h->mult[(size_t)t * P.ncell + idx] = NAN;
@@ -98,16 +101,43 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
     for (int sp = 0; sp < nspan; sp++)
       for (int e = 0; e < P.nens; e++)
         flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(),
-                                  fct_rows(h), line, e, sp * span, span, dt, dt_stage, true);
+                                  fct_rows(h), line, e, sp * span, span, dt, dt_stage, h->xtr_split == 0);
+  // awfl_xtr_kernel: phase 1 of the further tracers in a launch of its own (one wavefront per (span, pair)) unless it ran inline;
+  // then -- always a launch of its own -- phase 2 (the multipliers of unflagged rows are poisoned in between: the device does not
+  // store them)
+  const int npairs = (P.nt - 1 + 1) / 2;
+  for (int phase = h->xtr_split ? 1 : 2; phase <= 2; phase++) {
+    if (phase == 2) poison_unflagged_mult(h);
+    for (int line = 0; line < P.nz * P.ny; line++)
+      for (int sp = 0; sp < nspan; sp++)
+        for (int pair = 0; pair < npairs; pair++)
+          for (int e = 0; e < P.nens; e++) {
+            const int a = 5 + 2 * pair;
+            const int fa[2] = {a, a + 1};
+            double *fxp = h->fx.data(), *fyp = h->fy.data(), *fzp = h->fz.data(), *sdp = h->seed.data(), *mtp = h->mult.data();
+            if (a + 1 < 4 + P.nt) {
+              if (phase == 1) x_tracer_sweep<2, STAGE, 1>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
+              else x_tracer_sweep<2, STAGE, 2>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
+            } else {
+              if (phase == 1) x_tracer_sweep<1, STAGE, 1>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
+              else x_tracer_sweep<1, STAGE, 2>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
+            }
+          }
+  }
+  if (npairs == 0) poison_unflagged_mult(h);
 }
+// the pointwise tail of the fused stage as the device launches it: pressure pass (awfl_ptail_kernel), then the tracers' fix-up
+// pass, one wavefront per (tracer, x line, member block) (awfl_trfix_kernel)
 template <int STAGE>
-static void trupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
-  // one tracer: two passes, as the device launches them (awfl_ptail_kernel, awfl_trfix_kernel)
-  const bool two = (h->P.nt == 1);
-  for (int pass = 0; pass < (two ? 2 : 1); pass++)
-    for (long long idx = 0; idx < h->P.ncell; idx++)
-      tracer_update_body<STAGE>(h->P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fct_rows(h), h->seed.data(), dt,
-                                cell_of(h->P, idx), true, two ? pass == 1 : true, two ? pass == 0 : true);
+static void tail_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
+  const Params &P = h->P;
+  for (long long idx = 0; idx < P.ncell; idx++) pressure_tail_body(P, out, cell_of(P, idx));
+  const FctRows rows = fct_rows(h);
+  if (*rows.any != rows.seq) return;
+  for (int k = 0; k < P.nz; k++)       // tracer 0 only: the others were completed by phase 2 of their sweeps
+    for (int j = 0; j < P.ny; j++)
+      for (int e = 0; e < P.nens; e++)
+        tracer_fixup_line_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), rows, h->seed.data(), dt, 0, k, j, e);
 }
 
 static TracerPtrs tptrs(const Emu *h, double *tracers) {
@@ -147,7 +177,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
   h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
   h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
-  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P) + 1, 0);   // + the "any row flagged" word
+  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P) + 1 + (size_t)nt * fct_lines_per_tracer(P), 0);   // rows + "any" word + lines
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();
@@ -159,6 +189,7 @@ void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
 void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
 void emu_set_span(Emu *h, int span) { h->span = span; }
 void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
+void emu_set_xtr_split(Emu *h, int split) { h->xtr_split = split; }
 int emu_vz_per_ens(Emu *h) { return h->P.vz_per_ens; }
 double *emu_buffer(Emu *h, const char *name) {
   std::string k(name);
@@ -208,7 +239,7 @@ void emu_convert_coupler_to_dynamics(Emu *h, double *rho_d, double *u, double *v
 void emu_flux_stage(Emu *h, double dt) {
   h->fct_seq++;
   flux_launch(h, h->prim0.data());
-  fct_launch(h, dt, false);
+  fct_launch(h, dt);
 }
 
 int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers, double crm_dt,
@@ -224,18 +255,18 @@ int emu_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double
     // poison the x fluxes of the state: the fused stage must not read them
     for (int ic = 0; ic < ncycles; ic++) {
       std::fill(h->fx.begin(), h->fx.begin() + 5 * h->P.ncell, NAN);   // (field 0 is re-used as the x-sweep's own scratch)
-      h->fct_seq++; flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt, dt); fct_launch(h, dt, true); trupd_launch<1>(h, A, A, B, dt);
-      h->fct_seq++; flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt, (1.0 / 4.0) * dt); fct_launch(h, (1.0 / 4.0) * dt, true); trupd_launch<2>(h, B, A, C, dt);
-      h->fct_seq++; flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt, (2.0 / 3.0) * dt); fct_launch(h, (2.0 / 3.0) * dt, true); trupd_launch<3>(h, C, A, B, dt);
+      h->fct_seq++; flux_launch(h, A, 6, true); xupd_launch<1>(h, A, A, B, dt, dt); tail_launch<1>(h, A, A, B, dt);
+      h->fct_seq++; flux_launch(h, B, 6, true); xupd_launch<2>(h, B, A, C, dt, (1.0 / 4.0) * dt); tail_launch<2>(h, B, A, C, dt);
+      h->fct_seq++; flux_launch(h, C, 6, true); xupd_launch<3>(h, C, A, B, dt, (2.0 / 3.0) * dt); tail_launch<3>(h, C, A, B, dt);
       std::swap(A, B);
     }
     if (A != h->prim0.data()) h->prim0.swap(h->prim1);   // an odd number of sub-steps: the state sits in prim1
     p0 = h->prim0.data();
   } else {
     for (int ic = 0; ic < ncycles; ic++) {
-      h->fct_seq++; flux_launch(h, p0); fct_launch(h, dt, false); update_launch<1>(h, p0, p0, p1, dt);
-      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt, false); update_launch<2>(h, p1, p0, p1, dt);
-      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt, false); update_launch<3>(h, p1, p0, p0, dt);
+      h->fct_seq++; flux_launch(h, p0); fct_launch(h, dt); update_launch<1>(h, p0, p0, p1, dt);
+      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (1.0 / 4.0) * dt); update_launch<2>(h, p1, p0, p1, dt);
+      h->fct_seq++; flux_launch(h, p1); fct_launch(h, (2.0 / 3.0) * dt); update_launch<3>(h, p1, p0, p0, dt);
     }
   }
   TracerPtrs tp = tptrs(h, tracers);

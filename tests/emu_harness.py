@@ -32,6 +32,7 @@ def load():
         lib.emu_set_seg.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_span.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_fused.argtypes = [C.c_void_p, C.c_int]
+        lib.emu_set_xtr_split.argtypes = [C.c_void_p, C.c_int]
         lib.emu_vz_per_ens.argtypes = [C.c_void_p]
         lib.emu_buffer.restype = _DP
         lib.emu_buffer.argtypes = [C.c_void_p, C.c_char_p]
@@ -83,6 +84,9 @@ class EmuDycore:
 
     def set_fused(self, on):
         self.lib.emu_set_fused(self.h, int(bool(on)))
+
+    def set_xtr_split(self, on):
+        self.lib.emu_set_xtr_split(self.h, int(bool(on)))
 
     @property
     def vz_per_ens(self):

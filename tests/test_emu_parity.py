@@ -82,9 +82,10 @@ def test_emulated_kernels_match_oracle(case, fused):
         assert np.nansum(m < 1.0) > 0 and (f1["tracers"] == 0.0).any()
 
 
-@pytest.mark.parametrize("span", [0, 3], ids=["whole_lines", "spans_of_3"])
+@pytest.mark.parametrize("span,split", [(0, False), (3, False), (0, True), (3, True)],
+                         ids=["whole_lines", "spans_of_3", "whole_lines_xtr_launch", "spans_of_3_xtr_launch"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span):
+def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span, split):
     """flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update + pressure must reproduce flux(x,y,z) -> FCT ->
     update exactly: same helpers, same rounding points (awfl_device.h: acoustic_face, flux_divergence, rk_combine...).
     Odd and even numbers of sub-steps exercise both parities of the three-buffer rotation."""
@@ -105,6 +106,7 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span):
         g.set_fused(fused)
         if fused:
             g.set_span(span)      # the fused x-sweep cut into spans (each recomputes its closing face) vs whole-line three-kernel stage
+            g.set_xtr_split(split)  # tracers 1.. finished inline after the state pass, or in a launch of their own (awfl_xtr_kernel)
         g.declare_current_profile_as_hydrostatic(ff)
         ncyc = [g.time_step(ff, dt)[0] for dt in (2.0, 0.7, 2.0)]
         out.append((ncyc, ff))
