@@ -496,6 +496,11 @@ PAMA_D int wrap(int c, int n) {
 #else
 #define PAMA_HD inline
 #endif
+// The fused stage treats ONE tracer differently from the others: water vapour (index idWV; every microphysics registers it,
+// Dycore.h:83) is a smooth positive field in which the limiter is idle almost everywhere -- it rides with the state pass of the
+// fused x-sweep and is finished there, with a sparse fix-up afterwards.  The others (cloud, rain, ice ...: blobs with exact zeros
+// around them, limited in a large part of their cells) get the two-phase sweeps.  i-th further tracer -> tracer index:
+PAMA_HD int further_tracer(const Params &P, int i) { return i < P.idWV ? i : i + 1; }
 PAMA_HD bool skip_advected_v(const Params &P, bool diff) { return diff && P.sim2d; }
 // advected fields a sweep visits after pass 1 (everything but the normal velocity; see above), in pairs (host: launch geometry)
 PAMA_HD int flux_sweep_pairs(const Params &P, bool diff) { return (3 + P.nt - (skip_advected_v(P, diff) ? 1 : 0) + 1) / 2; }
@@ -934,7 +939,7 @@ PAMA_D double fct_multiplier(const Params &P, double seed_v, double xlo, double 
 }
 
 // FCT multiplier of one cell and tracer (Dycore.h:533-540): 1 when the cell is not limited.
-//   t0   first tracer to do (1 when the fused x-sweep has already done tracer 0)
+//   t0   first tracer to do (test hook)
 PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const double *__restrict__ fy,
                           const double *__restrict__ fz, const double *__restrict__ seed, double *__restrict__ mult,
                           const FctRows &rows, double dt, const CellId &c, int t0 = 0) {
@@ -1093,7 +1098,7 @@ PAMA_D void tracer_update_part(const Params &P, const double *prim_in, const dou
     tracer_update_one<STAGE>(P, t, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0, rrho, rdzk, false);
 }
 
-// Fix-up pass of the fused stage.  Every tracer has been advanced by its x-sweep (tracer 0 in the state pass of
+// Fix-up pass of the fused stage.  Every tracer has been advanced by its x-sweep (water vapour in the state pass of
 // flux_x_update_body, the others in x_tracer_sweep) with the update a cell gets when neither it nor one of its six neighbours is
 // limited, and the sweeps have stored the multipliers of limited cells, their row flags and -- per tracer, x line and member
 // block -- a line flag.  This pass redoes, with the complete arithmetic (tracer_update_one), exactly the neighbourhoods of flagged
@@ -1203,7 +1208,7 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
 
 // FCT multiplier of one tracer in one cell, formed inside an x-sweep with all six face fluxes of the cell at hand (Dycore.h:525-540):
 // final for THIS cell.  Row flag set where it is not 1.
-//   DENSE   false (tracer 0, state pass): stored only in rows with a limited member, and the line flag and the "any" word are set
+//   DENSE   false (water vapour, state pass): stored only in rows with a limited member, and the line flag and the "any" word are set
 //           (the fix-up pass reads multipliers through the flags);  true (further tracers, phase 1): always stored -- phase 2 reads
 //           it without looking at flags
 //   ix: offset of the cell inside an interior-sized field (wave-uniform)
@@ -1219,7 +1224,7 @@ PAMA_D void own_multiplier_cell(const Params &P, int t, double *__restrict__ mul
     if (limited) {
       rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
       if (!DENSE && rows.lines) rows.lines[(long long)t * fct_lines_per_tracer(P) + fct_line(P, k, j, e)] = rows.seq;
-      if (!DENSE) *rows.any = rows.seq;       // ("some row of tracer 0": the fix-up pass has work)
+      if (!DENSE) *rows.any = rows.seq;       // ("some row of water vapour": the fix-up pass has work)
     }
     if (DENSE || wave_any(limited)) uniw(mt)[eu] = m_t;
   } else {
@@ -1247,7 +1252,7 @@ PAMA_D void finish_tracer_cell(const Params &P, int t, double *prim_out, double 
 // x sweeps of the further tracers in the fused stage (advected-field indices fa[0..NF): 5 = tracer 1, ...), NF at a time, over the
 // cells c0..c0+span-1 of one periodic x line; upwinded by the face mass flux the state pass left in flux_x field 0 (Dycore.h:367-385).
 // These tracers (cloud, rain, ice ...: blobs with exact zeros around them) are limited in a large part of their cells, stage after
-// stage, so the "finish in the sweep, redo the few limited neighbourhoods" scheme of tracer 0 would redo most cells.  Instead the
+// stage, so the "finish in the sweep, redo the few limited neighbourhoods" scheme of water vapour would redo most cells.  Instead the
 // line is swept TWICE and the x fluxes never reach memory:
 //   PHASE 1   x fluxes -> with the y/z faces and the mass seed of the cell: its FCT multiplier (own_multiplier_cell; Dycore.h:525-540),
 //             stored for EVERY cell (a complete field: no flags to consult in phase 2).  Nothing else is written.
@@ -1461,9 +1466,10 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
     const double *pp = prim_in + (long long)P_PRES * P.prim_fs;
     const double *r0 = prim0 + (long long)P_RHO * P.prim_fs;
     double *out_rho = prim_out + (long long)P_RHO * P.prim_fs, *out_rt = prim_out + (long long)P_PRES * P.prim_fs;
-    double wm[5], wp[5], wq[NQ][5], wt[5];                 // wt: tracer 0 (there is always one: water_vapor) rides along, flux only
-    const double *pt = prim_in + (long long)P_TR0 * P.prim_fs;
-    double *flt = fx + (long long)5 * P.ncell + fbase;     // x flux of tracer 0
+    double wm[5], wp[5], wq[NQ][5], wt[5];                 // wt: water vapour (tracer idWV) rides along
+    const int tr = P.idWV;                                 // the tracer that rides with the state (water vapour)
+    const double *pt = prim_in + (long long)(P_TR0 + tr) * P.prim_fs;
+    double *flt = fx + (long long)(5 + tr) * P.ncell + fbase;   // its x flux
     const bool more_tracers = P.nt > 1;                    // the tracer sweeps below need the mass flux
     auto load_cell = [&](long long o, double &m, double &p, double (&qv)[NQ]) {
 #pragma unroll
@@ -1503,15 +1509,16 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) wq[n][4] = nq[n];
     }
-    double F_prev[1 + NQ], Ft_prev = 0.0;                  // face fluxes of rho, rho u, rho v, rho w, rho theta; of tracer 0
+    double F_prev[1 + NQ], Ft_prev = 0.0;                  // face fluxes of rho, rho u, rho v, rho w, rho theta; of water vapour
 #pragma unroll
     for (int l = 0; l <= NQ; l++) F_prev[l] = 0.0;
     // everything cell cc needs besides its x fluxes
     // y0*/z0*: the two y / z faces of the mass flux; dy, dz: flux differences of the other variables (DIFF sweeps)
-    //   t*: tracer 0 -- its y/z face fluxes, FCT mass seed and sub-step-start mixing ratio
+    //   t*: water vapour -- its y/z face fluxes, FCT mass seed and sub-step-start mixing ratio
     struct CellIn { double rho_in, rho_0, q0[NQ], y0l, y0h, z0l, z0h, dy[1 + NQ], dz[1 + NQ], tyl, tyh, tzl, tzh, tseed, tq0; };
-    const double *fyt = fy + (long long)5 * P.ncell, *fzt = fz + (long long)5 * P.fz_fs;
-    const double *pt0 = prim0 + (long long)P_TR0 * P.prim_fs;
+    const double *fyt = fy + (long long)(5 + tr) * P.ncell, *fzt = fz + (long long)(5 + tr) * P.fz_fs;
+    const double *pt0 = prim0 + (long long)(P_TR0 + tr) * P.prim_fs;
+    const double *sdt = seed + (long long)tr * P.ncell;
     auto load_in = [&](int cc, CellIn &ci) {
       const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
       ci.rho_in = uni(pr + o)[eu];
@@ -1531,7 +1538,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       ci.tyh = have_y ? uni(fyt + ix + jp1)[eu] : 0.0;
       ci.tzl = uni(fzt + ix)[eu];
       ci.tzh = uni(fzt + ix + P.sz)[eu];
-      ci.tseed = uni(seed + ix)[eu];
+      ci.tseed = uni(sdt + ix)[eu];
       ci.tq0 = (STAGE > 1) ? uni(pt0 + o)[eu] : 0.0;
     };
     // finish cell cc: F_lo/F_hi = its two x faces; m_in_u = rho*u of the stage input (the product window), q_in = v, w, theta
@@ -1558,7 +1565,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         if (l == 4) uniw(out_rt + o)[eu] = v;
       }
       // Tracer 0 (Dycore.h:525-550, :572-584, :162-221): finished here like the further tracers in x_tracer_sweep
-      finish_tracer_cell<STAGE>(P, 0, prim_out, seed, mult, rows, k, j, cc, e, eu, cu0 + (long long)cc * P.sx, fbase + (long long)cc * P.sx,
+      finish_tracer_cell<STAGE>(P, tr, prim_out, seed, mult, rows, k, j, cc, e, eu, cu0 + (long long)cc * P.sx, fbase + (long long)cc * P.sx,
                                 Ft_lo, Ft_hi, ci.tyl, ci.tyh, ci.tzl, ci.tzh, ci.tseed, qt_in, ci.tq0, ci.rho_in, ci.rho_0, rrho, dzk,
                                 rdzk, dt_dyn, dt_stage);
     };
@@ -1589,7 +1596,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       double ruf, ppf, F[1 + NQ];
       acoustic_face(prevR_m, Lm, prevR_p, Lp, false, ruf, ppf);
       const bool up = ruf > 0.0;                             // upwind (Dycore.h:368)
-      const double Ft = mul_rn(ruf, up ? prevR_t : Lt);      // x flux of tracer 0 (Dycore.h:367-385)
+      const double Ft = mul_rn(ruf, up ? prevR_t : Lt);      // x flux of water vapour (Dycore.h:367-385)
       if (c < c1) {                                          // the faces this span owns
         if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
         uniw(flt + (long long)c * P.sx)[eu] = Ft;            // (read again where the limiter acts: tracer_update_part)
@@ -1621,10 +1628,9 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
   // ---------------- the other tracers (Dycore.h:367-385): inline here, or -- small ensembles, where a wavefront per line is
   // too little parallelism for a chain this long -- by awfl_xtr_kernel, one wavefront per (line, pair of tracers)
   if (tracers_inline) {
-    const int nadv = 4 + P.nt;
-    for (int a = 5; a < nadv; a += FLUX_NF) {              // tracer 0 went with the state pass
-      const int fa[2] = {a, a + 1};
-      if (a + 1 < nadv) x_tracer_sweep<2, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
+    for (int i = 0; i < P.nt - 1; i += FLUX_NF) {          // water vapour went with the state pass
+      const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
+      if (i + 1 < P.nt - 1) x_tracer_sweep<2, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
       else x_tracer_sweep<1, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
     }
   }

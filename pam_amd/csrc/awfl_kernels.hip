@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
   const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
   const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne) {
-    const int a = 5 + 2 * pair;                 // advected-field index of the pair's first tracer (tracer 0 rides with the state)
-    const int fa[2] = {a, a + 1};
-    if (a + 1 < 4 + P.nt)
+    // advected-field indices of the pair's tracers (water vapour rides with the state pass)
+    const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
+    if (2 * pair + 1 < P.nt - 1)
       x_tracer_sweep<2, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
     else
       x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, d
     pressure_tail_body(P, prim_out, c);
   }
 }
-// (2) the fix-up of tracer 0 where the limiter acted (tracer_fixup_line_body): wave unit u -> (x line, member block).  Every
+// (2) the fix-up of water vapour (the tracer finished in the state pass) where the limiter acted (tracer_fixup_line_body): wave unit u -> (x line, member block).  Every
 // wavefront leaves after ONE scalar load unless some row (of any tracer) was flagged in this stage, and after its five line flags
 // unless a row of its own or of a neighbouring line was.
 template <int STAGE>
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
   const int line = uni_int(u / nblk), el = (u - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line >= P.nz * P.ny || el >= R.ne) return;
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
-  tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, 0, k, j, R.e0 + el);
+  tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, k, j, R.e0 + el);
 }
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
@@ -613,7 +613,7 @@ int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   }
   {
     ScopedTimer st(h, "trfix", s);
-    const long long units = (long long)h->P.nz * h->P.ny * ((r.ne + 63) / 64);   // tracer 0 only (the others are complete)
+    const long long units = (long long)h->P.nz * h->P.ny * ((r.ne + 63) / 64);   // water vapour only (the others are complete)
     if (units > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "fix-up launch: more than 2^30 wavefronts");
     hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, dim3(nblocks(units, 4)), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
                        h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);

@@ -78,7 +78,7 @@ static void fct_launch(Emu *h, double dt) {
 static void poison_unflagged_mult(Emu *h) {
   const Params &P = h->P;
   const long long nrows = fct_rows_per_tracer(P);
-  for (int t = 0; t < 1; t++)     // tracer 0 only: the further tracers' multipliers are a complete field (own_multiplier_cell<true>)
+  for (int t = P.idWV; t <= P.idWV; t++)     // water vapour only: the further tracers' multipliers are a complete field (own_multiplier_cell<true>)
     for (long long idx = 0; idx < P.ncell; idx++) {
       const CellId c = cell_of(P, idx);
       if (h->fct_flags[(size_t)t * nrows + fct_row(P, c.k, c.j, c.i, c.e)] != h->fct_seq) h->mult[(size_t)t * P.ncell + idx] = NAN;
@@ -112,10 +112,9 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
       for (int sp = 0; sp < nspan; sp++)
         for (int pair = 0; pair < npairs; pair++)
           for (int e = 0; e < P.nens; e++) {
-            const int a = 5 + 2 * pair;
-            const int fa[2] = {a, a + 1};
+            const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
             double *fxp = h->fx.data(), *fyp = h->fy.data(), *fzp = h->fz.data(), *sdp = h->seed.data(), *mtp = h->mult.data();
-            if (a + 1 < 4 + P.nt) {
+            if (2 * pair + 1 < P.nt - 1) {
               if (phase == 1) x_tracer_sweep<2, STAGE, 1>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
               else x_tracer_sweep<2, STAGE, 2>(P, in, p0, out, fxp, fyp, fzp, sdp, mtp, fct_rows(h), line, e, sp * span, span, fa, dt, dt_stage, false, 0.0);
             } else {
@@ -137,7 +136,7 @@ static void tail_launch(Emu *h, const double *in, const double *p0, double *out,
   for (int k = 0; k < P.nz; k++)       // tracer 0 only: the others were completed by phase 2 of their sweeps
     for (int j = 0; j < P.ny; j++)
       for (int e = 0; e < P.nens; e++)
-        tracer_fixup_line_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), rows, h->seed.data(), dt, 0, k, j, e);
+        tracer_fixup_line_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), rows, h->seed.data(), dt, P.idWV, k, j, e);
 }
 
 static TracerPtrs tptrs(const Emu *h, double *tracers) {
