@@ -26,12 +26,18 @@ Extra objects on the JSON line:
                 launch / mean launch duration; one launch = one tendency stage over all cells = cells/3 cell-updates x
                 64*(5+NT) B.  Launch durations are measured live with HIP events on the stream the kernels
                 run on (inside libpam_amd_awfl.so: pam_amd_awfl_set_kernel_timing), in a separate un-timed pass.
+                achieved / peak / frac (= hbm_frac) are the HBM view the metric asks for; `bound` names the roofline that
+                actually limits the kernel ("fp64-valu" when its VALU fraction exceeds its HBM fraction) and `valu`
+                quantifies it from the profile's SQ_INSTS_VALU / GRBM_GUI_ACTIVE (issue fraction at the clock the chip
+                held, and fraction of the 2.4 GHz spec with this run's duration).
                 `traffic` = HBM bytes per stage from rocprofv3 PMC passes of this command, valid only for the build they
-                were taken from (content hash of pam_amd/csrc; null when the sources have changed since).
-                `kernels` lists every stage kernel with the bytes it must itself move and its FP64 work.
+                were taken from (content hash of pam_amd/csrc; null when the sources have changed since);
+                `stage_traffic_ratio` = HBM bytes moved by all stage kernels / algorithmic bytes of the stage.
+                `kernel_rooflines` lists every stage kernel with the bytes it must itself move and its FP64 work.
   cpu_baseline  the CPU oracle (a port of the reference algorithm, oracle/awfl_oracle.c, OpenMP over the flux loop)
                 timed on this host on a bounded sample of the same workload (rank 0, N=1 only).
-  other_configs C3 / C4 throughput on this GPU (N=1, default run only), measured the same way with fewer steps.
+  other_configs C3 / C4 throughput on this GPU (N=1, default run only), measured the same way with fewer steps, each with its
+                own `roofline` (+ `traffic` from profiles/r03_c{3,4}_traffic.json) and `kernel_rooflines`.
 """
 import argparse
 import copy
@@ -326,6 +332,94 @@ def stage_rooflines(job, alone):
     return out
 
 
+PROFILE_ROUND = "r03"
+
+
+def load_profile(cfg_name):
+    """per-kernel PMC figures of this config (tools/profile_c2.sh / profile_small.sh -> profiles/<round>_<cfg>_traffic.json), valid only
+    for the build they were taken from: content hash of pam_amd/csrc"""
+    path = os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (PROFILE_ROUND, cfg_name))
+    if not os.path.exists(path):
+        return None, "no PMC profile for this configuration (%s)" % os.path.basename(path)
+    prof = json.load(open(path))
+    if prof.get("csrc_hash") != csrc_hash():
+        return None, "%s was measured on another build of pam_amd/csrc: not reported" % os.path.basename(path)
+    return prof, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE, separate passes, this build (%s)" % prof["csrc_hash"]
+
+
+def measure_roofline(job, args, default_workload=True):
+    """HIP-event pass over the stage kernels of `job` + the roofline object of its dominant kernel (see the module docstring)."""
+    d = job.dycore
+    cells = job.nens * job.nz * job.ny * job.nx
+    nt = job.nt
+    d.set_kernel_timing(True)
+    kernels = job.kernel_pass()                    # shipped configuration (chunks overlap: durations include contention)
+    d.set_ensemble_chunks(1)                       # every stage kernel on its own: whole ensemble per launch
+    alone = job.kernel_pass()
+    d.set_ensemble_chunks(args.chunks if args.chunks >= 0 else 0, args.lds_floor)
+    d.set_kernel_timing(False)
+    kernel_rooflines = stage_rooflines(job, alone)
+    stage = [k for k in STAGE_KERNELS if k in alone]
+    if not stage:
+        return None, kernels, kernel_rooflines
+    nstage = stage_count(alone)
+    dom = max(stage, key=lambda k: alone[k]["total_ms"])
+    avg_s = alone[dom]["total_ms"] / nstage * 1e-3    # per stage (the y and z sweeps may be two launches of one kernel)
+    alg_bytes = cells / 3.0 * 64.0 * (5 + nt)            # SURVEY 8d: 64*(5+NT) B per cell-update, 1/3 per stage
+    achieved = alg_bytes / avg_s / 1e9
+    kname = "awfl_%s_kernel" % dom.replace("fct_mult", "fct")
+    if dom.startswith("xtr"):
+        kname = "awfl_xtr_kernel<%s>" % dom[3:]
+    mine = [k for k in kernel_rooflines if k["kernel"] == kname]
+    prof, tnote = (load_profile(job.cfg_name) if default_workload else (None, "not the profiled workload"))
+    traffic, stage_traffic, valu = None, None, None
+    if prof is not None:
+        pk = prof["kernels"]
+
+        def pkey(name):      # "awfl_xtr_kernel<2>" is one template family in the profile
+            return name if name in pk else name.split("<")[0]
+        if pkey(kname) in pk:
+            traffic = pk[pkey(kname)]["hbm_bytes_per_stage"]
+        for kr in kernel_rooflines:
+            k = kr["kernel"]
+            if k in pk:
+                kr["traffic"] = pk[k]["hbm_bytes_per_stage"]
+        names = set(pkey(kr["kernel"]) for kr in kernel_rooflines)
+        stage_traffic = sum(pk[k]["hbm_bytes_per_stage"] for k in names if k in pk)
+        c = pk.get(pkey(kname), {})
+        if "valu_insts_per_stage" in c and "busy_cycles_per_xcd_per_stage" in c:
+            # counter-based VALU figures of the dominant kernel: a wave-level fp64 VALU instruction occupies its SIMD for 4
+            # cycles; 1024 SIMDs.  issue_frac: of the cycles the chip was busy (at the clock it actually held, ~1.9 GHz under this
+            # FP64 load); frac: of the 2.4 GHz spec, with this run's duration
+            simd_cycles = c["valu_insts_per_stage"] * 4.0 / 1024.0
+            valu = {"bound": "fp64-valu", "unit": "SIMD issue cycles per stage", "achieved": simd_cycles,
+                    "issue_frac_at_sustained_clock": simd_cycles / c["busy_cycles_per_xcd_per_stage"],
+                    "sustained_clock_GHz_approx": c["busy_cycles_per_xcd_per_stage"] / avg_s / 1e9,   # profile's busy cycles / this run's duration
+                    "peak": avg_s * 2.4e9, "frac": simd_cycles / (avg_s * 2.4e9),
+                    "source": "SQ_INSTS_VALU and GRBM_GUI_ACTIVE of the profile, duration of this run"}
+    if valu is None and mine:
+        valu = {"bound": "fp64-valu", "achieved": mine[0]["fp64_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": mine[0]["valu_frac"], "source": "instruction-count model (no counter profile of this build)"}
+    stage_ms = sum(alone[k]["total_ms"] for k in stage) / nstage
+    # which roofline binds the dominant kernel: FP64 vector issue when its VALU fraction exceeds its HBM fraction
+    hbm_frac = achieved / HBM_PEAK_GBS
+    bound = "fp64-valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
+    roofline = {"bound": bound, "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": hbm_frac, "hbm_frac": hbm_frac, "traffic": traffic, "traffic_note": tnote,
+                "ms_per_stage": alone[dom]["total_ms"] / nstage, "launches_per_stage": alone[dom]["launches"] / nstage,
+                "alg_bytes_per_launch": alg_bytes,
+                "note": "achieved/peak/frac are the HBM view asked for by the metric (SURVEY 8d algorithmic bytes of a whole stage / "
+                        "this kernel's time per stage, measured with one ensemble range, nothing co-running); `bound` names the "
+                        "roofline that actually limits the kernel, `valu` quantifies it; all stage kernels back to back take "
+                        "%.2f ms" % stage_ms,
+                "stage_ms_back_to_back": stage_ms,
+                "stage_frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "stage_traffic": stage_traffic,
+                "stage_traffic_ratio": (stage_traffic / alg_bytes) if stage_traffic else None,
+                "valu": valu}
+    return roofline, kernels, kernel_rooflines
+
+
 def worker(args):
     import torch
     import torch.distributed as dist
@@ -340,16 +434,27 @@ def worker(args):
                          "let it start the ranks" % (args.gpus, world))
     if os.environ.get("PAM_AMD_BENCH_DRYRUN") == "1":
         # launcher rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous over gloo, count the ranks, no dycore
-        n = 1.0
+        from pam_amd import parallel
+        nens_cfg = args.nens if args.nens > 0 else CONFIGS[args.config][0]
+        if args.scaling == "strong":
+            lo, hi = parallel.shard_range(nens_cfg, rank, world)
+            mine = hi - lo
+        else:
+            mine = nens_cfg
+        n, shards = 1.0, [mine]
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
             t = torch.ones(1, dtype=torch.float64)
             dist.all_reduce(t)
             n = float(t.item())
+            g = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(g, torch.tensor([mine], dtype=torch.int64))
+            shards = [int(x.item()) for x in g]
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": n, "scaling": args.scaling}))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": n, "scaling": args.scaling, "config": args.config,
+                              "shard_sizes": shards, "nens_total": sum(shards)}))
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -371,6 +476,11 @@ def worker(args):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dd = dist if (world > 1 or selftest) else None
+    ranks_seen = 1
+    if dd is not None:      # every rank adds one through the same backend the dt exchange uses: N ranks must be N
+        t = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dd.all_reduce(t)
+        ranks_seen = int(round(float(t.item())))
 
     job = Job(args.config, args, dev, rank, world, args.nens)
     job.sharded = dd is not None
@@ -383,51 +493,8 @@ def worker(args):
     # ---- per-kernel durations (HIP events on the stream each kernel is launched on), separate un-timed passes
     roofline, kernels, kernel_rooflines = None, {}, []
     if not args.no_kernel_timing:
-        d = job.dycore
-        d.set_kernel_timing(True)
-        kernels = job.kernel_pass()                    # shipped configuration (chunks overlap: durations include contention)
-        d.set_ensemble_chunks(1)                       # every stage kernel on its own: whole ensemble per launch
-        alone = job.kernel_pass()
-        d.set_ensemble_chunks(args.chunks if args.chunks >= 0 else 0, args.lds_floor)
-        d.set_kernel_timing(False)
-        kernel_rooflines = stage_rooflines(job, alone)
-        stage = [k for k in STAGE_KERNELS if k in alone]
-        if stage:
-            nstage = stage_count(alone)
-            dom = max(stage, key=lambda k: alone[k]["total_ms"])
-            avg_s = alone[dom]["total_ms"] / nstage * 1e-3    # per stage (the y and z sweeps are two launches of one kernel)
-            alg_bytes = cells / 3.0 * 64.0 * (5 + nt)            # 64*(5+NT) B per cell-update, 1/3 per stage
-            achieved = alg_bytes / avg_s / 1e9
-            kname = "awfl_%s_kernel" % dom.replace("fct_mult", "fct")
-            mine = [k for k in kernel_rooflines if k["kernel"] == kname]
-            traffic, tnote = None, "no PMC profile for this configuration"
-            tpath = os.path.join(ROOT, "profiles", "r02_c2_traffic.json")
-            if args.config == "c2" and args.nens == 0 and args.scaling == "weak" and os.path.exists(tpath):
-                prof = json.load(open(tpath))
-                if prof.get("csrc_hash") == csrc_hash() and kname in prof.get("kernels", {}):
-                    traffic = prof["kernels"][kname]["hbm_bytes_per_stage"]
-                    tnote = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, this build (%s)" % prof["csrc_hash"]
-                else:
-                    tnote = "profiles/r02_c2_traffic.json was measured on another build of pam_amd/csrc (or lacks this kernel): not reported"
-            if traffic is not None:
-                for kr in kernel_rooflines:
-                    parts = kr["kernel"].split("+")
-                    if all(q in prof["kernels"] for q in parts):
-                        kr["traffic"] = sum(prof["kernels"][q]["hbm_bytes_per_stage"] for q in parts)
-            stage_ms = sum(alone[k]["total_ms"] for k in stage) / nstage
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tnote,
-                        "ms_per_stage": alone[dom]["total_ms"] / nstage, "launches_per_stage": alone[dom]["launches"] / nstage,
-                        "alg_bytes_per_launch": alg_bytes,
-                        "binding_roofline": "fp64-valu",
-                        "note": "per tendency stage of the whole ensemble (the y and z sweeps are two launches of this kernel), "
-                                "measured with one ensemble range (nothing co-running); achieved = SURVEY 8d algorithmic "
-                                "bytes of a whole stage / this kernel's time per stage.  The kernel is FP64-VALU-bound (SURVEY F5), see `valu`; all stage kernels "
-                                "back to back take %.2f ms" % stage_ms,
-                        "stage_ms_back_to_back": stage_ms,
-                        "stage_frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "valu": ({"bound": "fp64-valu", "achieved": mine[0]["fp64_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": mine[0]["valu_frac"]} if mine else None)}
+        roofline, kernels, kernel_rooflines = measure_roofline(job, args, default_workload=(args.nens == 0 and args.scaling == "weak"
+                                                                                           and not args.limiter))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -452,6 +519,10 @@ def worker(args):
                 others[c] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / 3 * 1e3, "workload": j.desc % j.nens,
                              "num_tracers": j.nt, "substeps_per_step": sub / 3.0,
                              "hbm_frac": u / el * 64.0 * (5 + j.nt) / 1e9 / HBM_PEAK_GBS}
+                if not args.no_kernel_timing:
+                    rf, _, krf = measure_roofline(j, args)
+                    others[c]["roofline"] = rf
+                    others[c]["kernel_rooflines"] = krf
                 j.close()
                 del j
             except Exception as e:
@@ -467,7 +538,8 @@ def worker(args):
                           "parallelism": "nens-shard x%d" % world,
                           "limiter_input": args.limiter, "fct_rows_flagged_last_stage": fct_rows[0], "fct_rows": fct_rows[1],
                           "collective": None if world == 1 else "all-reduce(MIN) of dt, 8 B per timeStep, backend %s%s" % (
-                              backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev))},
+                              backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev)),
+                          "ranks_seen": ranks_seen, "device": str(dev)},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
                "other_configs": others}
         print(json.dumps(out))

@@ -78,6 +78,22 @@ int main(int argc, char **argv) {
 #else
     if (!mode_a) coupler.set_option<bool>("balance_hydrostasis_with_gravity", false);   // after init(), SURVEY 8c
     dycore.declare_current_profile_as_hydrostatic(coupler);                  // the host model does this once per GCM step
+    if (hdr[6] & 8) {
+      // the two converts with the reference's own argument lists (awfl/Dycore.h:1336-1338, :1281-1283), as E3SM's pam_driver
+      // calls them: coupler -> the caller's halo'd arrays, coupler fields wiped, arrays -> coupler
+      const int hs = 3;
+      const std::vector<int> hdims = {nz + 2 * hs, ny + 2 * hs, nx + 2 * hs, nens};
+      size_t nh = 1;
+      for (int d : hdims) nh *= d;
+      real *ps = nullptr, *pt = nullptr;
+      if (hipMalloc((void **)&ps, 5 * nh * sizeof(real)) != hipSuccess || hipMalloc((void **)&pt, (size_t)nt * nh * sizeof(real)) != hipSuccess) die("hipMalloc");
+      real5d state(ps, {5, hdims[0], hdims[1], hdims[2], hdims[3]}), tracers(pt, {nt, hdims[0], hdims[1], hdims[2], hdims[3]});
+      dycore.convert_coupler_to_dynamics(coupler, state, tracers);
+      for (auto &n : names) (void)hipMemsetAsync(dm.get<real, 4>(n).data(), 0xFF, ncell * sizeof(real), 0);   // NaN bit patterns
+      dycore.convert_dynamics_to_coupler(coupler, realConst5d(ps, state.dims()), realConst5d(pt, tracers.dims()));
+      if (hipDeviceSynchronize() != hipSuccess) die("device error");
+      (void)hipFree(ps); (void)hipFree(pt);
+    }
 #endif
     for (int s = 0; s < nsteps; s++) {
       coupler.run_module("dycore", [&](pam::PamCoupler &c) { dycore.timeStep(c); });    // driver.cpp:248

@@ -125,6 +125,15 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
 int pam_amd_awfl_convert_coupler_to_dynamics(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields);
 int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields);
 
+/* The same two members with the reference's own argument lists (Dycore.h:1336-1338, :1281-1283): the caller's HALO'D device
+ * arrays  state(5, nz+6, ny+6, nx+6, nens) = rho, rho u, rho v, rho w, rho theta  and  tracers(NT, nz+6, ny+6, nx+6, nens) =
+ * tracer densities, interior at [3+k][3+j][3+i].  coupler -> arrays fills the interior (halos untouched, Dycore.h:1370-1387);
+ * arrays -> coupler reads it (Dycore.h:1313-1330).  The handle's resident state is not involved. */
+int pam_amd_awfl_convert_coupler_to_dynamics_arrays(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double *state,
+                                                    double *tracers);
+int pam_amd_awfl_convert_dynamics_to_coupler_arrays(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, const double *state,
+                                                    const double *tracers);
+
 /* --- measurement hooks (not in the reference; cf. its -DPAM_FUNCTION_TIMERS, pam_coupler.h:144-150) ------------ */
 /* Enable HIP-event timing of every kernel launch on the handle's stream (off by default: zero overhead). */
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);

@@ -53,6 +53,8 @@ SYMBOLS = {
     "pam_amd_awfl_time_step": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_double, C.c_double, C.POINTER(C.c_int), _DP]),
     "pam_amd_awfl_convert_coupler_to_dynamics": (C.c_int, [C.c_void_p, C.POINTER(Fields)]),
     "pam_amd_awfl_convert_dynamics_to_coupler": (C.c_int, [C.c_void_p, C.POINTER(Fields)]),
+    "pam_amd_awfl_convert_coupler_to_dynamics_arrays": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_void_p, C.c_void_p]),
+    "pam_amd_awfl_convert_dynamics_to_coupler_arrays": (C.c_int, [C.c_void_p, C.POINTER(Fields), C.c_void_p, C.c_void_p]),
     "pam_amd_awfl_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_get_kernel_timing": (C.c_int, [C.c_void_p, C.c_char_p, _DP, C.POINTER(C.c_longlong)]),
     "pam_amd_awfl_reset_kernel_timing": (C.c_int, [C.c_void_p]),

@@ -855,6 +855,50 @@ PAMA_D void finalize_body(const Params &P, const double *__restrict__ prim, cons
   temp_c[idx] = press / (rho_d * P.R_d + rho_v * P.R_v);
 }
 
+// The reference's own signatures of the two converts take the caller's HALO'D arrays (Dycore.h:1281-1283, :1336-1338):
+// state(5, nz+6, ny+6, nx+6, nens) = rho, rho u, rho v, rho w, rho theta and tracers(NT, ...) = tracer densities, interior at
+// [hs+k][hs+j][hs+i].  These two bodies are that interface (the resident state of the handle is not involved): coupler fields ->
+// interior of the arrays (Dycore.h:1370-1387; halos untouched) and back (Dycore.h:1313-1330).
+PAMA_D long long halo_index(const Params &P, int l, int k, int j, int i, int e) {
+  return ((((long long)l * (P.nz + 2 * HS) + (k + HS)) * (P.ny + 2 * HS) + (j + HS)) * (P.nx + 2 * HS) + (i + HS)) * P.nens + e;
+}
+PAMA_D void coupler_to_halo_arrays_body(const Params &P, const double *__restrict__ rho_d_c, const double *__restrict__ u_c,
+                                        const double *__restrict__ v_c, const double *__restrict__ w_c,
+                                        const double *__restrict__ temp_c, const TracerPtrs &trc, double *__restrict__ state,
+                                        double *__restrict__ tracers, const CellId &c) {
+  const long long idx = c.idx;
+  const double rho_d = rho_d_c[idx], temp = temp_c[idx], rho_v = trc.p[P.idWV][idx];
+  const double press = rho_d * P.R_d * temp + rho_v * P.R_v * temp;
+  double rho = rho_d;
+  for (int t = 0; t < P.nt; t++)
+    if ((P.mass_mask >> t) & 1ull) rho += trc.p[t][idx];
+  const double theta = pow(press / P.C0, 1.0 / P.gamma) / rho;
+  state[halo_index(P, 0, c.k, c.j, c.i, c.e)] = rho;
+  state[halo_index(P, 1, c.k, c.j, c.i, c.e)] = rho * u_c[idx];
+  state[halo_index(P, 2, c.k, c.j, c.i, c.e)] = rho * v_c[idx];
+  state[halo_index(P, 3, c.k, c.j, c.i, c.e)] = rho * w_c[idx];
+  state[halo_index(P, 4, c.k, c.j, c.i, c.e)] = rho * theta;
+  for (int t = 0; t < P.nt; t++) tracers[halo_index(P, t, c.k, c.j, c.i, c.e)] = trc.p[t][idx];
+}
+PAMA_D void halo_arrays_to_coupler_body(const Params &P, const double *__restrict__ state, const double *__restrict__ tracers,
+                                        double *__restrict__ rho_d_c, double *__restrict__ u_c, double *__restrict__ v_c,
+                                        double *__restrict__ w_c, double *__restrict__ temp_c, const TracerPtrs &trc, const CellId &c) {
+  const long long idx = c.idx;
+  const double rho = state[halo_index(P, 0, c.k, c.j, c.i, c.e)];
+  const double u = state[halo_index(P, 1, c.k, c.j, c.i, c.e)] / rho, v = state[halo_index(P, 2, c.k, c.j, c.i, c.e)] / rho;
+  const double w = state[halo_index(P, 3, c.k, c.j, c.i, c.e)] / rho, theta = state[halo_index(P, 4, c.k, c.j, c.i, c.e)] / rho;
+  const double press = P.C0 * pow(rho * theta, P.gamma);
+  const double rho_v = tracers[halo_index(P, P.idWV, c.k, c.j, c.i, c.e)];
+  double rho_d = rho;
+  for (int t = 0; t < P.nt; t++) {
+    const double r = tracers[halo_index(P, t, c.k, c.j, c.i, c.e)];
+    if ((P.mass_mask >> t) & 1ull) rho_d -= r;
+    trc.p[t][idx] = r;
+  }
+  rho_d_c[idx] = rho_d; u_c[idx] = u; v_c[idx] = v; w_c[idx] = w;
+  temp_c[idx] = press / (rho_d * P.R_d + rho_v * P.R_v);
+}
+
 // CFL time step of one cell (Dycore.h:86-99); the caller min-reduces.
 PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, const double *__restrict__ u_c,
                        const double *__restrict__ v_c, const double *__restrict__ w_c,

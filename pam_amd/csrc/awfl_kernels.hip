@@ -263,6 +263,21 @@ __global__ void __launch_bounds__(256) awfl_finalize_kernel(Params P, EnsRange R
   if (grid_cell(P, R, c)) finalize_body(P, prim, seed, rho_d, u, v, w, temp, trc, c);
 }
 
+__global__ void __launch_bounds__(256) awfl_c2d_arrays_kernel(Params P, EnsRange R, const double *__restrict__ rho_d,
+                                                              const double *__restrict__ u, const double *__restrict__ v,
+                                                              const double *__restrict__ w, const double *__restrict__ temp,
+                                                              TracerPtrs trc, double *__restrict__ state, double *__restrict__ tracers) {
+  CellId c;
+  if (grid_cell(P, R, c)) coupler_to_halo_arrays_body(P, rho_d, u, v, w, temp, trc, state, tracers, c);
+}
+__global__ void __launch_bounds__(256) awfl_d2c_arrays_kernel(Params P, EnsRange R, const double *__restrict__ state,
+                                                              const double *__restrict__ tracers, double *__restrict__ rho_d,
+                                                              double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                                              double *__restrict__ temp, TracerPtrs trc) {
+  CellId c;
+  if (grid_cell(P, R, c)) halo_arrays_to_coupler_body(P, state, tracers, rho_d, u, v, w, temp, trc, c);
+}
+
 // CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, one atomicMin per wavefront on the
 // bit pattern (positive doubles order like unsigned integers).
 __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *__restrict__ rho_d,
@@ -982,6 +997,32 @@ int pam_amd_awfl_convert_dynamics_to_coupler(pam_amd_awfl_t *h, const pam_amd_aw
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   USE_DEVICE(h);
   return launch_finalize(h, fields, full_range(h->P), h->stream);
+}
+
+int pam_amd_awfl_convert_coupler_to_dynamics_arrays(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double *state,
+                                                    double *tracers) {
+  if (!h || !state || !tracers) return fail(PAM_AMD_EINVAL, "convert_coupler_to_dynamics: null argument");
+  USE_DEVICE(h);
+  TracerPtrs tp;
+  if (int rc = make_tracer_ptrs(h, fields, tp)) return rc;
+  const EnsRange r = full_range(h->P);
+  hipLaunchKernelGGL(awfl_c2d_arrays_kernel, cell_grid(h->P, r), dim3(256), 0, h->stream, h->P, r, fields->density_dry, fields->uvel,
+                     fields->vvel, fields->wvel, fields->temp, tp, state, tracers);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_convert_dynamics_to_coupler_arrays(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, const double *state,
+                                                    const double *tracers) {
+  if (!h || !state || !tracers) return fail(PAM_AMD_EINVAL, "convert_dynamics_to_coupler: null argument");
+  USE_DEVICE(h);
+  TracerPtrs tp;
+  if (int rc = make_tracer_ptrs(h, fields, tp)) return rc;
+  const EnsRange r = full_range(h->P);
+  hipLaunchKernelGGL(awfl_d2c_arrays_kernel, cell_grid(h->P, r), dim3(256), 0, h->stream, h->P, r, state, tracers, fields->density_dry,
+                     fields->uvel, fields->vvel, fields->wvel, fields->temp, tp);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
 }
 
 int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *fields, double crm_dt, double dt_dyn_hint,

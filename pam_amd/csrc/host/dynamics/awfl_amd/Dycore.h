@@ -147,8 +147,18 @@ class Dycore {
     chk(pam_amd_awfl_declare_current_profile_as_hydrostatic(h, &f, &g));
   }
 
-  // awfl/Dycore.h:1336 / :1281.  The reference passes its halo'd state/tracers arrays as further arguments; here the
-  // dynamics state is resident inside the handle, so the coupler is the only argument.
+  // awfl/Dycore.h:1336-1338 / :1281-1283, the reference's argument lists: the caller's halo'd arrays
+  // state(5, nz+2hs, ny+2hs, nx+2hs, nens) and tracers(num_tracers, ...), hs = 3 (what E3SM's pam_driver passes)
+  void convert_coupler_to_dynamics(pam::PamCoupler &coupler, real5d &state, real5d &tracers) const {
+    auto f = fields_readonly(coupler);
+    chk(pam_amd_awfl_convert_coupler_to_dynamics_arrays(h, &f, state.data(), tracers.data()));
+  }
+  void convert_dynamics_to_coupler(pam::PamCoupler &coupler, realConst5d state, realConst5d tracers) const {
+    auto f = fields(coupler);
+    chk(pam_amd_awfl_convert_dynamics_to_coupler_arrays(h, &f, state.data(), tracers.data()));
+  }
+  // ... and without them: the dynamics state resident inside the handle is refreshed from / written to
+  // the coupler
   void convert_coupler_to_dynamics(pam::PamCoupler &coupler) const {
     auto f = fields_readonly(coupler);
     chk(pam_amd_awfl_convert_coupler_to_dynamics(h, &f));

@@ -59,13 +59,16 @@ inline void apply_gcm_forcing_tendencies(pam::PamCoupler &coupler) {
   auto c = gcm_forcing_detail::crm_fields(coupler);
   auto g = gcm_forcing_detail::gcm_columns(coupler);
   auto t = gcm_forcing_detail::tendencies(coupler);
-  double *work = nullptr;
-  if (hipMalloc((void **)&work, ((size_t)6 * nz * nens + 2 * nens + 4) * sizeof(double)) != hipSuccess)
-    endrun("ERROR: gcm forcing scratch allocation failed");
+  // scratch in a DataManager entry registered on first use (like gcm_forcing_tend_*, gcm_forcing.h:132-147): no allocation and no
+  // device-wide synchronisation per CRM step
+  int nwork = 6 * nz * nens + 2 * nens + 4;
+  if (dm.entry_exists("gcm_forcing_scratch") && (int)dm.get<real, 1>("gcm_forcing_scratch").size() != nwork)
+    dm.unregister_and_deallocate("gcm_forcing_scratch");
+  if (!dm.entry_exists("gcm_forcing_scratch"))
+    dm.register_and_allocate<real>("gcm_forcing_scratch", "GCM forcing column sums", {nwork});
   int rc = pam_amd_gcm_forcing_apply(nens, nx, ny, nz, c.data(), g.data(), t.data(), dm.get<real const, 2>("vertical_cell_dz").data(),
-                                     coupler.get_option<real>("crm_dt"), coupler.get_option<real>("gcm_physics_dt"), work, nullptr,
-                                     nullptr);
-  (void)hipFree(work);
+                                     coupler.get_option<real>("crm_dt"), coupler.get_option<real>("gcm_physics_dt"),
+                                     dm.get<real, 1>("gcm_forcing_scratch").data(), nullptr, nullptr);
   if (rc) endrun(pam_amd_awfl_last_error());
 }
 

@@ -39,6 +39,12 @@ class DeviceView {
   std::vector<int> const &dims() const { return dims_; }
 };
 
+}  // namespace pam
+// pam_const.h:30-55: YAKL device arrays by rank; here every rank is the same non-owning view
+typedef pam::DeviceView<real> real5d;
+typedef pam::DeviceView<real const> realConst5d;
+namespace pam {
+
 class Options {
   std::map<std::string, std::variant<int, real, bool, std::string>> opts;
  public:

@@ -167,16 +167,35 @@ class Dycore:
         self.last_ncycles, self.last_dt_dyn = n.value, dt.value
         return n.value
 
-    def convert_coupler_to_dynamics(self, coupler):
+    def _halo_arrays(self, coupler, state, tracers):
+        hs = 3
+        shape = (coupler.get_nz() + 2 * hs, coupler.get_ny() + 2 * hs, coupler.get_nx() + 2 * hs, coupler.get_nens())
+        for a, n in ((state, 5), (tracers, coupler.get_num_tracers())):
+            if tuple(a.shape) != (n,) + shape or a.dtype != torch.float64 or not a.is_contiguous() or not a.is_cuda:
+                endrun("ERROR: state / tracers must be contiguous fp64 (n, nz+6, ny+6, nx+6, nens) arrays on the GPU")
+
+    def convert_coupler_to_dynamics(self, coupler, state=None, tracers=None):
+        """Dycore.h:1336.  With the reference's argument list (coupler, state, tracers): fills the interior of the caller's halo'd
+        arrays; with the coupler alone: refreshes the dycore's resident state."""
         self._need()
         self._sync_balance_option(coupler)
         f = self._mk_fields(coupler, readonly=True)
-        check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics(self._h, C.byref(f)))
+        if state is None and tracers is None:
+            check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics(self._h, C.byref(f)))
+            return
+        self._halo_arrays(coupler, state, tracers)
+        check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics_arrays(self._h, C.byref(f), state.data_ptr(), tracers.data_ptr()))
 
-    def convert_dynamics_to_coupler(self, coupler):
+    def convert_dynamics_to_coupler(self, coupler, state=None, tracers=None):
+        """Dycore.h:1281.  (coupler, state, tracers): coupler fields from the caller's halo'd arrays; coupler alone: from the
+        dycore's resident state."""
         self._need()
         f = self._mk_fields(coupler)
-        check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler(self._h, C.byref(f)))
+        if state is None and tracers is None:
+            check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler(self._h, C.byref(f)))
+            return
+        self._halo_arrays(coupler, state, tracers)
+        check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler_arrays(self._h, C.byref(f), state.data_ptr(), tracers.data_ptr()))
 
     def dycore_name(self):
         lib = self._lib or capi.load()

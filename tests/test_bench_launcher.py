@@ -25,6 +25,25 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2.0 and line["scaling"] == "strong"
 
 
+def test_eight_ranks_strong_scaling_of_c2_is_128_members_each():
+    """the driver's N = 8 line: `bench.py --gpus 8 --scaling strong --config c2` starts 8 ranks, every one of them is seen by the
+    collective, and each owns 128 of the 1024 members (BASELINE config C2 sharded by nens)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--scaling", "strong", "--config", "c2"], env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8.0
+    assert line["shard_sizes"] == [128] * 8 and line["nens_total"] == 1024
+
+
+def test_eight_ranks_weak_scaling_keeps_the_config_per_rank():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--config", "c4"], env=_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ranks_seen"] == 8.0 and line["shard_sizes"] == [512] * 8      # C4: 512 = one GPU's shard of nens = 4096
+
+
 def test_single_rank_default():
     r = subprocess.run([sys.executable, BENCH], env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]

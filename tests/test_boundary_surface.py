@@ -94,6 +94,8 @@ AWFL_SIGNATURES = {
     "void timeStep(pam::PamCoupler &coupler)": 107,
     "real compute_time_step(pam::PamCoupler const &coupler, real cfl = 0.8) const": 65,
     "void declare_current_profile_as_hydrostatic(pam::PamCoupler &coupler, bool use_gcm_data = false) const": 1392,
+    "void convert_dynamics_to_coupler(pam::PamCoupler &coupler, realConst5d state, realConst5d tracers) const": 1281,
+    "void convert_coupler_to_dynamics(pam::PamCoupler &coupler, real5d &state, real5d &tracers) const": 1336,
     "char const *dycore_name() const": 1544,
     "void finalize(pam::PamCoupler const &coupler) const": 1548,
 }

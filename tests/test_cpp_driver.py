@@ -55,6 +55,45 @@ def test_cpp_driver_matches_oracle(tmp_path, mode_a):
 
 
 @pytest.mark.gpu
+def test_cpp_dycore_converts_with_the_reference_argument_lists(tmp_path):
+    """convert_coupler_to_dynamics(coupler, state, tracers) / convert_dynamics_to_coupler(coupler, state, tracers) -- the
+    signatures E3SM's pam_driver calls (awfl/Dycore.h:1336-1338, :1281-1283) -- through the C++ plug-in class: coupler -> halo'd
+    arrays, coupler fields overwritten with NaN patterns, arrays -> coupler; no time step.  The round trip reproduces the inputs
+    (tracers bit for bit, the rest to the rounding of the two pow calls)."""
+    assert os.path.exists(DRIVER), "examples/driver missing: run __graft_entry__.build()"
+    nens, nx, ny, nz = 5, 7, 4, 9
+    tr = idz.TRACERS_KESSLER_SHOC
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    xlen, ylen = nx * 500.0, ny * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    c = idz.CONSTS_DEFAULT
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as fh:
+        fh.write(struct.pack("<8q", nens, nx, ny, nz, len(tr), 0, 1 | 8, 1))      # no steps; bit 8: the halo-array round trip
+        fh.write(struct.pack("<3d", xlen, ylen, 2.0))
+        fh.write(struct.pack("<6d", c["R_d"], c["cp_d"], c["R_v"], c["cp_v"], c["p0"], c["grav"]))
+        fh.write(np.asarray(zint, dtype="<f8").tobytes())
+        fh.write(bytes(bytearray(v for t in range(len(tr)) for v in (int(pos[t]), int(mass[t])))))
+        fh.write(struct.pack("<q", idwv))
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            fh.write(f[k].astype("<f8").tobytes())
+        for t in range(len(tr)):
+            fh.write(f["tracers"][t].astype("<f8").tobytes())
+    r = subprocess.run([DRIVER, inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(outp, dtype="<f8").reshape(5 + len(tr), nz, ny, nx, nens)
+    exp = [f["density_dry"], f["uvel"], f["vvel"], f["wvel"], f["temp"]] + [f["tracers"][t] for t in range(len(tr))]
+    for i, e in enumerate(exp):
+        assert np.isfinite(raw[i]).all(), i
+        if i >= 5:
+            assert np.array_equal(raw[i], e), i
+        else:
+            assert np.abs(raw[i] - e).max() <= 1e-14 * max(np.abs(e).max(), 1e-300), (i, np.abs(raw[i] - e).max())
+
+
+@pytest.mark.gpu
 def test_cpp_driver_crm_loop_dycore_sponge_kessler(tmp_path):
     """The CRM step loop of the reference driver minus SGS (driver.cpp:248-253): dycore -> sponge_layer -> Kessler
     micro, all three through their C++ plug-in mirrors, against the same sequence of oracle calls."""

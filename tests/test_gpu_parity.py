@@ -204,6 +204,41 @@ def test_raw_fluxes_match_oracle():
     dycore.finalize(coupler)
 
 
+def test_converts_with_halo_arrays_match_oracle():
+    """Dycore::convert_coupler_to_dynamics(coupler, state, tracers) and convert_dynamics_to_coupler(coupler, state, tracers) with
+    the reference's halo'd arrays (Dycore.h:1336-1388, :1281-1331) against the oracle's restatement of the same two kernels."""
+    import torch
+    nens, nx, ny, nz = 3, 6, 4, 8
+    tr = idz.TRACERS_KESSLER_SHOC
+    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, idz.stretched_interfaces(nz, 12000.0))
+    nt = len(tr)
+    st_o, tr_o = oracle.convert_coupler_to_dynamics(fo)
+    st = torch.full((5, nz + 6, ny + 6, nx + 6, nens), float("nan"), dtype=torch.float64, device="cuda:0")
+    trc = torch.full((nt, nz + 6, ny + 6, nx + 6, nens), float("nan"), dtype=torch.float64, device="cuda:0")
+    dycore.convert_coupler_to_dynamics(coupler, st, trc)
+    torch.cuda.synchronize()
+    gs, gt = st.cpu().numpy(), trc.cpu().numpy()
+    inner = (slice(None), slice(3, -3), slice(3, -3), slice(3, -3), slice(None))
+    for l in range(5):
+        assert np.abs(gs[inner][l] - st_o[inner][l]).max() <= 1e-14 * np.abs(st_o[inner][l]).max(), l
+    assert np.array_equal(gt[inner], tr_o[inner])
+    halo = np.ones(gs.shape, dtype=bool)
+    halo[inner] = False
+    assert np.isnan(gs[halo]).all() and np.isnan(gt[np.broadcast_to(halo[:1], gt.shape)]).all(), "halos must stay untouched"
+    # back: a modified state (as if the caller had advanced it) -> coupler
+    st_o[inner] *= 1.01
+    tr_o[inner] *= 0.5
+    fexp = copy.deepcopy(fo)
+    oracle.convert_dynamics_to_coupler(st_o, tr_o, fexp)
+    dycore.convert_dynamics_to_coupler(coupler, torch.from_numpy(st_o).to("cuda:0"), torch.from_numpy(tr_o).to("cuda:0"))
+    torch.cuda.synchronize()
+    got = coupler.dump_fields()
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+        assert np.abs(got[k] - fexp[k]).max() <= 1e-14 * np.abs(fexp[k]).max(), k
+    assert np.array_equal(got["tracers"], fexp["tracers"])
+    dycore.finalize(coupler)
+
+
 def test_gcm_column_hydrostatic_branch():
     """declare_current_profile_as_hydrostatic(use_gcm_data=true), Dycore.h:1415-1434."""
     nens, nx, ny, nz = 3, 6, 1, 12

@@ -227,7 +227,7 @@ def test_single_stage_every_prognostic_field_1e12(case, fused, mode_a):
 def test_single_substep_every_prognostic_field_1e12(case):
     """ONE SSPRK3 sub-step (crm_dt just below the CFL step -> ncycles = 1) through Dycore::timeStep: every coupler field,
     every tracer, gated at the north_star tolerance.  Multi-step runs amplify last-bit differences of the small, noisy
-    fields (v, w) through the flow's own sensitivity -- the growth is printed by test_error_growth_is_the_flows_own."""
+    fields (v, w) through the flow's own sensitivity -- the growth is gated, step by step, by test_tolerance_vs_steps_c1_bubble_is_the_flows_own_sensitivity."""
     import torch
     if case == "3d_nt4_fct":
         coupler, dycore, oracle, fo, names, dims = _fct_case()
@@ -259,34 +259,57 @@ def test_single_substep_every_prognostic_field_1e12(case):
     dycore.finalize(coupler)
 
 
-def test_error_growth_is_the_flows_own():
-    """Why multi-step gates on u, v, w are looser than 1e-12: the oracle run twice, once from inputs perturbed by one unit in
-    the last place, diverges from itself at the same rate as the HIP path diverges from the oracle.  Prints both series."""
+def test_tolerance_vs_steps_c1_bubble_is_the_flows_own_sensitivity():
+    """Tolerance as a function of N, asserted (north_star: "prognostic state after N steps ... to a stated fp64 tolerance").
+    BASELINE config C1 exactly -- dry rising bubble, nens = 2, 32 x 32 x 60, the reference's 20 km box -- over 10 timeSteps
+    (30 SSPRK3 sub-steps), three runs side by side: the HIP path, the oracle, and the oracle started from inputs perturbed by ONE
+    unit in the last place of the temperature.  At EVERY step:
+      * rho_d and T agree with the oracle ELEMENT-WISE to 1e-12 (|a - b| <= 1e-12 |b| in every cell; measured ~7e-15);
+      * for every prognostic field, max|HIP - oracle| <= 4 x max|oracle(+1 ulp) - oracle| (floor 1e-14, relative to max|field|): the
+        HIP path differs from the oracle by no more than the oracle differs from itself under the smallest possible change of its
+        input.  u, v, w sit at 1e-12..5e-12 of their maxima in BOTH series from the first step on -- that is the flow's own
+        sensitivity (acoustic adjustment of a bubble sampled at cell centres), which is why the multi-step gates on the velocity
+        components (test_gpu_parity.py) are looser than 1e-12, and what any change of the kernels' arithmetic (e.g. a cheaper pow,
+        DESIGN.md section 6) must stay within.
+    The table is written to gpurun_out/r03_error_growth_c1.txt (committed as profiles/r03_error_growth_c1.txt)."""
+    import os
     import torch
-    nens, nx, ny, nz = 2, 8, 6, 10
-    tr = idz.TRACERS_NONE
-    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, idz.stretched_interfaces(nz, 12000.0), mag=1.0)
     from oracle import awfl_oracle as ao
+    nens, nx, ny, nz, nsteps = 2, 32, 32, 60, 10
+    tr = idz.TRACERS_NONE
+    zint = idz.uniform_interfaces(nz, 20000.0)
+    coupler, dycore, oracle, fo, names = _setup(nens, nx, ny, nz, tr, zint, supercell=False, dxy=625.0)
     names_, pos, mass, idwv = idz.tracer_flags(tr)
-    o2 = ao.OracleDycore(nens, nx, ny, nz, nx * 500.0, ny * 500.0, np.diff(idz.stretched_interfaces(nz, 12000.0)), pos, mass, idwv)
+    o2 = ao.OracleDycore(nens, nx, ny, nz, nx * 625.0, ny * 625.0, np.diff(zint), pos, mass, idwv)
     f2 = copy.deepcopy(fo)
     f2["temp"] = np.nextafter(f2["temp"], np.inf)
     dycore.declare_current_profile_as_hydrostatic(coupler)
     oracle.declare_current_profile_as_hydrostatic(fo)
     o2.declare_current_profile_as_hydrostatic(f2)
-    rows = []
-    for step in range(6):
-        dycore.timeStep(coupler)
-        oracle.time_step(fo, 2.0)
-        o2.time_step(f2, 2.0)
+    keys = ("density_dry", "temp", "uvel", "vvel", "wvel")
+    lines = ["# C1 dry bubble, nens=2, 32x32x60, crm_dt=2 s: per timeStep, relative to max|field| (rho_d, T also element-wise)",
+             "# step substeps | HIP vs oracle: rho_d T u v w | oracle(+1 ulp T) vs oracle: rho_d T u v w | element-wise HIP vs oracle: rho_d T"]
+    sub = 0
+    for step in range(1, nsteps + 1):
+        n = dycore.timeStep(coupler)
+        n1, _ = oracle.time_step(fo, 2.0)
+        n2, _ = o2.time_step(f2, 2.0)
+        assert n == n1 == n2
+        sub += n
         torch.cuda.synchronize()
         got = coupler.dump_fields()
-        rows.append((step + 1,) + tuple(np.abs(got[k] - fo[k]).max() / np.abs(fo[k]).max() for k in ("density_dry", "temp", "uvel", "wvel", "vvel"))
-                    + tuple(np.abs(f2[k] - fo[k]).max() / np.abs(fo[k]).max() for k in ("density_dry", "temp", "uvel", "wvel", "vvel")))
-    print("timeStep | HIP vs oracle: rho_d T u w v | oracle vs oracle(+1ulp T): rho_d T u w v")
-    for r in rows:
-        print("%8d | %s | %s" % (r[0], " ".join("%.1e" % x for x in r[1:6]), " ".join("%.1e" % x for x in r[6:])))
-    last = rows[-1]
-    for i in range(5):      # the HIP path stays within 20x of the oracle's own 1-ulp sensitivity (and within the multi-step gates)
-        assert last[1 + i] <= max(20.0 * last[6 + i], 1e-13), (i, last)
+        hip = [np.abs(got[k] - fo[k]).max() / np.abs(fo[k]).max() for k in keys]
+        own = [np.abs(f2[k] - fo[k]).max() / np.abs(fo[k]).max() for k in keys]
+        elw = [np.abs((got[k] - fo[k]) / fo[k]).max() for k in ("density_dry", "temp")]
+        lines.append("%2d %3d | %s | %s | %s" % (step, sub, " ".join("%.1e" % x for x in hip), " ".join("%.1e" % x for x in own),
+                                                 " ".join("%.1e" % x for x in elw)))
+        for i, k in enumerate(keys):
+            assert hip[i] <= max(4.0 * own[i], 1e-14), (step, k, hip[i], own[i])
+        assert max(elw) <= TOL, (step, elw)
+    text = "\n".join(lines)
+    print(text)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r03_error_growth_c1.txt"), "w") as fh:
+        fh.write(text + "\n")
     dycore.finalize(coupler)

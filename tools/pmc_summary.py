@@ -78,6 +78,12 @@ def main():
             res[base] = {"hbm_bytes_per_launch": (fetch + write) / n, "launches": n, "launches_per_stage": n / nstage,
                          "hbm_bytes_per_stage": (fetch + write) / nstage, "fetch_bytes_x2_corrected_per_stage": fetch / nstage,
                          "write_bytes_per_stage": write / nstage}
+            # VALU issue: wave-level instructions and busy cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs), all template instances
+            inst = sum(sum(acc[k]["SQ_INSTS_VALU"]) for k in acc if re.sub(r"<.*", "", k) == base and "SQ_INSTS_VALU" in acc[k])
+            busy = sum(sum(acc[k]["GRBM_GUI_ACTIVE"]) for k in acc if re.sub(r"<.*", "", k) == base and "GRBM_GUI_ACTIVE" in acc[k])
+            if inst and busy:
+                res[base]["valu_insts_per_stage"] = inst / nstage
+                res[base]["busy_cycles_per_xcd_per_stage"] = busy / 8.0 / nstage
         i = sys.argv.index("--traffic-json")
         print(json.dumps({"csrc_hash": sys.argv[i + 1], "kernels": res,
                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py, config %s" % os.environ.get("PMC_SOURCE_CONFIG", "c2")}))
