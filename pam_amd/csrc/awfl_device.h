@@ -49,7 +49,7 @@ constexpr int FLUX_WAVES = FLUX_THREADS / 64;
 #endif
 constexpr int FLUX_NF = PAMA_FLUX_NF;   // advected fields swept together (independent polynomial chains per iteration)
 constexpr int FLUX_MAX_SPAN = 64; // longest span one wavefront sweeps without a cut (a 61-face column, a 64-cell line)
-constexpr int VZ_STRIDE = 30;  // per-level vertical table in difference form (struct DTable)
+constexpr int VZ_STRIDE = 31;  // per-level vertical table in difference form (struct DTable + one derived factor)
 
 enum PrimField { P_RHO = 0, P_PRES = 1, P_U = 2, P_V = 3, P_W = 4, P_THETA = 5, P_TR0 = 6 };
 
@@ -71,7 +71,7 @@ struct Params {
   const double *grav_var; // (nz,nens)
   const double *hy_dens;  // (nz,nens)
   const double *hy_pres;  // (nz,nens)
-  const double *vz;       // vertical difference-form tables: (nz+2,38) or (nz+2,38,nens)
+  const double *vz;       // vertical difference-form tables: (nz+2,VZ_STRIDE) or (nz+2,VZ_STRIDE,nens)
   unsigned long long pos_mask, mass_mask;  // tracer_positive / tracer_adds_mass bit sets
   int idWV;
 };
@@ -139,7 +139,7 @@ PAMA_D WenoConsts weno_consts() {
 struct WenoLin {
   double a1[3], a2[3];   // lower candidates: x coefficient; x^2 coefficient (UNIFORM: the second difference d_{i+1}-d_i = 2 a2)
   double h1, h2, h3, h4; // bridged upper polynomial: x, x^2 coefficients; x^3, x^4 coefficients times sqrt of their TV weight
-  double k2, k4;         // vertical only: even-part factors of the level (see weno5_blend)
+  double k2, k4, k2s;    // vertical only: even-part factors of the level (see weno5_blend); k2s = k2 / sqrt(13/3) goes with the scaled a2
 };
 
 // Non-linear part (WenoLimiter.h:141-180: TV, sigma blend, weights, convexify, map, convexify, weighted sum).
@@ -149,14 +149,32 @@ struct WenoLin {
 // source must give the same bits in every kernel it is inlined into (x/y/z sweeps, the fused x-sweep, the KAT hook), and the
 // backend's own contraction choices depend on the surrounding code (seen on gfx950: tv*tv + 1e-20 fused in one kernel and
 // not in another -- visible only where tv^2 ~ 1e-20, i.e. at the edges of tracer blobs).
+// UNIFORM, scaling: the total variation of a lower candidate is a1^2 + K2U (2 a2)^2 with K2U = 13/12.  weno5_const forms every
+// x coefficient (a1 of the candidates, h1..h4 of the upper polynomial) with literal factors, so it delivers them divided by
+// sqrt(K2U) at no cost: all four TVs then come out divided by K2U -- a1'^2 + (2 a2)^2 is one multiply and one fma instead of two
+// multiplies and an fma, three instructions per polynomial less -- and the weights, which are ratios of 1/(tv^2 + eps), are those of
+// the unscaled TVs when the two eps constants carry the factor (tv^2 + eps = K2U^2 (tv'^2 + eps / K2U^2); the eps added to the sum
+// of the unnormalised weights gets K2U^2).  The odd part and the upper polynomial's share of the even part are linear in the scaled
+// coefficients: the factor moves into their constants.
+constexpr double csqrt_(double v) {      // compile-time square root (Newton; v > 0)
+  double x = v > 1.0 ? v : 1.0;
+  for (int i = 0; i < 200; i++) x = 0.5 * (x + v / x);
+  return x;
+}
+constexpr double WENO_K2U = 0.25 * AWFL_TV3_A2A2;            // uniform grid: p.a2 holds the second difference = 2 a2
+constexpr double WENO_SQRT_K2U = csqrt_(WENO_K2U), WENO_RSQRT_K2U = 1.0 / WENO_SQRT_K2U;
 template <bool UNIFORM>
 PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, double &left, double &right) {
 #pragma clang fp contract(off)
-  constexpr double K2 = UNIFORM ? 0.25 * AWFL_TV3_A2A2 : AWFL_TV3_A2A2;
   constexpr double K13 = AWFL_TV5_A1A3 / AWFL_TV5_SQRT_A3A3, K24 = AWFL_TV5_A2A4 / AWFL_TV5_SQRT_A4A4;
+  constexpr double EPS_TV = UNIFORM ? 1.0e-20 / (WENO_K2U * WENO_K2U) : 1.0e-20;      // added to tv^2
+  constexpr double EPS_SUM = UNIFORM ? 1.0e-20 * (WENO_K2U * WENO_K2U) : 1.0e-20;     // added to the sum of the unnormalised weights
+  constexpr double UNSCALE = UNIFORM ? WENO_SQRT_K2U : 1.0;                           // scaled x coefficients -> true ones
   double tv[4];
 #pragma unroll
-  for (int i = 0; i < 3; i++) tv[i] = fma(p.a1[i], p.a1[i], (p.a2[i] * p.a2[i]) * K2);
+  for (int i = 0; i < 3; i++) {
+    tv[i] = fma(p.a1[i], p.a1[i], p.a2[i] * p.a2[i]);   // (vertical: the table delivers a2 times sqrt(13/3), see weno5_table)
+  }
   // coefs_to_tv<5> (TransformMatrices.h:871-876) grouped as h1 (h1 + .5 h3) + h2 (c2 h2 + 4.2 h4) + c3 h3^2 + c4 h4^2, with
   // h3, h4 carried pre-scaled by sqrt(c3), sqrt(c4)
   {
@@ -168,12 +186,12 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   // w_i = idl_i/(tv_i^2+eps), then convexify: w_i /= (sum_k w_k + eps) (WenoLimiter.h:163-166).  One reciprocal,
   // through products of the denominators d_i.  The eps added to the SUM matters when the TVs are large (pressure
   // stencils: sum ~ 1e-17), so it is kept: numerator and denominator are both scaled by d0*d1*d2*d3.
-  const double d0 = fma(tv[0], tv[0], 1.0e-20), d1 = fma(tv[1], tv[1], 1.0e-20);
-  const double d2 = fma(tv[2], tv[2], 1.0e-20), d3 = fma(tv[3], tv[3], 1.0e-20);
+  const double d0 = fma(tv[0], tv[0], EPS_TV), d1 = fma(tv[1], tv[1], EPS_TV);
+  const double d2 = fma(tv[2], tv[2], EPS_TV), d3 = fma(tv[3], tv[3], EPS_TV);
   const double p01 = d0 * d1, p23 = d2 * d3;
   const double x0 = d1 * p23, x1 = d0 * p23, x2 = d3 * p01, x3 = d2 * p01;
   const double n0 = wc.idl[0] * x0, n1 = wc.idl[1] * x1, n2 = wc.idl[2] * x2, n3 = wc.idl[3] * x3;
-  const double rs = weno_rcp(fma(1.0e-20, p01 * p23, fma(wc.idl[3], x3, fma(wc.idl[2], x2, fma(wc.idl[0], x0, n1)))));
+  const double rs = weno_rcp(fma(EPS_SUM, p01 * p23, fma(wc.idl[3], x3, fma(wc.idl[2], x2, fma(wc.idl[0], x0, n1)))));
   // map_weights (WenoLimiter.h:11-19) then convexify, again with one reciprocal; the normalisation 1/sum(m) is applied
   // to the two weighted sums instead of to the four weights
   const double nn[4] = {n0, n1, n2, n3};
@@ -194,12 +212,12 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
   // a2 (1/4 - w^2/12) (+ a4 (1/16 - w^4/80)) and needs no coefficients of its own.  (UNIFORM: p.a2 holds 2 a2.)
   const double lo_e = fma(m0, p.a2[0], fma(m1, p.a2[1], m2 * p.a2[2]));
   double se;
-  if (UNIFORM) se = fma(1.0 / 12.0, lo_e, m3 * fma(p.h4, 0.05 / AWFL_TV5_SQRT_A4A4, p.h2 * (1.0 / 6.0)));
-  else se = fma(p.k2, lo_e, m3 * fma(p.h4, p.k4, p.h2 * p.k2));
+  if (UNIFORM) se = fma(1.0 / 12.0, lo_e, m3 * fma(p.h4, UNSCALE * 0.05 / AWFL_TV5_SQRT_A4A4, p.h2 * (UNSCALE / 6.0)));
+  else se = fma(p.k2s, lo_e, m3 * fma(p.h4, p.k4, p.h2 * p.k2));
   // odd part: a1/2 (+ a3/8 for the upper polynomial); h3 is carried times sqrt(c3)
   const double so = fma(m3, fma(0.25 / AWFL_TV5_SQRT_A3A3, p.h3, p.h1), fma(m0, p.a1[0], fma(m1, p.a1[1], m2 * p.a1[2])));
   const double even = fma(rm, se, u2);
-  const double odd = (0.5 * rm) * so;
+  const double odd = ((0.5 * UNSCALE) * rm) * so;
   left = even - odd;
   right = even + odd;
 }
@@ -209,7 +227,9 @@ PAMA_D void weno5_blend(double u2, const WenoLin &p, const WenoConsts &wc, doubl
 //   hi[p-1][4]   p=1..4       bridged upper coefficients; the x^3 and x^4 rows are scaled by sqrt(39.1125), sqrt(625.8)
 //                             (their weights in coefs_to_tv<5>), see weno5_blend
 //   k2, k4                    even-part factors 1/4 - w^2/12 and (1/16 - w^4/80)/sqrt(625.8), w = width of the centre cell
-// VZ_STRIDE = 30 doubles per level in this order.
+// VZ_STRIDE doubles per level in this order, then k2 / sqrt(13/3).  In the STORED vertical tables (awfl_vertical.h) the lo2 rows
+// are multiplied by sqrt(13/3), the weight of a2^2 in coefs_to_tv<3> (TransformMatrices.h:188-193): the candidates' TV is then
+// a1^2 + a2'^2 -- one multiply and one fma instead of two multiplies and an fma -- and the even part, linear in a2', takes k2s.
 struct DTable { double lo1[3][2], lo2[3][2], hi[4][4], k2, k4; };
 
 // conversion of a stencil-form linear functional  sum_s c_s u_{s0+s}  (cells s0..s0+n-1 of the 5-stencil, centre = 2)
@@ -304,14 +324,15 @@ PAMA_D void weno5_const(const double u[5], const WenoConsts &wc, double &left, d
   p.a2[0] = d[1] - d[0];
   p.a2[1] = d[2] - d[1];
   p.a2[2] = d[3] - d[2];
-  p.a1[0] = fma(T.lo1[0][1], d[1], T.lo1[0][0] * d[0]);
-  p.a1[1] = 0.5 * s12;
-  p.a1[2] = fma(T.lo1[2][1], d[3], T.lo1[2][0] * d[2]);
-  p.h1 = fma(T.hi[0][1], s12, T.hi[0][0] * s03);
-  p.h2 = fma(-T.hi[1][0], t03, T.hi[1][2] * p.a2[1]);
-  p.h3 = T.hi[2][0] * (s03 - s12);
-  p.h4 = T.hi[3][3] * fma(-3.0, p.a2[1], t03);
-  p.k2 = p.k4 = 0.0;   // unused on the uniform grid (weno5_blend<true>)
+  constexpr double S = WENO_RSQRT_K2U;     // every x coefficient is delivered divided by sqrt(K2U) (see weno5_blend)
+  p.a1[0] = fma(S * T.lo1[0][1], d[1], (S * T.lo1[0][0]) * d[0]);
+  p.a1[1] = (S * 0.5) * s12;
+  p.a1[2] = fma(S * T.lo1[2][1], d[3], (S * T.lo1[2][0]) * d[2]);
+  p.h1 = fma(S * T.hi[0][1], s12, (S * T.hi[0][0]) * s03);
+  p.h2 = fma(-S * T.hi[1][0], t03, (S * T.hi[1][2]) * p.a2[1]);
+  p.h3 = (S * T.hi[2][0]) * (s03 - s12);
+  p.h4 = (S * T.hi[3][3]) * fma(-3.0, p.a2[1], t03);
+  p.k2 = p.k4 = p.k2s = 0.0;   // unused on the uniform grid (weno5_blend<true>)
   weno5_blend<true>(u[2], p, wc, left, right);
 }
 
@@ -335,6 +356,7 @@ PAMA_D void weno5_table(const double u[5], TabPtr tab, long long ts, const WenoC
   p.h4 = fma(tab[24 * ts], d[0], fma(tab[25 * ts], d[1], fma(tab[26 * ts], d[2], tab[27 * ts] * d[3])));
   p.k2 = tab[28 * ts];
   p.k4 = tab[29 * ts];
+  p.k2s = tab[30 * ts];
   weno5_blend<false>(u[2], p, wc, left, right);
 }
 

@@ -6,7 +6,7 @@
 // The reference inverts with yakl::intrinsics::matinv_ge, a third-party routine absent from the tree (YAKL
 // submodule, version unpinned); here it is Gauss-Jordan elimination without pivoting, (col,row) order.
 //
-// Output per level (and per ensemble member): VZ_STRIDE = 30 doubles, the difference-form table `DTable` of
+// Output per level (and per ensemble member): VZ_STRIDE = 31 doubles, the difference-form table `DTable` of
 // awfl_device.h (make_dtable): lower-candidate x / x^2 / even-edge coefficients and the bridged upper polynomial
 // (WenoLimiter.h:128-136 folded in; linear in the stencil, so exact up to rounding).
 // The stencil-form vert_sten_to_coefs / vert_weno_recon_lower are also returned for the DataManager entries of
@@ -94,9 +94,15 @@ inline void level_matrices(const double *dzcol /* stride nens */, long long stri
       for (int ii = 0; ii < 3; ii++) lo[i][s][ii] = wrl[(i * 3 + s) * 3 + ii];
   for (int s = 0; s < 5; s++)
     for (int ii = 0; ii < 5; ii++) hi[s][ii] = s2c[s * 5 + ii];
-  const DTable t = make_dtable(lo, hi, idl, locs[3] - locs[2]);   // width of the centre cell in the matrices' coordinate
-  static_assert(sizeof(DTable) == VZ_STRIDE * sizeof(double), "DTable layout");
+  DTable t = make_dtable(lo, hi, idl, locs[3] - locs[2]);   // width of the centre cell in the matrices' coordinate
+  static_assert(sizeof(DTable) == (VZ_STRIDE - 1) * sizeof(double), "DTable layout");
+  // stored form: the x^2 rows of the lower candidates times sqrt(13/3) (their TV is then a1^2 + a2'^2), and the matching
+  // even-part factor behind the struct (awfl_device.h: DTable, weno5_blend)
+  const double sq = std::sqrt(AWFL_TV3_A2A2);
+  for (int i = 0; i < 3; i++)
+    for (int q = 0; q < 2; q++) t.lo2[i][q] *= sq;
   std::memcpy(dform, &t, sizeof(t));
+  dform[VZ_STRIDE - 1] = t.k2 / sq;
 }
 
 // dz: host copy of vertical_cell_dz (nz,nens)
