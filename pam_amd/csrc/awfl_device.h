@@ -573,8 +573,12 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive: the faces this span owns
   // DIFF: the five state variables leave as flux DIFFERENCES of cells (F[c] - F[c+1], what the divergence needs), so the
   // sweep also computes the face that closes its last cell: face fend, or the periodic face n == face 0 (same bits)
-  const int cl = DIFF ? (fend < g.n ? fend : g.n) : fend - 1;          // last face computed (inclusive)
+  const int cl = DIFF ? (fend < g.n ? fend : g.n) : fend - 1;          // last face needed (inclusive)
   const bool periodic = (DIR != 2);
+  // DIFF on a periodic line (swept whole: f0 = 0): the closing face n IS face 0 -- its fluxes are kept from the first trip and
+  // the last cell is closed after the loop, instead of reconstructing the same polynomials a second time (one trip in n + 1)
+  const bool reuse0 = DIFF && periodic && f0 == 0 && cl == g.n;
+  const int cloop = reuse0 ? cl - 1 : cl;                               // last face the loops compute
   const int ncomp = (DIR == 0) ? P_U : (DIR == 1 ? P_V : P_W);         // normal velocity field
 
   auto cell_off = [&](int c) -> long long {
@@ -620,9 +624,9 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
       wn[4] = nn; wm[4] = mul_rn(uni(pr + on)[eu], nn); wp[4] = uni(pp + on)[eu];
     }
-    double Fpn = 0.0;                                      // DIFF: the previous face's normal-momentum flux
+    double Fpn = 0.0, Fn0 = 0.0;                           // DIFF: the previous face's normal-momentum flux; face 0's
 #pragma clang loop unroll(disable)
-    for (int c = f0; c <= cl; c++) {                       // window = cells c-2..c+2; face c lies between cells c-1 and c
+    for (int c = f0; c <= cloop; c++) {                    // window = cells c-2..c+2; face c lies between cells c-1 and c
       const long long on = cell_off(c + 3);                // the next cell entering the window
       const double nn = uni(pn + on)[eu], nm = mul_rn(uni(pr + on)[eu], nn), np_ = uni(pp + on)[eu];
       double Lm, Rm, Lp, Rp, Ln, Rn;
@@ -638,6 +642,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       if (!(DIFF && periodic && c == g.n)) uniw(fl0 + (long long)c * g.cs)[eu] = ruf;
       if (DIFF) {
         if (c > f0) uniw(fln + (long long)(c - 1) * g.cs)[eu] = Fpn - fn;   // cell c-1 is closed by faces c-1 and c
+        else Fn0 = fn;
         Fpn = fn;
       } else {
         uniw(fln + (long long)c * g.cs)[eu] = fn;
@@ -647,6 +652,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
       wm[4] = nm; wp[4] = np_; wn[4] = nn;
     }
+    if (reuse0) uniw(fln + (long long)(g.n - 1) * g.cs)[eu] = Fpn - Fn0;   // the last cell: closed by face n == face 0
   }
   // ---------------- the other advected quantities (Dycore.h:367-385), FLUX_NF fields per sweep ------------------
   // One polynomial is a long dependent chain (differences -> coefficients -> TVs -> weights -> map -> blend); with few
@@ -681,11 +687,11 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         w[n][4] = uni(q[n] + on)[eu];
       }
     }
-    double Fp[NF];
+    double Fp[NF], F0[NF];
 #pragma unroll
-    for (int n = 0; n < NF; n++) Fp[n] = 0.0;
+    for (int n = 0; n < NF; n++) Fp[n] = F0[n] = 0.0;
 #pragma clang loop unroll(disable)
-    for (int c = f0; c <= cl; c++) {
+    for (int c = f0; c <= cloop; c++) {
       const long long on = cell_off(c + 3);
       double nq[NF], L[NF], R[NF];
 #pragma unroll
@@ -700,6 +706,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
         if (n < NS) {
           if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = Fp[n] - F;
+          else F0[n] = F;
           Fp[n] = F;
         } else if (c < fend) {
           uniw(fl[n] + (long long)c * g.cs)[eu] = F;
@@ -709,6 +716,10 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
         w[n][4] = nq[n];
       }
+    }
+    if (reuse0) {
+#pragma unroll
+      for (int n = 0; n < NS; n++) uniw(fl[n] + (long long)(g.n - 1) * g.cs)[eu] = Fp[n] - F0[n];   // closed by face n == face 0
     }
   };
   // dispatch: NF fields per sweep, of which the leading ns are state variables in difference form
