@@ -21,7 +21,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCL
   cp $(find /tmp/pmc_$tag -name '*counter_collection.csv') $OUT/pmc_${tag}.csv
 done
 cd $R
-python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_SQ.csv $OUT/pmc_GRBM_GUI_ACTIVE.csv --traffic-json $HASH > $OUT/pmc_summary.txt
+PMC_SOURCE_CONFIG=c2 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_SQ.csv $OUT/pmc_GRBM_GUI_ACTIVE.csv --traffic-json $HASH > $OUT/pmc_summary.txt
 tail -1 $OUT/pmc_summary.txt > $OUT/traffic.json
 sed -i '$ d' $OUT/pmc_summary.txt
 tail -12 $OUT/pmc_summary.txt
