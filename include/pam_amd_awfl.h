@@ -172,6 +172,8 @@ int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long
  * of the centre cell (Dycore.h:591-604 with ind = 0/1).  level < 0: the constant uniform-grid matrices (x, y sweeps);
  * 0 <= level <= nz+1: this handle's vertical matrices of that index, member 0 (z sweep, Dycore.h:454-469). */
 int pam_amd_awfl_debug_weno(pam_amd_awfl_t *h, int level, const double *stencils, int n, double *left, double *right);
+/* The device's x^y for positive x (pow_pos_fast, awfl_device.h: every pow of the step) on n values (DEVICE arrays). */
+int pam_amd_awfl_debug_pow(pam_amd_awfl_t *h, const double *x, int n, double y, double *out);
 /* ONE tendency stage (stage 1 of a sub-step of length dt_dyn: a forward-Euler step of the resident state, Dycore.h:156-176)
  * with the selected stage structure; afterwards "prim0" holds the new density-divided state. */
 int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn);

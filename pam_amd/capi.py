@@ -66,6 +66,7 @@ SYMBOLS = {
     "pam_amd_awfl_debug_fct_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "pam_amd_awfl_debug_flux_stage": (C.c_int, [C.c_void_p, C.c_double]),
     "pam_amd_awfl_debug_weno": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pam_amd_awfl_debug_pow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "pam_amd_awfl_debug_stage": (C.c_int, [C.c_void_p, C.c_double]),
 }
 

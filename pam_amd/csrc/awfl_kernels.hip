@@ -355,6 +355,7 @@ struct pam_amd_awfl {
   double *prim0 = nullptr, *prim1 = nullptr, *prim2 = nullptr, *flux_x = nullptr, *flux_y = nullptr, *flux_z = nullptr;
   double *seed = nullptr, *mult = nullptr, *dz = nullptr, *grav_var = nullptr, *hy_dens = nullptr, *hy_pres = nullptr;
   double *vz = nullptr, *vert_s2c = nullptr, *vert_wrl = nullptr;
+  PowTab *pow_tab = nullptr;    // tables of pow_pos_fast (device)
   // storage the kernels actually use for the dycore's named arrays: the handle's own buffers until the host model binds
   // DataManager-owned storage (pam_amd_awfl_bind_array; the reference's entries are register_and_allocate'd, Dycore.h:868,897-898,983-984)
   double *act_grav_var = nullptr, *act_hy_dens = nullptr, *act_hy_pres = nullptr, *act_vert_s2c = nullptr, *act_vert_wrl = nullptr;
@@ -736,6 +737,8 @@ void free_all(pam_amd_awfl *h) {
   }
   if (h->dt_bits) (void)hipFree(h->dt_bits);
   h->dt_bits = nullptr;
+  if (h->pow_tab) (void)hipFree(h->pow_tab);
+  h->pow_tab = nullptr;
   if (h->fct_flags) (void)hipFree(h->fct_flags);
   h->fct_flags = nullptr;
 }
@@ -850,6 +853,13 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->vert_s2c, vt.s2c.size() * 8));
   INIT_TRY(hipMalloc(&h->vert_wrl, vt.wrl.size() * 8));
   INIT_TRY(hipMalloc(&h->dt_bits, 8));
+  {
+    PowTab pt;
+    build_pow_tab(pt);
+    INIT_TRY(hipMalloc(&h->pow_tab, sizeof(PowTab)));
+    INIT_TRY(hipMemcpy(h->pow_tab, &pt, sizeof(PowTab), hipMemcpyHostToDevice));
+    P.pw = h->pow_tab;
+  }
   INIT_TRY(hipMemcpy(h->dz, dz_host.data(), nzn * 8, hipMemcpyHostToDevice));
   INIT_TRY(hipMemcpy(h->vz, vt.table.data(), vt.table.size() * 8, hipMemcpyHostToDevice));
   INIT_TRY(hipMemcpy(h->vert_s2c, vt.s2c.data(), vt.s2c.size() * 8, hipMemcpyHostToDevice));
@@ -1282,6 +1292,20 @@ int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **
   else if (k == "seed") { *device_ptr = h->seed; *nelem = h->n_seed; }
   else if (k == "mult") { *device_ptr = h->mult; *nelem = h->n_seed; }
   else return fail(PAM_AMD_EINVAL, "debug_get_buffer: unknown buffer " + k);
+  return PAM_AMD_OK;
+}
+
+__global__ void __launch_bounds__(256) awfl_pow_kat_kernel(Params P, const double *__restrict__ x, int n, double y, double *__restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = pow_pos(P, x[t], y);
+}
+
+int pam_amd_awfl_debug_pow(pam_amd_awfl_t *h, const double *x, int n, double y, double *out) {
+  if (!h || !x || !out || n < 0) return fail(PAM_AMD_EINVAL, "debug_pow: bad argument");
+  USE_DEVICE(h);
+  if (n == 0) return PAM_AMD_OK;
+  hipLaunchKernelGGL(awfl_pow_kat_kernel, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->P, x, n, y, out);
+  HIP_TRY(hipGetLastError());
   return PAM_AMD_OK;
 }
 

@@ -59,6 +59,23 @@ inline void sten_to_coefs_variable_host(int n, const double *locs, double *rslt)
   matinv_ge_host(n, c2s, rslt);
 }
 
+// Tables of pow_pos_fast (awfl_device.h), in 80-bit arithmetic: 1/c_i with 24 bits and -log2 of that stored value in two words (the
+// high one a multiple of 2^-32), 2^(j/64) in two words.
+inline void build_pow_tab(PowTab &T) {
+  for (int i = 0; i < 128; i++) {
+    const long double c = 1.0L + (i + 0.5L) / 128.0L;
+    const double ic = (double)(float)(1.0L / c);
+    const long double l2c = -log2l((long double)ic);
+    const double lh = (double)(floorl(l2c * 4294967296.0L + 0.5L) / 4294967296.0L);
+    T.lg[i].ic = ic; T.lg[i].lh = lh; T.lg[i].ll = (double)(l2c - (long double)lh);
+  }
+  for (int j = 0; j < 64; j++) {
+    const long double v = exp2l(j / 64.0L);
+    const double th = (double)v;
+    T.ex[j].th = th; T.ex[j].tl = (double)(v - (long double)th);
+  }
+}
+
 struct VerticalTables {
   bool per_ens;                 // false: all ensemble members share one dz column
   std::vector<double> table;    // (nz+2,VZ_STRIDE) or (nz+2,VZ_STRIDE,nens)

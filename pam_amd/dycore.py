@@ -257,6 +257,13 @@ class Dycore:
         check(self._lib.pam_amd_awfl_debug_weno(self._h, int(level), st.data_ptr(), st.shape[0], left.data_ptr(), right.data_ptr()))
         return left, right
 
+    def debug_pow(self, x, y):
+        """x: float64 CUDA tensor (> 0) -> x ** y as the kernels compute it (test hook)"""
+        xx = x.contiguous()
+        out = torch.empty_like(xx)
+        check(self._lib.pam_amd_awfl_debug_pow(self._h, xx.data_ptr(), xx.numel(), float(y), out.data_ptr()))
+        return out
+
     def debug_stage(self, dt_dyn):
         check(self._lib.pam_amd_awfl_debug_stage(self._h, float(dt_dyn)))
 

@@ -20,6 +20,7 @@ struct Emu {
   Params P;
   std::vector<double> prim0, prim1, prim2, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
   VerticalTables vt;
+  PowTab pow_tab;
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
   int xtr_split = 0;   // fused stage: tracers 1.. swept in a launch of their own (awfl_xtr_kernel) instead of inline
   int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
@@ -180,10 +181,18 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();
+  build_pow_tab(h->pow_tab);
+  P.pw = &h->pow_tab;
   return h;
 }
 
 void emu_destroy(Emu *h) { delete h; }
+// pow_pos_fast on the host: the same IEEE operations as on the device (tests/test_pow_pos.py)
+void emu_pow(const double *x, int n, double y, double *out) {
+  PowTab T;
+  build_pow_tab(T);
+  for (int i = 0; i < n; i++) out[i] = pow_pos_fast(x[i], y, &T);
+}
 void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
 void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
 void emu_set_span(Emu *h, int span) { h->span = span; }

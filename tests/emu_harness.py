@@ -31,6 +31,7 @@ def load():
         lib.emu_set_grav_balance.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_seg.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_span.argtypes = [C.c_void_p, C.c_int]
+        lib.emu_pow.argtypes = [_DP, C.c_int, C.c_double, _DP]
         lib.emu_set_fused.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_xtr_split.argtypes = [C.c_void_p, C.c_int]
         lib.emu_vz_per_ens.argtypes = [C.c_void_p]
@@ -115,3 +116,11 @@ class EmuDycore:
         out = C.c_double(0)
         n = self.lib.emu_time_step(self.h, *self._f(f), float(crm_dt), float(dt_dyn), C.byref(out))
         return n, out.value
+
+
+def emu_pow(x, y):
+    """pow_pos_fast (pam_amd/csrc/awfl_device.h) evaluated on the host"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    load().emu_pow(_p(x), x.size, float(y), _p(out))
+    return out
