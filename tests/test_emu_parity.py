@@ -1,8 +1,10 @@
 """CPU-only: the HIP kernel BODIES (pam_amd/csrc/awfl_device.h), compiled by g++ into a host emulation harness
 (tests/emu/, test infrastructure), against the oracle.  This covers the host-visible logic -- launch geometry, segment
 handling, periodic wrap, vertical ghosts, FCT multipliers and the periodic-seam quirk, SSPRK3 in-place aliasing, the
-ensemble-uniform / per-member vertical tables -- on a machine without a GPU.  The real device build is tested by
-tests/test_gpu_parity.py (-m gpu)."""
+ensemble-uniform / per-member vertical tables -- on a machine without a GPU.  It checks INDEXING AND STRUCTURE, not the device's
+rounding: the host build divides exactly where the device uses v_rcp_f64 + Newton steps (fast_rcp, weno_rcp in awfl_device.h) and
+contracts nothing; only pow_pos_fast is the same arithmetic on both sides (tests/test_pow_pos.py).  The real device build is tested
+by tests/test_gpu_parity.py and tests/test_kernel_level_parity.py (-m gpu)."""
 import copy
 
 import numpy as np
