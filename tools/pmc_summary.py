@@ -62,10 +62,16 @@ def main():
         # HBM bytes per launch of every stage kernel: FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated on
         # kernels of known byte counts) + WRITE_SIZE; template instances of one kernel are averaged
         import json, re
+
+        def family(k):
+            """template instances of one kernel are one family -- except the two PHASES of the tracer sweeps, which are different
+            kernels in all but name: awfl_xtr_kernel<STAGE, PHASE> -> awfl_xtr_kernel<PHASE> (bench.py's name for them)"""
+            m = re.match(r"(awfl_xtr_kernel)<\s*\d+\s*,\s*(\d+)\s*>", k)
+            return "%s<%s>" % (m.group(1), m.group(2)) if m else re.sub(r"<.*", "", k)
         out = {}
         for k in acc:
             if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
-                base = re.sub(r"<.*", "", k)
+                base = family(k)
                 f, w = acc[k]["FETCH_SIZE"], acc[k]["WRITE_SIZE"]
                 out.setdefault(base, []).append((sum(f) * 1024 * 2, sum(w) * 1024, len(f)))
         res = {}
@@ -79,8 +85,8 @@ def main():
                          "hbm_bytes_per_stage": (fetch + write) / nstage, "fetch_bytes_x2_corrected_per_stage": fetch / nstage,
                          "write_bytes_per_stage": write / nstage}
             # VALU issue: wave-level instructions and busy cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs), all template instances
-            inst = sum(sum(acc[k]["SQ_INSTS_VALU"]) for k in acc if re.sub(r"<.*", "", k) == base and "SQ_INSTS_VALU" in acc[k])
-            busy = sum(sum(acc[k]["GRBM_GUI_ACTIVE"]) for k in acc if re.sub(r"<.*", "", k) == base and "GRBM_GUI_ACTIVE" in acc[k])
+            inst = sum(sum(acc[k]["SQ_INSTS_VALU"]) for k in acc if family(k) == base and "SQ_INSTS_VALU" in acc[k])
+            busy = sum(sum(acc[k]["GRBM_GUI_ACTIVE"]) for k in acc if family(k) == base and "GRBM_GUI_ACTIVE" in acc[k])
             if inst and busy:
                 res[base]["valu_insts_per_stage"] = inst / nstage
                 res[base]["busy_cycles_per_xcd_per_stage"] = busy / 8.0 / nstage
