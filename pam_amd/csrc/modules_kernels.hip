@@ -15,25 +15,44 @@ struct FieldPtrs { double *p[MAX_FIELDS]; };
 
 // horizontal mean of level k = nz-1-kloc for (field, member), accumulated in the reference's serial atomicAdd order
 // (j outer, i inner: sponge_layer.h:73-76) -> deterministic.  wvel (field 3) keeps a zero mean (:34,:75).
+// Strips: the walk of a (field, layer, member) triple over its ny*nx cells is cut into `nstrip` strips of `cpt` consecutive cells,
+// one thread each, when one thread per triple would leave the chip mostly empty (fields*layers*nens threads: 480 wavefronts at
+// nens = 1024, ONE at nens = 1); every strip sums its cells in the reference's serial order (j outer, i inner) and a second, tiny
+// kernel adds the strips in ascending order.  With one strip the sums are the serial reference's bit for bit; with more they differ
+// by re-association only.  part: (triple, nstrip) partial sums, e fastest inside the triple index.
 __global__ void __launch_bounds__(64) sponge_mean_kernel(FieldPtrs F, int nens, int nx, int ny, int nz, int num_fields,
-                                                         int num_layers, double *__restrict__ havg) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)num_fields * num_layers * nens) return;
-  const int e = (int)(t % nens);
-  const int kloc = (int)((t / nens) % num_layers);
-  const int ifld = (int)(t / ((long long)nens * num_layers));
+                                                         int num_layers, double *__restrict__ havg, int cpt, int nstrip,
+                                                         double *__restrict__ part) {
+  const long long tt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ntrip = (long long)num_fields * num_layers * nens;
+  if (tt >= ntrip * nstrip) return;
+  const int e = (int)(tt % nens);
+  const long long r = tt / nens;
+  const int sidx = (int)(r % nstrip);
+  const long long fl = r / nstrip;                       // field * num_layers + layer
+  const int kloc = (int)(fl % num_layers), ifld = (int)(fl / num_layers);
+  const long long t = fl * nens + e;                     // the triple's slot in havg
   const int k = nz - 1 - kloc;
   double s = 0.0;
   if (ifld != 3) {
     const double r_nx_ny = 1.0 / (nx * ny);
     const double *f = F.p[ifld] + (long long)k * ny * nx * nens + e;
-    for (int j = 0; j < ny; j++)
-      for (int i = 0; i < nx; i++) s += f[((long long)j * nx + i) * nens] * r_nx_ny;
+    const int c_end = (sidx + 1) * cpt < ny * nx ? (sidx + 1) * cpt : ny * nx;
+    for (int c = sidx * cpt; c < c_end; c++) s += f[(long long)c * nens] * r_nx_ny;
   }
-  havg[t] = s;
+  if (nstrip > 1) part[(fl * nstrip + sidx) * nens + e] = s;
+  else havg[t] = s;
 }
-
-// sponge_layer.h:87-93
+__global__ void __launch_bounds__(64) sponge_mean_finish_kernel(long long ntrip, int nens, int nstrip, const double *__restrict__ part,
+                                                                double *__restrict__ havg) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntrip) return;
+  const int e = (int)(t % nens);
+  const long long fl = t / nens;
+  double a = 0.0;
+  for (int q = 0; q < nstrip; q++) a += part[(fl * nstrip + q) * nens + e];
+  havg[t] = a;
+}
 __global__ void __launch_bounds__(256) sponge_relax_kernel(FieldPtrs F, int nens, int nx, int ny, int nz, int num_fields,
                                                            int num_layers, const double *__restrict__ havg,
                                                            const double *__restrict__ zint, const double *__restrict__ zmid,
@@ -487,8 +506,21 @@ extern "C" int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fi
   }
   hipStream_t s = (hipStream_t)stream;
   const long long n1 = (long long)num_fields * num_layers * nens;
-  hipLaunchKernelGGL(sponge_mean_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, F, nens, nx, ny, nz, num_fields,
-                     num_layers, workspace);
+  // strips of the horizontal walks: enough threads for ~4 wavefronts per SIMD, never fewer than 8 cells each
+  const long long cells = (long long)ny * nx;
+  long long want = (262144 + n1 - 1) / n1;
+  if (want > cells / 8) want = cells / 8;
+  if (want < 1) want = 1;
+  const int cpt = (int)((cells + want - 1) / want), nstrip = (int)((cells + cpt - 1) / cpt);
+  double *part = nullptr;     // partial sums of the strips: stream-ordered scratch
+  if (nstrip > 1 && hipMallocAsync((void **)&part, (size_t)n1 * nstrip * sizeof(double), s) != hipSuccess)
+    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "sponge_layer: no memory for the partial sums");
+  hipLaunchKernelGGL(sponge_mean_kernel, dim3((unsigned)((n1 * nstrip + 63) / 64)), dim3(64), 0, s, F, nens, nx, ny, nz, num_fields,
+                     num_layers, workspace, cpt, nstrip, part);
+  if (nstrip > 1) {
+    hipLaunchKernelGGL(sponge_mean_finish_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, n1, nens, nstrip, part, workspace);
+    (void)hipFreeAsync(part, s);
+  }
   const long long n2 = n1 * ny * nx;
   hipLaunchKernelGGL(sponge_relax_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, F, nens, nx, ny, nz, num_fields,
                      num_layers, workspace, zint, zmid, crm_dt / time_scale);
