@@ -1026,8 +1026,10 @@ PAMA_D double cfl_body(const Params &P, const double *__restrict__ rho_d_c, cons
 //   sparse_store   (FCT kernel) every wavefront of the launch IS one row (member range aligned to 64) and the caller does not
 //                  need a complete `mult`: an unflagged row's multipliers are not even stored.  Otherwise (ragged ranges, the
 //                  three-kernel stage, the host emulation) they are always stored.
-//   any            one more int: == seq when ANY row of any tracer was flagged in this stage (the fix-up launch of the NT=1
-//                  tail leaves at once when it is not)
+//   any            one int per block of 64 members: == seq when some row of that member block was flagged in this stage (the
+//                  fix-up launch leaves at once where it is not).  PER MEMBER BLOCK, not one word: member ranges of one handle
+//                  advance on their own streams, and a range that is already a stage ahead must not overwrite the answer of a
+//                  range that is about to look (one shared word did exactly that at full C2 size: tools/soak_configs.py)
 //   lines          (nt, nz, ny, ceil(nens/64)) ints, same convention: == seq when some row of the x line (k, j) of that tracer and
 //                  member block was flagged in this stage.  The fix-up pass of the fused stage (tracer_fixup_line_body) is driven by
 //                  them: a wavefront per (tracer, x line, member block) looks at its own line flag and those of the four
@@ -1108,7 +1110,7 @@ PAMA_D void fct_mult_body(const Params &P, const double *__restrict__ fx, const 
       const bool limited = (m != 1.0);
       if (limited) {
         rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
-        *rows.any = rows.seq;
+        rows.any[e >> 6] = rows.seq;
       }
       if (rows.sparse_store) store = wave_any(limited);
     }
@@ -1369,7 +1371,7 @@ PAMA_D void own_multiplier_cell(const Params &P, int t, double *__restrict__ mul
     if (limited) {
       rows.flags[(long long)t * fct_rows_per_tracer(P) + fct_row(P, k, j, i, e)] = rows.seq;
       if (!DENSE && rows.lines) rows.lines[(long long)t * fct_lines_per_tracer(P) + fct_line(P, k, j, e)] = rows.seq;
-      if (!DENSE) *rows.any = rows.seq;       // ("some row of water vapour": the fix-up pass has work)
+      if (!DENSE) rows.any[e >> 6] = rows.seq;  // ("some row of water vapour in this member block": the fix-up pass has work)
     }
     if (DENSE || wave_any(limited)) uniw(mt)[eu] = m_t;
   } else {

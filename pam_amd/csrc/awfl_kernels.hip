@@ -207,11 +207,11 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ fx, const double *__restrict__ fy,
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
-  if (*rows.any != rows.seq) return;
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int line = uni_int(u / nblk), el = (u - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line >= P.nz * P.ny || el >= R.ne) return;
+  if (rows.any[(R.e0 + el) >> 6] != rows.seq) return;     // no row of this member block was flagged in this stage
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
   tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, k, j, R.e0 + el);
 }
@@ -372,7 +372,7 @@ struct pam_amd_awfl {
   size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
   int *fct_flags = nullptr;     // row flags of the FCT multiplier (FctRows in awfl_device.h)
-  size_t n_fct_flags = 0, n_fct_lines = 0;
+  size_t n_fct_flags = 0, n_fct_lines = 0, n_fct_any = 0;
   int fct_seq = 0;              // launch number of the current stage's FCT kernel: the value a flag must hold to count
   size_t n_prim = 0, n_flux_xy = 0, n_flux_z = 0, n_seed = 0;
   bool timing = false;
@@ -544,7 +544,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
 int next_fct_stage(pam_amd_awfl *h) {
   if (h->fct_seq == 0x7fffffff) {   // wrap (once per 2^31 stages): drain everything, forget every flag
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));
+    HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + h->n_fct_any + h->n_fct_lines) * sizeof(int)));
     h->fct_seq = 0;
   }
   h->fct_seq++;
@@ -555,8 +555,8 @@ int next_fct_stage(pam_amd_awfl *h) {
 FctRows fct_rows(const pam_amd_awfl *h, EnsRange r, bool sparse_store) {
   FctRows rows;
   rows.flags = h->fct_flags;
-  rows.any = h->fct_flags + h->n_fct_flags;   // one int behind the rows
-  rows.lines = h->fct_flags + h->n_fct_flags + 1;   // ... and the line flags behind that
+  rows.any = h->fct_flags + h->n_fct_flags;                  // one int per member block behind the rows
+  rows.lines = h->fct_flags + h->n_fct_flags + h->n_fct_any;   // ... and the line flags behind those
   rows.seq = h->fct_seq;
   rows.sparse_store = (sparse_store && r.e0 % 64 == 0 && r.ne % 64 == 0) ? 1 : 0;
   return rows;
@@ -852,8 +852,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->mult, h->n_seed * 8));
   h->n_fct_flags = (size_t)P.nt * (size_t)P.nz * P.ny * P.nx * (size_t)((P.nens + 63) / 64);   // FctRows: (nt, nz, ny, nx, blocks of 64 members)
   h->n_fct_lines = (size_t)P.nt * (size_t)P.nz * P.ny * (size_t)((P.nens + 63) / 64);          // (nt, nz, ny, blocks): line flags
-  INIT_TRY(hipMalloc(&h->fct_flags, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));   // rows, the "any row flagged in this stage" word, lines
-  INIT_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + 1 + h->n_fct_lines) * sizeof(int)));
+  h->n_fct_any = (size_t)((P.nens + 63) / 64);                                                  // "some row of this member block"
+  INIT_TRY(hipMalloc(&h->fct_flags, (h->n_fct_flags + h->n_fct_any + h->n_fct_lines) * sizeof(int)));   // rows, the "any row flagged in this stage" word, lines
+  INIT_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + h->n_fct_any + h->n_fct_lines) * sizeof(int)));
   h->fct_seq = 0;
   INIT_TRY(hipMalloc(&h->dz, nzn * 8));
   INIT_TRY(hipMalloc(&h->grav_var, nzn * 8));
@@ -1322,14 +1323,15 @@ int pam_amd_awfl_debug_pow(pam_amd_awfl_t *h, const double *x, int n, double y, 
 int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long long *rows_total, int *any_flagged) {
   if (!h || !rows_flagged || !rows_total || !any_flagged) return fail(PAM_AMD_EINVAL, "debug_fct_rows: null argument");
   USE_DEVICE(h);
-  std::vector<int> flags(h->n_fct_flags + 1);
+  std::vector<int> flags(h->n_fct_flags + h->n_fct_any);
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(flags.data(), h->fct_flags, flags.size() * sizeof(int), hipMemcpyDeviceToHost));
   long long n = 0;
   for (size_t i = 0; i < h->n_fct_flags; i++) n += (flags[i] == h->fct_seq) ? 1 : 0;
   *rows_flagged = n;
   *rows_total = (long long)h->n_fct_flags;
-  *any_flagged = (flags[h->n_fct_flags] == h->fct_seq) ? 1 : 0;
+  *any_flagged = 0;
+  for (size_t b = 0; b < h->n_fct_any; b++) *any_flagged |= (flags[h->n_fct_flags + b] == h->fct_seq) ? 1 : 0;
   return PAM_AMD_OK;
 }
 

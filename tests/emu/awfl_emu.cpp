@@ -31,7 +31,8 @@ struct Emu {
 static FctRows fct_rows(Emu *h) {   // layout as on the device: rows, the "any" word, line flags
   FctRows r;
   const size_t nrows = (size_t)h->P.nt * fct_rows_per_tracer(h->P);
-  r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + nrows; r.lines = h->fct_flags.data() + nrows + 1;
+  const size_t nany = (size_t)((h->P.nens + 63) >> 6);
+  r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + nrows; r.lines = h->fct_flags.data() + nrows + nany;
   r.seq = h->fct_seq; r.sparse_store = 0;
   return r;
 }
@@ -133,7 +134,9 @@ static void tail_launch(Emu *h, const double *in, const double *p0, double *out,
   const Params &P = h->P;
   for (long long idx = 0; idx < P.ncell; idx++) pressure_tail_body(P, out, cell_of(P, idx));
   const FctRows rows = fct_rows(h);
-  if (*rows.any != rows.seq) return;
+  bool any = false;
+  for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || rows.any[b] == rows.seq;
+  if (!any) return;
   for (int k = 0; k < P.nz; k++)       // tracer 0 only: the others were completed by phase 2 of their sweeps
     for (int j = 0; j < P.ny; j++)
       for (int e = 0; e < P.nens; e++)
@@ -177,7 +180,7 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->fx.assign((size_t)(5 + nt) * P.ncell, nan); h->fy.assign((size_t)(5 + nt) * P.ncell, nan);
   h->fz.assign((size_t)(5 + nt) * P.fz_fs, nan);
   h->seed.assign((size_t)nt * P.ncell, nan); h->mult.assign((size_t)nt * P.ncell, nan);
-  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P) + 1 + (size_t)nt * fct_lines_per_tracer(P), 0);   // rows + "any" word + lines
+  h->fct_flags.assign((size_t)nt * fct_rows_per_tracer(P) + (size_t)((nens + 63) >> 6) + (size_t)nt * fct_lines_per_tracer(P), 0);   // rows + "any" words + lines
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();

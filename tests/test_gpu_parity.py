@@ -363,6 +363,45 @@ def test_full_baseline_size_c2_properties():
         assert torch.equal(results[0][k], results[1][k]), k
 
 
+def test_full_size_c2_vapour_limited_member_ranges_do_not_interfere():
+    """C2 at full size with the limiter active on water vapour in nearly every row (dry slabs at member-dependent places), one
+    member range against two.  Member ranges of one handle advance on their own streams, so one can be a tendency stage ahead of
+    the other: anything they share must not depend on the stage.  (Round 3: the "some row was flagged" word WAS shared -- the range
+    that was ahead overwrote it, the other one's fix-up pass left early, and its vapour came out wrong in ~1e6 cells; only this
+    size opens the window.  tools/soak_configs.py repeats it over 54 sub-steps for C2, C3 and C4.)"""
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz, ngen = 1024, 32, 32, 60, 16
+    zint = idz.l60_interfaces()
+    f = idz.supercell_fields(ngen, nx, ny, nz, zint, magnitude=0.5)
+    idz.carve_dry_air(f, idz.TRACERS_NONE)
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 2.0)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(nx * 1000.0, ny * 1000.0, zint)
+    coupler.add_tracer("water_vapor", "", True, True)
+    dycore = Dycore()
+    dycore.init(coupler)
+    names = ["density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"]
+    init = {k: torch.from_numpy(f[k]).to("cuda:0").repeat(1, 1, 1, nens // ngen).contiguous() for k in names[:5]}
+    init["water_vapor"] = torch.from_numpy(f["tracers"][0]).to("cuda:0").repeat(1, 1, 1, nens // ngen).contiguous()
+    res = []
+    for chunks in (1, 2, 4):
+        for k in names:
+            coupler.dm.get(k).copy_(init[k])
+        dycore.set_ensemble_chunks(chunks)
+        dycore.declare_current_profile_as_hydrostatic(coupler)
+        n = dycore.timeStep(coupler)
+        torch.cuda.synchronize()
+        flagged, total, _ = dycore.debug_fct_rows()
+        assert n >= 3 and flagged > total // 2
+        res.append({k: coupler.dm.get(k, readonly=True).clone() for k in names})
+    for k in names:
+        assert torch.isfinite(res[0][k]).all(), k
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+    dycore.finalize(coupler)
+
+
 @pytest.mark.parametrize("cfg", ["c3_nens4096_kessler_shoc", "c4_shard512_p3_shoc"])
 def test_full_baseline_size_c3_c4_properties(cfg):
     """BASELINE.json configs[2] (nens=4096, 2-D 32x1x60, 4 tracers) and one GPU's shard of configs[3] (512 of 4096 members, 10
