@@ -10,7 +10,10 @@ from pam_amd import Dycore, PamCoupler, idealized as idz
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 CONFIGS = {"c2_limiter": (1024, 32, 32, idz.TRACERS_NONE, idz.CONSTS_DEFAULT, True),
            "c3": (4096, 32, 1, idz.TRACERS_KESSLER_SHOC, idz.CONSTS_DEFAULT, False),
-           "c4": (512, 32, 1, idz.TRACERS_P3_SHOC, idz.CONSTS_P3, False)}
+           "c4": (512, 32, 1, idz.TRACERS_P3_SHOC, idz.CONSTS_P3, False),
+           # 3-D with many tracers (the y faces of the two-phase tracer sweeps) and vapour limited as well
+           "3d_nt4_limiter": (256, 32, 32, idz.TRACERS_KESSLER_SHOC, idz.CONSTS_DEFAULT, True),
+           "3d_nt10_p3": (128, 32, 32, idz.TRACERS_P3_SHOC, idz.CONSTS_P3, False)}
 allok = True
 for name, (nens, nx, ny, tr, consts, dry) in CONFIGS.items():
     nz, zint = 60, idz.l60_interfaces()
