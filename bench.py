@@ -292,8 +292,8 @@ def stage_rooflines(job, alone):
     if fused:
         nyz = nall - 1                     # the flux kernel sweeps y (3-D only) and z: mass + tracers as faces, the rest as differences
         acct["flux"] = (nyz * (6 + nt) * pb + nyz * (5 + nt) * fb, cells * nyz * (6 + nt) * poly)
-        # fused x-sweep: the state and tracer 0 complete (stage input 7 fields, sub-step start 6, y/z flux differences 5 and
-        # tracer-0 faces 1 per direction, FCT seed; writes rho, u, v, w, theta, rho*theta, tracer 0, its seed, its x flux (+ the face
+        # fused x-sweep: the state and water vapour complete (stage input 7 fields, sub-step start 6, y/z flux differences 5 and
+        # vapour faces 1 per direction, FCT seed; writes rho, u, v, w, theta, rho*theta, vapour, its seed, its x flux (+ the face
         # mass flux when further tracers follow))
         state = (7 * pb + (2.0 / 3.0) * 6 * pb + nyz * 6 * fb + fb + 7 * pb + 2 * fb + (fb if nt > 1 else 0), cells * (7 * poly + 6 * 60.0 + 40.0))
         # sweeps of the further tracers.  Phase 1 (FCT multipliers): per tracer the stage input, its y/z faces and seed, per pair

@@ -14,7 +14,13 @@
 //   * update_body        Dycore.h:553-584 (flux divergence + gravity), :162-221 (SSPRK3 combines, clipping,
 //                        next FCT seed), fused with the NEXT stage's Dycore.h:310-321 (pressure, divide by rho)
 //                        and :662-710 (vertical ghost cells).
+//   * flux_x_update_body the fused x-sweep of the default stage: x fluxes + the complete update of the state and of water vapour
+//                        (Dycore.h:334-386, :553-584, :162-221, :525-550); x_tracer_sweep: the further tracers, swept twice
+//                        (FCT multipliers, then the complete update); tracer_fixup_line_body, pressure_tail_body: the tail.
+//   * pow_pos_fast       every x^y of the step (positive bases): Dycore.h:310-321, :682-709, :1313-1387.
 //   * init_prim_body     Dycore.h:1370-1387 (coupler -> dycore state), :130-134 (clip), fused with :310-321,:662-710.
+//   * coupler_to_halo_arrays_body / halo_arrays_to_coupler_body   the two converts with the reference's argument lists
+//                        (Dycore.h:1336-1388, :1281-1331).
 //   * finalize_body      Dycore.h:1313-1330 (dycore state -> coupler).
 //   * cfl_body           Dycore.h:86-101.
 //   * pint_body / hydro_mean_body   Dycore.h:1450-1501 (declare_current_profile_as_hydrostatic).
@@ -1561,23 +1567,23 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
 // registers.  Here a wavefront owns a whole periodic x line (k, j) of 64 members: when faces c-1 and c of a variable are
 // known, cell c-1 is complete -- its x flux difference never leaves the registers, its stage-input value is the window
 // element the polynomial was built from, and only the y/z flux differences and the sub-step-start value are loaded.  The
-// x fluxes of the state are never stored (except the mass flux, the thread's own scratch for the later passes); tracer x
-// fluxes still are (the FCT limiter needs all six faces of a cell before any tracer update: fct_mult_body, then
-// tracer_update_body).
+// x fluxes of the state are never stored (except the mass flux, for the tracer sweeps), nor are those of the further tracers
+// (x_tracer_sweep forms them twice); only water vapour's is kept, for the fix-up pass (tracer_fixup_line_body).
 //
 // Passes over the line (5-cell sliding windows, one polynomial per cell, as flux_line_body):
-//   state    rho*u, p, u, v, w, theta together (six independent polynomial chains per cell): face mass flux ruf and face
-//            pressure, the x fluxes of all five state variables, and the complete update of every cell: new density, u, v, w,
-//            theta density-divided to prim_out (+ vertical ghosts when k is a boundary level); the new rho*theta goes to
-//            prim_out[P_PRES] for the pointwise kernel that follows (tracer_update_body: next stage's pressure and
-//            density/pressure ghosts).  ruf is also written to flux_x field 0 for the tracer sweeps (the lane's own line,
-//            L2-resident; no LDS, so residency is bounded by registers only).  Each input is read exactly once.
-//   tracers  FLUX_NF at a time, upwinded by the ruf read back: only their x flux is stored.
+//   state    rho*u, p, u, v, w, theta and water vapour together (seven independent polynomial chains per cell): face mass flux
+//            ruf and face pressure, the x fluxes of all five state variables, and the complete update of every cell: new density,
+//            u, v, w, theta density-divided to prim_out (+ vertical ghosts when k is a boundary level); the new rho*theta goes to
+//            prim_out[P_PRES] for the pressure pass that follows (pressure_tail_body: next stage's pressure and density/pressure
+//            ghosts); water vapour finished as well (own FCT multiplier, the update an unlimited neighbourhood gets).  ruf is
+//            also written to flux_x field 0 for the tracer sweeps (the lane's own line, L2-resident; no LDS, so residency is
+//            bounded by registers only).  Each input is read exactly once.
+//   tracers  phase 1 of the further tracers' sweeps (x_tracer_sweep), FLUX_NF at a time, upwinded by the ruf read back.
 // prim_in, prim0 and prim_out must be three different buffers: the line is periodic (cells 0..2 are read again at the
 // end of the sweep) and later passes re-read the stage-input density, so nothing may be updated in place.
 // Bit-for-bit the arithmetic of flux_line_body<0> + update_body (shared helpers above; tests/test_fused_stage.py).
 //   line   wave-uniform index of the x line: k * ny + j          e   ensemble member of this lane
-//   tracers_inline   sweep tracers 1.. here (else the caller launches awfl_xtr_kernel)
+//   tracers_inline   phase 1 of the further tracers here (else the caller launches awfl_xtr_kernel<., 1>)
 template <int STAGE>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
@@ -1707,7 +1713,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
         const double m_0 = (STAGE > 1) ? mul_rn(ci.q0[n], ci.rho_0) : 0.0;
         const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
         store_adv_u(P, prim_out, P_U + n, k, cu0 + (long long)cc * P.sx, eu, v * rrho, (l == 3) ? 0.0 : v * rrho);
-        // the new rho*theta goes where the pressure belongs: tracer_update_body turns it into the next stage's pressure
+        // the new rho*theta goes where the pressure belongs: pressure_tail_body turns it into the next stage's pressure
         // (a pow per cell, kept out of this register-critical loop)
         if (l == 4) uniw(out_rt + o)[eu] = v;
       }
@@ -1746,7 +1752,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       const double Ft = mul_rn(ruf, up ? prevR_t : Lt);      // x flux of water vapour (Dycore.h:367-385)
       if (c < c1) {                                          // the faces this span owns
         if (more_tracers) uniw(ruf_line + (long long)c * P.sx)[eu] = ruf;   // for the tracer sweeps
-        uniw(flt + (long long)c * P.sx)[eu] = Ft;            // (read again where the limiter acts: tracer_update_part)
+        uniw(flt + (long long)c * P.sx)[eu] = Ft;            // (read again where the limiter acts: tracer_fixup_line_body)
       }
       ruf_close = ruf;                                       // (after the last trip: face c1)
       F[0] = ruf;

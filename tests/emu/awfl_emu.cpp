@@ -75,7 +75,7 @@ static void fct_launch(Emu *h, double dt) {
   for (long long idx = 0; idx < P.ncell; idx++)
     fct_mult_body(P, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fct_rows(h), dt, cell_of(P, idx), 0);
 }
-// What the device does in the fused stage: tracer 0's multipliers of a row no member of which was limited are not stored by the
+// What the device does in the fused stage: water vapour's multipliers of a row no member of which was limited are not stored by the
 // state pass.  Emulated by poisoning them after the sweeps: a fix-up that loads one of them anyway produces NaN.
 static void poison_unflagged_mult(Emu *h) {
   const Params &P = h->P;
@@ -137,7 +137,7 @@ static void tail_launch(Emu *h, const double *in, const double *p0, double *out,
   bool any = false;
   for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || rows.any[b] == rows.seq;
   if (!any) return;
-  for (int k = 0; k < P.nz; k++)       // tracer 0 only: the others were completed by phase 2 of their sweeps
+  for (int k = 0; k < P.nz; k++)       // water vapour only: the others were completed by phase 2 of their sweeps
     for (int j = 0; j < P.ny; j++)
       for (int e = 0; e < P.nens; e++)
         tracer_fixup_line_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), rows, h->seed.data(), dt, P.idWV, k, j, e);

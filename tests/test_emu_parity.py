@@ -26,7 +26,7 @@ CASES = {
     "3d_nt4_stretched_B": (2, 6, 6, 8, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(8, 12000.0), {}, False, 8),
     "3d_nt10_perens_A_p3": (3, 6, 4, 8, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(8, 12000.0),
                             dict(per_ens=True, consts=idz.CONSTS_P3), True, 5),
-    # one tracer (water_vapor) limited in every stage: the NT=1 tail's fix-up branch (tracer_update_body with do_tracers only),
+    # one tracer (water_vapor) limited in every stage: the fix-up pass (tracer_fixup_line_body),
     # mode A and mode B; and mode B with one smooth tracer
     "3d_nt1_vapour_limited_A": (6, 8, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), dict(dry_air=True), True, 8),
     "3d_nt1_vapour_limited_B": (5, 6, 4, 8, idz.TRACERS_NONE, idz.stretched_interfaces(8, 12000.0), dict(dry_air=True), False, 3),

@@ -113,7 +113,7 @@ def _assert_limiter_ran(dycore, fused, nt, shape):
     flags); with the three-kernel stage the complete multiplier field is there to look at as well"""
     flagged, total, any_word = dycore.debug_fct_rows()
     assert flagged > 0, (flagged, total, any_word)
-    if nt == 1:         # the word the fix-up pass of tracer 0 looks at (fused stage: set by tracer 0 only)
+    if nt == 1:         # the words the fix-up pass of water vapour looks at (fused stage: set by vapour only)
         assert any_word
     assert flagged < total, "rows without any limited member must exist too (they are the ones that are skipped)"
     if not fused:
