@@ -6,7 +6,8 @@ bit-identical to the oracle by construction (FMA contraction, v_rcp_f64+Newton r
 bridge matrices and weight normalisation, device pow), each a ~1e-16 relative perturbation per operation; the
 oracle's own response to 1-ulp input noise over the same steps is ~2e-15 (rho, T), ~3e-14 (u), ~1e-12 (w) and up to
 ~2e-11 (v, which is ~1e-1 m/s noise in these cases) -- see DESIGN.md "Parity budget".  So:
-   density_dry, temp, water_vapor:  max|a-b| <= 1e-12 * max|b|          (the north_star gate)
+   density_dry, temp, water_vapor:  max|a-b| <= 1e-12 * max|b|          (the north_star gate); density_dry and temp also
+                                    ELEMENT-WISE: |a-b| <= 1e-12 |b| in every cell
    uvel, wvel, vvel, other tracers: max|a-b| <= 1e-9  * max|b|          (small, noise-dominated fields)
 """
 import copy
@@ -69,6 +70,11 @@ def _compare(got, exp, names):
     for k, e in worst.items():
         tol = TOL_TIGHT if k in ("density_dry", "temp", "water_vapor") else TOL_LOOSE
         assert e <= tol, (k, e, worst)
+    # rho_d and T are bounded away from zero: for them "rtol 1e-12" is asserted ELEMENT-WISE as well
+    for k in ("density_dry", "temp"):
+        el = np.abs((got[k] - exp[k]) / exp[k]).max()
+        assert el <= TOL_TIGHT, (k, "element-wise", el)
+        worst[k + "_elementwise"] = el
     return worst
 
 
