@@ -196,6 +196,16 @@ PAMA_D WenoConsts weno_consts() {
     w.c2[i] = w.idl[i] * w.idl[i];
     w.idl3x[i] = 3.0 * w.idl[i];
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The addends of map_weights' multiply-adds for weights 1 and 3 (weights 0 and 2 share theirs: idl0 == idl2) do not fit the scalar
+  // file beside the other literals of a sweep, and the compiler keeps them in vector registers.  As KNOWN constants it rebuilds each
+  // one in the destination of its v_fmac (a v_mov_b64 per use: 6 of ~135 vector instructions per polynomial); as opaque values
+  // it reads them as the third operand of a v_fma.  Same arithmetic, same bits.
+  asm("" : "+v"(w.idl3x[1]), "+v"(w.c0[1]), "+v"(w.c2[1]), "+v"(w.idl3x[3]), "+v"(w.c0[3]), "+v"(w.c2[3]));
+  // c2 of weights 0 and 2 meets a second constant in its multiply-add (c1 w + c2: one scalar operand per instruction): same cure
+  asm("" : "+v"(w.c2[0]));
+  if (raw[0] == raw[2]) w.c2[2] = w.c2[0];
+#endif
   return w;
 }
 
@@ -764,31 +774,40 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     double Fp[NF], F0[NF];
 #pragma unroll
     for (int n = 0; n < NF; n++) Fp[n] = F0[n] = 0.0;
+    // The window does not move: trip r of five uses the slots (r, r+1, .. r+4) mod 5 and overwrites slot r -- the oldest cell --
+    // with the cell that enters; after five trips the naming is back where it started.  (Shifting the window costs 4 v_mov_b64
+    // per field and trip, 6 % of the vector instructions of a sweep.)
 #pragma clang loop unroll(disable)
-    for (int c = f0; c <= cloop; c++) {
-      const long long on = cell_off(c + 3);
-      double nq[NF], L[NF], R[NF];
+    for (int c = f0; c <= cloop;) {
 #pragma unroll
-      for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
-      // this lane's own store of pass 1 (the periodic face n is face 0)
-      const double ruf = uni(fl0 + (long long)((DIFF && periodic && c == g.n) ? 0 : c) * g.cs)[eu];
+      for (int r = 0; r < 5; r++) {
+        if (c > cloop) break;
+        const long long on = cell_off(c + 3);
+        double nq[NF], L[NF], R[NF];
 #pragma unroll
-      for (int n = 0; n < NF; n++) weno(w[n], c, L[n], R[n]);
-      const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
+        for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
+        // this lane's own store of pass 1 (the periodic face n is face 0)
+        const double ruf = uni(fl0 + (long long)((DIFF && periodic && c == g.n) ? 0 : c) * g.cs)[eu];
 #pragma unroll
-      for (int n = 0; n < NF; n++) {
-        const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
-        if (n < NS) {
-          if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = Fp[n] - F;
-          else F0[n] = F;
-          Fp[n] = F;
-        } else if (c < fend) {
-          uniw(fl[n] + (long long)c * g.cs)[eu] = F;
+        for (int n = 0; n < NF; n++) {
+          const double u[5] = {w[n][r % 5], w[n][(r + 1) % 5], w[n][(r + 2) % 5], w[n][(r + 3) % 5], w[n][(r + 4) % 5]};
+          weno(u, c, L[n], R[n]);
         }
-        prevR[n] = R[n];
+        const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)
 #pragma unroll
-        for (int s = 0; s < 4; s++) w[n][s] = w[n][s + 1];
-        w[n][4] = nq[n];
+        for (int n = 0; n < NF; n++) {
+          const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
+          if (n < NS) {
+            if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = Fp[n] - F;
+            else F0[n] = F;
+            Fp[n] = F;
+          } else if (c < fend) {
+            uniw(fl[n] + (long long)c * g.cs)[eu] = F;
+          }
+          prevR[n] = R[n];
+          w[n][r % 5] = nq[n];
+        }
+        c++;
       }
     }
     if (reuse0) {
