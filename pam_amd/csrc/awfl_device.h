@@ -172,8 +172,11 @@ PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
   const int j = k & 63, n = k >> 6;                         // k = 64 n + j, 0 <= j < 64 (arithmetic shift)
   const double t2h = T->ex[j].th, t2l = T->ex[j].tl;
   const double res = ldexp(fma(t2h, p, t2l) + t2h, n);
-  // a base that is not positive only occurs in a state that has already blown up: keep the C library's answers (0 -> 0, else NaN)
-  return (x > 0.0) ? res : ((x == 0.0) ? 0.0 : NAN);
+  // a base that is not positive and finite only occurs in a state that has already blown up: keep the C library's answers
+  // (0 -> 0 and +inf -> +inf for y > 0, the other way round for y < 0; negative or NaN -> NaN)
+  if (!(x > 0.0)) return (x == 0.0) ? (y > 0.0 ? 0.0 : INFINITY) : NAN;
+  if (!(x < INFINITY)) return y > 0.0 ? INFINITY : 0.0;
+  return res;
 }
 
 PAMA_D double pow_pos(const Params &P, double x, double y) { return pow_pos_fast(x, y, P.pw); }

@@ -8,11 +8,13 @@
 // ~18 launches and ~13 allocations there):
 //     fused stage (default), per stage:
 //                 awfl_flux_kernel<.,DIFF>  y and z sweeps in ONE launch (Dycore.h:387-519)
-//                 awfl_xupd_kernel          x sweep + update of the state and of EVERY tracer (own FCT multiplier + the update an
+//                 awfl_xupd_kernel          x sweep + update of the state and of water vapour (its own FCT multiplier + the update an
 //                                           unlimited neighbourhood gets; Dycore.h:334-386,525-584,162-221, next stage's :310-321 divide,
-//                                           :662-710 ghosts) [+ awfl_xtr_kernel: the further tracers' sweeps for small ensembles]
+//                                           :662-710 ghosts); for large ensembles also phase 1 of the further tracers' x sweeps
+//                 awfl_xtr_kernel<.,1>      (small ensembles) phase 1 of the further tracers: x fluxes -> their FCT multipliers
+//                 awfl_xtr_kernel<.,2>      phase 2: the same x fluxes again + the complete limited update (NT > 1 only)
 //                 awfl_ptail_kernel         next stage's pressure + density/pressure ghosts (Dycore.h:310-321,:682-709)
-//                 awfl_trfix_kernel         tracers redone where the limiter acted (driven by line flags; leaves at once elsewhere)
+//                 awfl_trfix_kernel         water vapour redone where its limiter acted (driven by line flags; leaves at once elsewhere)
 //     three-kernel stage (cross-check, every face flux and multiplier stored):
 //                 awfl_flux_kernel (x, y, z) -> awfl_fct_kernel (Dycore.h:525-550) -> awfl_update_kernel
 // All scratch is allocated once in init.
@@ -1275,7 +1277,6 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
   USE_DEVICE(h);
   h->chunks_requested = chunks;
   h->flux_lds_floor = (size_t)flux_lds_floor_bytes;
-  if (const char *e = getenv("PAMA_NO_PRIO")) h->use_priorities = (atoi(e) == 0);   // experiment switch
   return build_chunks(h);
 }
 

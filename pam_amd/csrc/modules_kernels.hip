@@ -559,7 +559,7 @@ extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, c
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
-  hipMemsetAsync(slot, 0x7f, 8, s);
+  if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
   hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
                      (double *)nullptr, (double *)nullptr, const_cast<double *>(rho_r), rho_dry, (double *)nullptr,
                      (double *)nullptr, zmid, dt, 1., 1., 1., 1., (double *)nullptr, slot);
@@ -581,7 +581,7 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     // read-back.  It is taken with the NON-writing form of the prep kernel, so that a failure here (a NaN state, an absurd
     // sub-cycle count, a HIP error) leaves the coupler arrays untouched -- the writing form below converts rho_x -> q and
     // T -> theta in place and cannot be undone from an error path.
-    hipMemsetAsync(slot, 0x7f, 8, s);
+    if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
     hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
                        rho_v, rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
     double dt_max;
@@ -670,7 +670,7 @@ extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, doubl
   const long long n2 = (long long)nz * nens, per_level = (long long)ny * nx * nens, ncell = per_level * nz;
   double *glob = workspace + 6 * n2;
   int *flags = (int *)(glob + 2 * (long long)nens);
-  hipMemsetAsync(flags, 0, 8 * sizeof(int), s);
+  if (hipMemsetAsync(flags, 0, 8 * sizeof(int), s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
   const GcmStrips S = gcm_strips(nens, nx, ny, nz);
   double *part = nullptr;
   if (S.nstrip > 1 && hipMallocAsync((void **)&part, (size_t)9 * n2 * S.nstrip * sizeof(double), s) != hipSuccess)

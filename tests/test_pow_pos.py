@@ -32,8 +32,11 @@ def test_pow_pos_fast_is_within_0p55_ulp_of_powl():
 
 def test_pow_pos_fast_edge_values():
     y = 1003.0 / 716.0
-    x = np.array([1.0, 2.0, 0.5, 1.0 - 2.0 ** -53, 1.0 + 2.0 ** -52, 4.0, 1e-300, 1e300, 0.0, -1.0, np.nan])
+    x = np.array([1.0, 2.0, 0.5, 1.0 - 2.0 ** -53, 1.0 + 2.0 ** -52, 4.0, 1e-300, 1e300, 0.0, -1.0, np.nan, np.inf, 5e-324])
     got = eh.emu_pow(x, y)
+    assert np.isinf(got[11]) and got[11] > 0 and got[12] == 0.0    # +inf stays +inf; the smallest subnormal underflows to 0
+    neg = eh.emu_pow(np.array([0.0, np.inf, 4.0]), -0.5)
+    assert np.isinf(neg[0]) and neg[1] == 0.0 and abs(neg[2] - 0.5) <= 1e-16
     with np.errstate(invalid="ignore", over="ignore"):
         exp = np.power(x, y)
     assert got[0] == 1.0 and got[8] == 0.0 and np.isnan(got[9]) and np.isnan(got[10])
