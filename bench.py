@@ -56,10 +56,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (spec; 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 
 CONFIGS = {
-    # name: (nens per GPU, nx, ny, tracer set, constants, crm_dt, description)
+    # name: (nens per GPU, nx, ny, tracer set, constants, crm_dt, description[, nz, vertical grid, xlen])
     "c2": (1024, 32, 32, "none", "default", 2.0, "AWFL supercell idealized, nens=%d/GPU, 32x32x60 L60, NT=1, fp64"),
     "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
     "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
+    # the shape of the reference's own input file (standalone/mmf_simplified/inputs/input_pama.yaml: crm_nx 250, crm_ny 1,
+    # nens 1, 50 equal levels to 20 km, xlen 128 km) with the Kessler + SHOC tracer registrations
+    "ref": (1, 250, 1, "kessler_shoc", "default", 2.0, "reference input shape (input_pama.yaml), nens=%d/GPU, 2-D 250x1x50 uniform 20 km, NT=4, fp64",
+            50, "uniform20km", 128000.0),
 }
 STAGE_KERNELS = ("flux", "xupd", "xtr1", "xtr2", "ptail", "trfix", "fct_mult", "update")
 
@@ -157,7 +161,8 @@ class Job:
         import torch
         from pam_amd import Dycore, PamCoupler, idealized as idz, parallel
         self.torch, self.parallel, self.idz = torch, parallel, idz
-        nens_pg, nx, ny, trname, cname, crm_dt, desc = CONFIGS[cfg_name]
+        nens_pg, nx, ny, trname, cname, crm_dt, desc = CONFIGS[cfg_name][:7]
+        nz_cfg, grid_cfg, xlen_cfg = CONFIGS[cfg_name][7:] or (60, "l60", None)
         if nens_override > 0:
             nens_pg = nens_override
         self.nens_total = nens_pg * world
@@ -168,12 +173,12 @@ class Job:
             if nens_pg < 1:
                 raise SystemExit("bench.py: --scaling strong leaves rank %d without members" % rank)
         self.cfg_name, self.desc, self.crm_dt = cfg_name, desc, crm_dt
-        self.nens, self.nx, self.ny, self.nz = nens_pg, nx, ny, 60
+        self.nens, self.nx, self.ny, self.nz = nens_pg, nx, ny, nz_cfg
         self.tracers = {"none": idz.TRACERS_NONE, "kessler_shoc": idz.TRACERS_KESSLER_SHOC, "p3_shoc": idz.TRACERS_P3_SHOC}[trname]
         self.consts = {"default": idz.CONSTS_DEFAULT, "p3": idz.CONSTS_P3}[cname]
         self.nt = len(self.tracers)
-        self.zint = idz.l60_interfaces()
-        self.xlen = nx * 1000.0
+        self.zint = idz.l60_interfaces() if grid_cfg == "l60" else idz.uniform_interfaces(nz_cfg, 20000.0)
+        self.xlen = xlen_cfg if xlen_cfg else nx * 1000.0
         self.ylen = ny * 1000.0 if ny > 1 else self.xlen
         self.world = world
         # ---- coupler + dycore, inputs resident in HBM before anything is timed
@@ -193,6 +198,11 @@ class Job:
             dycore.set_flux_span(args.span)
         if args.fused >= 0:
             dycore.set_fused_stage(args.fused)
+        if args.lanes != "auto" or args.xkernels != "auto":
+            dycore.set_lane_mapping(args.lanes, args.xkernels)
+        if args.xtile:
+            dycore.set_x_tile(*[int(v) for v in args.xtile.split(",")])
+        self.lane_mapping = dycore.get_lane_mapping()
         self.chunks = args.chunks
         self.lds_floor = args.lds_floor
         if args.chunks >= 0:
@@ -504,6 +514,7 @@ def worker(args):
             cpu = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
     desc, nens_pg, nens_total = job.desc % job.nens, job.nens, job.nens_total
+    lane_mapping = job.lane_mapping
     ny, nx, nz, crm_dt = job.ny, job.nx, job.nz, job.crm_dt
     job.close()
     del job
@@ -539,7 +550,7 @@ def worker(args):
                           "limiter_input": args.limiter, "fct_rows_flagged_last_stage": fct_rows[0], "fct_rows": fct_rows[1],
                           "collective": None if world == 1 else "all-reduce(MIN) of dt, 8 B per timeStep, backend %s%s" % (
                               backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev)),
-                          "ranks_seen": ranks_seen, "device": str(dev)},
+                          "ranks_seen": ranks_seen, "device": str(dev), "lane_mapping": lane_mapping},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
                "other_configs": others}
         print(json.dumps(out))
@@ -566,6 +577,11 @@ def main():
                          "water_vapor itself in every stage along the slab edges (with one tracer: times the flagged path of the NT=1 "
                          "tail); 2: slabs at member-dependent places (nearly every row of 64 members flagged: worst case of the "
                          "sparse multiplier); default 0: smooth vapour")
+    ap.add_argument("--lanes", default="auto", choices=("auto", "member", "flat"),
+                    help="lanes of the y/z sweeps: 64 members of one line / 64 items of the flattened (x, member) axis (auto: flat when nens < 64)")
+    ap.add_argument("--xkernels", default="auto", choices=("auto", "sweep", "tile"),
+                    help="x direction: a wavefront per line span / a lane per cell with LDS exchange (auto: tile when nens < 64)")
+    ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")

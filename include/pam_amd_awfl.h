@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PAM_AMD_AWFL_ABI_VERSION 2
+#define PAM_AMD_AWFL_ABI_VERSION 3
 
 #define PAM_AMD_OK 0
 #define PAM_AMD_EINVAL (-1)   /* bad argument / inconsistent dimensions (reference: endrun) */
@@ -159,6 +159,24 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
  * limiter acted, next stage's pressure); the state's x fluxes never reach HBM.  0: flux(x,y,z) ->
  * FCT multiplier -> update, every face flux and multiplier stored.  Both produce the same bits (tests/test_fused_stage.py). */
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
+
+/* Lane mapping of the fused stage; results do not depend on it (bit for bit, tests/test_lane_mapping.py).
+ * The coupler stores every field with nens fastest and x next (pam_core/pam_coupler.h:259-263).  Large ensembles run with MEMBER
+ * lanes: a wavefront is 64 consecutive members of one grid line and sweeps the line serially (stencil in the lane's registers).
+ * Every input file the reference ships has nens = 1 (standalone/mmf_simplified/inputs/input_pama.yaml:14): there a member-lane
+ * wavefront is one lane.  Small ensembles therefore run with lanes over the flattened (x, member) axis:
+ *   yz_lanes   1: member lanes; 2: FLAT lanes -- a wavefront of a y / z sweep takes 64 consecutive (x, member) pairs (and rows of
+ *              them), the stencil stays in the lane;
+ *   x_kernels  1: sweep kernels (a wavefront per span of an x line); 2: TILE kernels -- a lane per cell, one polynomial set per
+ *              lane, right-edge values and face fluxes handed to the neighbouring lanes (distance nens) through LDS;
+ *   0 = automatic for either: flat / tile when nens < 64.
+ * set_x_tile tunes the tile geometry (0 = automatic): lanes per row (members of one cell that sit in one row), cells a tile
+ * completes (a tile shorter than the line gets one halo row on each side), lines per workgroup (whole-line tiles only). */
+int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels);
+int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group);
+/* the resolved mapping: flat y/z lanes, x tile kernels, pointwise kernels on a grid flat over every cell (0/1 each) and the tile
+ * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */
+int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]);
 
 /* --- test hooks: read-only views of resident device buffers, and a single tendency stage ------------------------- */
 /* name: "prim0","prim1","prim2","flux_x","flux_y","flux_z","seed","mult". */

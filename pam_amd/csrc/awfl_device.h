@@ -68,6 +68,7 @@ struct Params {
   int grav_balance;   // option balance_hydrostasis_with_gravity (Dycore.h:284)
   int vz_per_ens;     // 0: vertical matrices identical for every ensemble member (wave-uniform table)
   int seg;            // shortest span a sweep line may be cut into when the ensemble alone does not fill the chip
+  int flat_cells;     // pointwise kernels: the launch grid is flat over every cell (small ensembles: nx*nens does not fill a workgroup)
   double dx, dy, rdx, rdy;
   double C0, gamma, grav, R_d, R_v;
   long long sx, sy, sz;   // cell strides in doubles: nens, nx*nens, ny*nx*nens
@@ -637,26 +638,65 @@ PAMA_HD int flux_sweep_pairs(const Params &P, bool diff) { return (3 + P.nt - (s
 //            face form.  Periodic lines must then be swept whole (f0 = 0, span >= n).
 // Reference: Dycore.h:334-519.  `prim` holds rho, p, and the density-divided u,v,w,theta,tracers (Dycore.h:310-321)
 // with vertical ghosts already filled (Dycore.h:662-710).
+// Where a lane of a sweep works: the wave-uniform offsets of the line's cell 0 inside a prim field (pbase) and of its face 0 inside a
+// flux field (fbase), the lane's own element offset on top of both (eu, < 2^28: scalar base + 32-bit lane offset addressing) and the
+// ensemble member whose per-member tables it reads (et).
+//   member lanes (member_lane): the 64 lanes are 64 consecutive MEMBERS of ONE line; eu = member.  Full lanes when nens is a
+//                multiple of 64 -- the layout every large ensemble runs with.
+//   flat lanes   (flat_lane, the y and z sweeps of small ensembles): nens is the fastest axis and x the next, so for a sweep along y
+//                or z the (x, member) pairs of a row -- and, row after row, everything that is not the sweep direction -- form ONE
+//                flat index space whose 64 consecutive items sit in consecutive lanes: the stencil stays in the lane (its neighbours
+//                are sy / sz doubles away in memory), accesses stay coalesced along the fastest (x, nens) axes, and a wavefront is
+//                full whenever nx*nens (times the rows that are packed with it) reaches 64, whatever nens is.
+struct LineLane { long long pbase, fbase; unsigned eu; int et; };
+template <int DIR>
+PAMA_D LineLane member_lane(const Params &P, int line, int e) {
+  LineLane ll;
+  ll.eu = member_offset(e);
+  ll.et = e;
+  if (DIR == 0) {  // line = k*ny + j
+    const int k = uni_int(line / P.ny), j = line - k * P.ny;
+    ll.pbase = (long long)(k + HS) * P.sz + (long long)j * P.sy;
+    ll.fbase = (long long)k * P.sz + (long long)j * P.sy;
+  } else if (DIR == 1) {  // line = k*nx + i
+    const int k = uni_int(line / P.nx), i = line - k * P.nx;
+    ll.pbase = (long long)(k + HS) * P.sz + (long long)i * P.sx;
+    ll.fbase = (long long)k * P.sz + (long long)i * P.sx;
+  } else {  // line = j*nx + i ; cell c lives at kz = c + HS
+    ll.pbase = (long long)HS * P.sz + (long long)line * P.sx;
+    ll.fbase = (long long)line * P.sx;
+  }
+  return ll;
+}
+// item q of the flat index space of a y sweep ((level, x, member): nz * nx*nens items) or a z sweep ((y, x, member): ny * nx*nens)
+PAMA_HD long long flat_items(const Params &P, int dir) { return (long long)(dir == 1 ? P.nz : P.ny) * P.nx * P.nens; }
+template <int DIR>
+PAMA_D LineLane flat_lane(const Params &P, unsigned q) {
+  static_assert(DIR == 1 || DIR == 2, "flat lanes: y and z sweeps (the x direction has its own tile kernels)");
+  LineLane ll;
+  ll.pbase = (long long)HS * P.sz;
+  ll.fbase = 0;
+  const unsigned row = (unsigned)P.nx * (unsigned)P.nens;                // (x, member) pairs of a row: contiguous in memory
+  if (DIR == 1) {
+    const unsigned k = q / row, r = q - k * row;
+    ll.eu = member_offset((int)(k * (unsigned)P.sz + r));
+    ll.et = (int)(r % (unsigned)P.nens);
+  } else {
+    ll.eu = member_offset((int)q);                                        // (y, x, member) is contiguous as it stands
+    ll.et = (int)(q % (unsigned)P.nens);
+  }
+  return ll;
+}
+
 template <int DIR, bool VZ_PER_ENS, bool DIFF>
-PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
+PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
                            int f0, int span, int pair_sel = -1) {
-  const unsigned eu = member_offset(e);
+  const unsigned eu = ll.eu;
+  const int e = ll.et;
   const LineGeom g = line_geom(P, DIR);
   const WenoConsts wc = weno_consts();
   // base offset of the line's cell 0 inside a prim field, and of its face 0 inside a flux field (wave-uniform)
-  long long pbase, fbase;
-  if (DIR == 0) {  // line = k*ny + j
-    const int k = uni_int(line / P.ny), j = line - k * P.ny;
-    pbase = (long long)(k + HS) * P.sz + (long long)j * P.sy;
-    fbase = (long long)k * P.sz + (long long)j * P.sy;
-  } else if (DIR == 1) {  // line = k*nx + i
-    const int k = uni_int(line / P.nx), i = line - k * P.nx;
-    pbase = (long long)(k + HS) * P.sz + (long long)i * P.sx;
-    fbase = (long long)k * P.sz + (long long)i * P.sx;
-  } else {  // line = j*nx + i ; cell c lives at kz = c + HS
-    pbase = (long long)HS * P.sz + (long long)line * P.sx;
-    fbase = (long long)line * P.sx;
-  }
+  const long long pbase = ll.pbase, fbase = ll.fbase;
   const int fend = (f0 + span < g.nfaces) ? f0 + span : g.nfaces;     // exclusive: the faces this span owns
   // DIFF: the five state variables leave as flux DIFFERENCES of cells (F[c] - F[c+1], what the divergence needs), so the
   // sweep also computes the face that closes its last cell: face fend, or the periodic face n == face 0 (same bits)
@@ -848,6 +888,13 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     ipair++;
     if (pair_sel < 0 || pair_sel == ipair) run(1, fa);
   }
+}
+
+// lanes = members of one line (the layout of large ensembles; also what the host emulation runs)
+template <int DIR, bool VZ_PER_ENS, bool DIFF>
+PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
+                           int f0, int span, int pair_sel = -1) {
+  flux_line_body<DIR, VZ_PER_ENS, DIFF>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1308,6 +1355,34 @@ PAMA_D void tracer_fixup_line_body(const Params &P, const double *prim_in, const
     tracer_update_one<STAGE>(P, t, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0,
                              fast_rcp(rho_new), rdzk, false);   // (the seven flags were just looked at)
   }
+}
+
+// The same fix-up with one lane per CELL (small ensembles: a wavefront per (line, member block) would be one lane): the five line
+// flags, then the seven row flags of the cell, then the complete update.  Cells of a wavefront that is in here for a neighbour's
+// sake are redone with multipliers of exactly 1: the value the state pass already stored, bit for bit.
+template <int STAGE>
+PAMA_D void tracer_fixup_cell_body(const Params &P, const double *prim_in, const double *prim0, double *prim_out,
+                                   const double *__restrict__ fx, const double *__restrict__ fy, const double *__restrict__ fz,
+                                   const double *__restrict__ mult, const FctRows &rows, double *__restrict__ seed, double dt_dyn,
+                                   int t, const CellId &c) {
+  const int k = c.k, j = c.j, e = c.e;
+  {
+    const int *ln = rows.lines + (long long)t * fct_lines_per_tracer(P);
+    const int sq = rows.seq;
+    const bool zl = (k > 0), zh = (k < P.nz - 1);
+    const int jm = (j == 0) ? P.ny - 1 : j - 1, jp = (j == P.ny - 1) ? 0 : j + 1;
+    const int a0 = ln[fct_line(P, k, j, e)], a1 = ln[fct_line(P, k, jm, e)], a2 = ln[fct_line(P, k, jp, e)];
+    const int a3 = ln[fct_line(P, zl ? k - 1 : k, j, e)], a4 = ln[fct_line(P, zh ? k + 1 : k, j, e)];
+    if (!wave_any_or_lane((a0 == sq) | (a1 == sq) | (a2 == sq) | (a3 == sq) | (a4 == sq))) return;
+  }
+  if (!wave_any_or_lane(fct_flagged_near(P, rows, t, k, j, c.i, e))) return;
+  const double rdzk = fast_rcp(P.dz[(long long)k * P.nens + e]);
+  const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)c.i * P.sx + e;
+  const double rho_new = prim_out[P_RHO * P.prim_fs + o];
+  const double rho_in = prim_in[P_RHO * P.prim_fs + o];
+  const double rho_0 = (STAGE > 1) ? prim0[P_RHO * P.prim_fs + o] : 0.0;
+  tracer_update_one<STAGE>(P, t, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c, rho_in, rho_0,
+                           fast_rcp(rho_new), rdzk, false);
 }
 
 // Pointwise remainder of the fused stage: the next stage's pressure (Dycore.h:310-321) and the density / pressure ghosts
@@ -1807,6 +1882,339 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
       if (i + 1 < P.nt - 1) x_tracer_sweep<2, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
       else x_tracer_sweep<1, STAGE, 1>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, e, c0, span, fa, dt_dyn, dt_stage, true, ruf_close);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TILE form of the x direction: one lane per CELL instead of one lane per member of a line that is swept serially.
+//
+// With nens the fastest axis and x the next, a periodic x line of `nx` cells and `nens` members is ONE contiguous run of nx*nens
+// doubles, and the stencil neighbours of a lane's cell are the lanes `nens` positions to its left and right.  A workgroup takes a
+// tile of `rows` rows of that run -- a row = (one cell) x (W consecutive members), W = nens when the whole ensemble fits a row
+// (small ensembles: rows follow each other without a gap, the lanes of a wavefront are 64 consecutive (x, member) pairs whatever
+// nens is), else a block of members -- and every lane
+//   A  builds the ONE polynomial set of its own cell (the same weno5_const on the same five values as the sweeps: same bits) and
+//      puts the right-edge values into LDS;
+//   B  takes the right-edge values of the cell to its left from LDS, forms the fluxes through its own left face (acoustic pair +
+//      upwinding, as flux_x_update_body) and puts them into LDS;
+//   C  takes the fluxes of its right face from the lane to its right and finishes its cell exactly as the sweep does (divergence,
+//      gravity, SSPRK3 combine, vertical ghosts, water vapour's own FCT multiplier and provisional update).
+// A tile is either a whole periodic line (`halo` 0: the neighbour rows wrap inside the tile; several short lines share a
+// workgroup) or `tc` cells of it with one halo row on each side (the left one only builds polynomials, the right one also the face
+// that closes the tile; both recompute what the neighbouring tile computes, with the same bits).
+// What this buys over the sweep: no serial chain along the line (a wavefront per 64 cells instead of per 64 lines), lanes that are
+// full whenever nx*nens reaches 64, and half the registers (4 waves per SIMD).  What it costs: the stage input is read through
+// five shifted loads per field instead of one (L1 / L2 hits), and the halo rows.  Launches that fill the chip with one wavefront
+// per line span keep the sweep (HBM-bound there, and it reads every input once).
+// Reference: Dycore.h:334-386 (x fluxes), :553-571, :162-221, next stage's :310-321 (divide), :662-710 (ghosts), :525-550 + :572-584
+// (water vapour); x_tile_tracer_*: :367-385, :525-548, :572-584 for the further tracers.
+struct XTileGeom {
+  int W;       // lanes per row
+  int nmb;     // member blocks per line: ceil(nens / W)
+  int tc;      // cells a tile completes
+  int halo;    // 0: a tile is a whole periodic line; 1: tc cells + one halo row on each side
+  int ntl;     // tiles per line
+  int lpb;     // lines per workgroup (halo == 0 only)
+};
+PAMA_HD int xtile_rows(const XTileGeom &G) { return G.tc + 2 * G.halo; }
+PAMA_HD int xtile_threads(const XTileGeom &G) { return G.W * xtile_rows(G) * G.lpb; }
+// automatic geometry (w_req / tc_req / lpb_req > 0 override: tuning and tests; results never depend on the geometry)
+PAMA_HD XTileGeom xtile_geometry(const Params &P, int w_req, int tc_req, int lpb_req) {
+  XTileGeom G;
+  G.W = (P.nens <= 64) ? P.nens : 64;
+  if (w_req > 0) G.W = w_req < P.nens ? w_req : P.nens;
+  if (G.W > 1024 / 3) G.W = 64;
+  G.nmb = (P.nens + G.W - 1) / G.W;
+  const int max_threads = 1024;
+  if (tc_req <= 0 && P.nx * G.W <= max_threads) {        // a whole periodic line per tile
+    G.halo = 0; G.tc = P.nx; G.ntl = 1;
+    // lines per workgroup: the fewest that fill their wavefronts (lanes used / lanes launched within 3 % of the best any
+    // count reaches) with at least 192 lanes
+    const int row = P.nx * G.W, most = max_threads / row;
+    auto used = [&](int l) { return (double)(l * row) / (double)(((l * row + 63) / 64) * 64); };
+    double best = 0.0;
+    for (int l = 1; l <= most; l++) best = used(l) > best ? used(l) : best;
+    G.lpb = most;
+    for (int l = 1; l <= most; l++)
+      if (used(l) >= best - 0.03 && (l * row >= 192 || l == most)) { G.lpb = l; break; }
+    if (lpb_req > 0) G.lpb = lpb_req < most ? lpb_req : most;
+    if (G.lpb < 1) G.lpb = 1;
+  } else {
+    G.halo = 1; G.lpb = 1;
+    int tc = tc_req > 0 ? tc_req : 14;
+    if (tc > P.nx) tc = P.nx;
+    while (tc > 1 && (tc + 2) * G.W > max_threads) tc--;
+    G.ntl = (P.nx + tc - 1) / tc;
+    G.tc = tc_req > 0 ? tc : (P.nx + G.ntl - 1) / G.ntl;   // automatic: even tiles
+  }
+  return G;
+}
+// lanes of the tile kernels address with `uniform field base + 32-bit lane offset`: every field must stay below 2^28 doubles
+PAMA_HD bool xtile_supported(const Params &P) { return P.prim_fs < (1ll << 28) && P.fz_fs < (1ll << 28) && (long long)P.nz * P.ny < (1ll << 30); }
+
+// A lane of a tile kernel: its cell, its roles and its neighbours.
+struct XLane {
+  int k, j, i, e;                       // level, y index, cell (wrapped into [0, nx)), member
+  bool poly, face, upd;                 // builds polynomials / forms its left face / completes its cell
+  int slot, slot_l, slot_r;             // LDS slots: own, of the row to the left, of the row to the right
+  unsigned po, io, ke;                  // offsets of the cell inside a prim field / an interior-sized field; of (level, member)
+  unsigned pm2, pm1, pp1, pp2;          // prim offsets of the cells i-2, i-1, i+1, i+2 (periodic, Dycore.h:629-657)
+};
+// (bx, by): workgroup index (tile of a line and member block; group of lines); (tx, ty, tz): lane inside it = (member of the row,
+// row, line of the group)
+PAMA_D XLane xtile_lane(const Params &P, const XTileGeom &G, int bx, int by, int tx, int ty, int tz) {
+  XLane X;
+  const int rows = xtile_rows(G);
+  const int mb = bx / G.ntl, tl = bx - mb * G.ntl;
+  const int line = by * G.lpb + tz;
+  const int c0 = tl * G.tc;
+  const int tcl = (c0 + G.tc <= P.nx) ? G.tc : P.nx - c0;           // cells this tile really holds
+  const int nrow = tcl + 2 * G.halo;
+  X.e = mb * G.W + tx;
+  const bool valid = line < P.nz * P.ny && X.e < P.nens && ty < nrow;
+  X.k = P.sim2d ? line : line / P.ny;
+  X.j = P.sim2d ? 0 : line - X.k * P.ny;
+  if (!valid) { X.k = 0; X.j = 0; X.e = 0; }
+  const int c = c0 - G.halo + (valid ? ty : G.halo);                  // -1 .. nx
+  X.i = c < 0 ? c + P.nx : (c >= P.nx ? c - P.nx : c);
+  X.poly = valid;
+  X.face = valid && (G.halo == 0 || ty >= 1);
+  X.upd = valid && ty >= G.halo && ty < G.halo + tcl;
+  X.slot = (tz * rows + ty) * G.W + tx;
+  X.slot_l = (ty > 0) ? X.slot - G.W : X.slot + (nrow - 1) * G.W;   // (halo 0: the periodic neighbour; halo 1: unused)
+  X.slot_r = (ty < nrow - 1) ? X.slot + G.W : X.slot - (nrow - 1) * G.W;
+  const unsigned lrow = (unsigned)(X.j * P.nx) * (unsigned)P.nens + (unsigned)X.e;       // (j, i = 0, e) inside a level
+  const unsigned sx = (unsigned)P.nens;
+  auto at = [&](int ii) -> unsigned { return lrow + (unsigned)(ii < 0 ? ii + P.nx : (ii >= P.nx ? ii - P.nx : ii)) * sx; };
+  const unsigned lev_p = (unsigned)(X.k + HS) * (unsigned)P.sz, lev_i = (unsigned)X.k * (unsigned)P.sz;
+  X.po = member_offset((int)(lev_p + at(X.i)));
+  X.io = member_offset((int)(lev_i + at(X.i)));
+  X.pm2 = member_offset((int)(lev_p + at(X.i - 2)));
+  X.pm1 = member_offset((int)(lev_p + at(X.i - 1)));
+  X.pp1 = member_offset((int)(lev_p + at(X.i + 1)));
+  X.pp2 = member_offset((int)(lev_p + at(X.i + 2)));
+  X.ke = (unsigned)X.k * (unsigned)P.nens + (unsigned)X.e;
+  return X;
+}
+
+// store_adv with a per-lane offset: `lo` = offset of the cell inside a level
+PAMA_D void store_adv_l(const Params &P, double *prim, int pf, int k, unsigned lo, double val, double ghost_val) {
+  g_ptr f = uniw(prim + (long long)pf * P.prim_fs);
+  const unsigned sz = (unsigned)P.sz;
+  f[member_offset((int)((unsigned)(k + HS) * sz + lo))] = val;
+  if (k == 0)
+    for (int kk = 0; kk < HS; kk++) f[member_offset((int)((unsigned)(HS - 1 - kk) * sz + lo))] = ghost_val;        // Dycore.h:670,675
+  if (k == P.nz - 1)
+    for (int kk = 0; kk < HS; kk++) f[member_offset((int)((unsigned)(HS + P.nz + kk) * sz + lo))] = ghost_val;     // Dycore.h:671,676
+}
+
+// ---- state tile (the arithmetic of flux_x_update_body's state pass, cell by cell) --------------------------------------------
+// fields of the state tile, in LDS order: 0 rho*u, 1 pressure, 2 u, 3 v, 4 w, 5 theta, 6 water vapour
+constexpr int XT_NS = 7;    // right-edge values a lane hands to its right neighbour
+constexpr int XT_NF = 6;    // face fluxes a lane hands to its left neighbour: rho, rho u, rho v, rho w, rho theta, vapour
+// A: one polynomial per field of the lane's own cell.  cen: the stage-input values the update needs again: rho*u, v, w, theta,
+// vapour (window element of the cell in the sweep) and the density
+PAMA_D void xtile_state_polys(const Params &P, const double *__restrict__ prim_in, const XLane &X, double (&L)[XT_NS],
+                              double (&R)[XT_NS], double (&cen)[6]) {
+  const WenoConsts wc = weno_consts();
+  const unsigned o5[5] = {X.pm2, X.pm1, X.po, X.pp1, X.pp2};
+  auto stencil = [&](int pf, double (&u)[5]) {
+    gc_ptr f = uni(prim_in + (long long)pf * P.prim_fs);
+#pragma unroll
+    for (int s = 0; s < 5; s++) u[s] = f[o5[s]];
+  };
+  double r[5], u[5], w[5];
+  stencil(P_RHO, r);
+  stencil(P_U, u);
+#pragma unroll
+  for (int s = 0; s < 5; s++) w[s] = mul_rn(r[s], u[s]);
+  cen[0] = w[2];
+  cen[5] = r[2];
+  weno5_const(w, wc, L[0], R[0]);
+  weno5_const(u, wc, L[2], R[2]);
+  stencil(P_PRES, w);
+  weno5_const(w, wc, L[1], R[1]);
+  if (!P.sim2d) {
+    stencil(P_V, w);
+    cen[1] = w[2];
+    weno5_const(w, wc, L[3], R[3]);
+  } else {                                                  // 2-D: the v flux is never used (skip_advected_v)
+    cen[1] = uni(prim_in + (long long)P_V * P.prim_fs)[X.po];
+    L[3] = R[3] = 0.0;
+  }
+  stencil(P_W, w);
+  cen[2] = w[2];
+  weno5_const(w, wc, L[4], R[4]);
+  stencil(P_THETA, w);
+  cen[3] = w[2];
+  weno5_const(w, wc, L[5], R[5]);
+  stencil(P_TR0 + P.idWV, w);
+  cen[4] = w[2];
+  weno5_const(w, wc, L[6], R[6]);
+}
+// B: the fluxes through the lane's LEFT face from the right-edge values of the cell to its left (Rl) and its own left-edge values
+// (Dycore.h:341-386).  own_face: the face belongs to this tile (its cell is one the tile completes): the mass flux (when further
+// tracers follow) and water vapour's flux go to flux_x as in the sweep.
+PAMA_D void xtile_state_face(const Params &P, double *__restrict__ fx, const XLane &X, const double (&L)[XT_NS],
+                             const double (&Rl)[XT_NS], bool own_face, double (&F)[XT_NF]) {
+  double ruf, ppf;
+  acoustic_face(Rl[0], L[0], Rl[1], L[1], false, ruf, ppf);
+  const bool up = ruf > 0.0;                               // upwind (Dycore.h:368)
+  const double Ft = mul_rn(ruf, up ? Rl[6] : L[6]);
+  if (own_face) {
+    if (P.nt > 1) uniw(fx)[X.io] = ruf;                     // for the tracer tiles
+    uniw(fx + (long long)(5 + P.idWV) * P.ncell)[X.io] = Ft;   // (read again where the limiter acts: tracer_fixup_line_body)
+  }
+  F[0] = ruf;
+  F[1] = fma(ruf, up ? Rl[2] : L[2], ppf);
+#pragma unroll
+  for (int n = 1; n < 4; n++) F[1 + n] = mul_rn(ruf, up ? Rl[2 + n] : L[2 + n]);
+  F[5] = Ft;
+}
+// C: the lane's cell complete (the `finish` of flux_x_update_body): Flo / Fhi = the fluxes through its left / right face
+template <int STAGE>
+PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                               double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
+                               double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
+                               const double (&Flo)[XT_NF], const double (&Fhi)[XT_NF], const double (&cen)[6], double dt_dyn,
+                               double dt_stage) {
+  const bool have_y = !P.sim2d;
+  const int k = X.k, j = X.j;
+  const unsigned po = X.po, io = X.io;
+  const unsigned jp1 = member_offset((int)(io + (unsigned)((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy)));
+  const unsigned kp1 = member_offset((int)(io + (unsigned)P.sz));
+  const double dzk = P.dz[X.ke];
+  const double rdzk = fast_rcp(dzk);
+  const double gcoef = gravity_coef(P, X.ke);
+  const int tr = P.idWV;
+  const double rho_in = cen[5];
+  const double rho_0 = (STAGE > 1) ? uni(prim0 + (long long)P_RHO * P.prim_fs)[po] : 0.0;
+  double q0[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) q0[n] = (STAGE > 1) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs)[po] : 0.0;
+  const double y0l = have_y ? uni(fy)[io] : 0.0, y0h = have_y ? uni(fy)[jp1] : 0.0;
+  const double z0l = uni(fz)[io], z0h = uni(fz)[kp1];
+  double dy[5], dz[5];
+#pragma unroll
+  for (int l = 1; l <= 4; l++) {
+    dy[l] = have_y ? uni(fy + (long long)l * P.ncell)[io] : 0.0;
+    dz[l] = (l == 2 && !have_y) ? 0.0 : uni(fz + (long long)l * P.fz_fs)[io];     // 2-D: no v tendency, nothing stored
+  }
+  const double tyl = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[io] : 0.0;
+  const double tyh = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[jp1] : 0.0;
+  const double tzl = uni(fz + (long long)(5 + tr) * P.fz_fs)[io], tzh = uni(fz + (long long)(5 + tr) * P.fz_fs)[kp1];
+  const double tseed = uni(seed + (long long)tr * P.ncell)[io];
+  const double tq0 = (STAGE > 1) ? uni(prim0 + (long long)(P_TR0 + tr) * P.prim_fs)[po] : 0.0;
+  const unsigned lo = po - (unsigned)(k + HS) * (unsigned)P.sz;                     // the cell inside its level
+
+  const double qn = rk_combine<STAGE>(rho_0, rho_in, dt_dyn, flux_divergence(P, Flo[0], Fhi[0], y0l, y0h, z0l, z0h, rdzk));
+  const double rrho = fast_rcp(qn);
+  uniw(prim_out + (long long)P_RHO * P.prim_fs)[po] = qn;
+  const double q_in[4] = {0.0, cen[1], cen[2], cen[3]};
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const int l = 1 + n;                                   // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
+    double tend = flux_divergence_d(P, Flo[l], Fhi[l], dy[l], dz[l], rdzk);
+    if (l == 3) tend = add_gravity(P, tend, rho_in, gcoef);
+    if (l == 2 && P.sim2d) tend = 0.0;
+    const double m_in = (n == 0) ? cen[0] : mul_rn(q_in[n], rho_in);
+    const double m_0 = (STAGE > 1) ? mul_rn(q0[n], rho_0) : 0.0;
+    const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
+    store_adv_l(P, prim_out, P_U + n, k, lo, v * rrho, (l == 3) ? 0.0 : v * rrho);
+    if (l == 4) uniw(prim_out + (long long)P_PRES * P.prim_fs)[po] = v;   // the new rho*theta: pressure_tail_body makes the pressure of it
+  }
+  // water vapour (finish_tracer_cell): its own multiplier (sparse store + flags) and the update an unlimited neighbourhood gets
+  own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, tseed, dzk, rdzk, dt_stage);
+  double v, new_seed;
+  tracer_new_value<STAGE>(P, tr, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, cen[4], tq0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+  uniw(seed + (long long)tr * P.ncell)[io] = new_seed;
+  store_adv_l(P, prim_out, P_TR0 + tr, k, lo, v * rrho, v * rrho);
+}
+
+// ---- tracer tiles (the arithmetic of x_tracer_sweep, cell by cell): NF further tracers per lane ------------------------------
+template <int NF>
+PAMA_D void xtile_tracer_polys(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int *fa, double (&L)[NF],
+                               double (&R)[NF], double (&cen)[NF]) {
+  const WenoConsts wc = weno_consts();
+  const unsigned o5[5] = {X.pm2, X.pm1, X.po, X.pp1, X.pp2};
+#pragma unroll
+  for (int n = 0; n < NF; n++) {
+    gc_ptr f = uni(prim_in + (long long)(P_U + fa[n]) * P.prim_fs);
+    double w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = f[o5[s]];
+    cen[n] = w[2];
+    weno5_const(w, wc, L[n], R[n]);
+  }
+}
+// the fluxes through the lane's left face, upwinded by the face mass flux the state kernel left in flux_x field 0 (Dycore.h:367-385)
+template <int NF>
+PAMA_D void xtile_tracer_face(const Params &P, const double *__restrict__ fx, const XLane &X, const double (&L)[NF],
+                              const double (&Rl)[NF], double (&F)[NF]) {
+  const double ruf = uni(fx)[X.io];
+  const bool up = ruf > 0.0;
+#pragma unroll
+  for (int n = 0; n < NF; n++) F[n] = mul_rn(ruf, up ? Rl[n] : L[n]);
+}
+// PHASE 1: the cell's FCT multipliers (a complete field); PHASE 2 (a later launch): the complete limited update
+template <int NF, int STAGE, int PHASE>
+PAMA_D void xtile_tracer_finish(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                                double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
+                                double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
+                                const int *fa, const double (&Flo)[NF], const double (&Fhi)[NF], const double (&cen)[NF],
+                                double dt_dyn, double dt_stage) {
+  const bool have_y = !P.sim2d;
+  const int k = X.k, j = X.j, i = X.i;
+  const unsigned po = X.po, io = X.io;
+  const unsigned sx = (unsigned)P.nens, sy = (unsigned)P.sy, sz = (unsigned)P.sz;
+  const unsigned jp1 = member_offset((int)((j == P.ny - 1) ? io - (unsigned)(P.ny - 1) * sy : io + sy));
+  const unsigned jm1 = member_offset((int)((j == 0) ? io + (unsigned)(P.ny - 1) * sy : io - sy));
+  const unsigned ip1 = member_offset((int)((i == P.nx - 1) ? io - (unsigned)(P.nx - 1) * sx : io + sx));
+  const unsigned im1 = member_offset((int)((i == 0) ? io + (unsigned)(P.nx - 1) * sx : io - sx));
+  const unsigned kp1 = member_offset((int)(io + sz));
+  const bool zlo = (k > 0), zhi = (k < P.nz - 1);
+  const unsigned km1 = zlo ? member_offset((int)(io - sz)) : io;
+  const double dzk = P.dz[X.ke];
+  const double rdzk = fast_rcp(dzk);
+  double rho_in = 0.0, rho_0 = 0.0, rho_new = 1.0;
+  if (PHASE == 2) {
+    rho_in = uni(prim_in + (long long)P_RHO * P.prim_fs)[po];
+    rho_0 = (STAGE > 1) ? uni(prim0 + (long long)P_RHO * P.prim_fs)[po] : 0.0;
+    rho_new = uni(prim_out + (long long)P_RHO * P.prim_fs)[po];        // written by the state kernel (an earlier launch)
+  }
+  const double rrho = (PHASE == 2) ? fast_rcp(rho_new) : 0.0;
+  const unsigned lo = po - (unsigned)(k + HS) * sz;
+#pragma unroll
+  for (int n = 0; n < NF; n++) {
+    const int t = fa[n] - 4;                               // tracer index
+    gc_ptr fyt = uni(fy + (long long)(1 + fa[n]) * P.ncell), fzt = uni(fz + (long long)(1 + fa[n]) * P.fz_fs);
+    const double yl = have_y ? fyt[io] : 0.0, yh = have_y ? fyt[jp1] : 0.0;
+    const double zl = fzt[io], zh = fzt[kp1];
+    if (PHASE == 1) {
+      const double sd = uni(seed + (long long)t * P.ncell)[io];
+      own_multiplier_cell<true>(P, t, mult, rows, k, j, i, X.e, io, 0, Flo[n], Fhi[n], yl, yh, zl, zh, sd, dzk, rdzk, dt_stage);
+    } else {
+      gc_ptr mt = uni(mult + (long long)t * P.ncell);
+      const double q_0 = (STAGE > 1) ? uni(prim0 + (long long)(P_U + fa[n]) * P.prim_fs)[po] : 0.0;
+      const double m_c = mt[io], m_im1 = mt[im1], m_ip1 = mt[ip1];
+      double m_jm1 = 1.0, m_jp1 = 1.0, m_km1 = 1.0, m_kp1 = 1.0;
+      if (have_y) { m_jm1 = mt[jm1]; m_jp1 = mt[jp1]; }
+      if (zlo) m_km1 = mt[km1];
+      if (zhi) m_kp1 = mt[kp1];
+      const double f_x = limited_flux(Flo[n], m_im1, m_c, i == 0);
+      const double f_xp1 = limited_flux(Fhi[n], m_c, m_ip1, i == P.nx - 1);
+      double f_y = 0.0, f_yp1 = 0.0;
+      if (have_y) {
+        f_y = limited_flux(yl, m_jm1, m_c, j == 0);
+        f_yp1 = limited_flux(yh, m_c, m_jp1, j == P.ny - 1);
+      }
+      const double f_z = limited_flux(zl, m_km1, m_c, false);
+      const double f_zp1 = limited_flux(zh, m_c, m_kp1, false);
+      double v, new_seed;
+      tracer_new_value<STAGE>(P, t, f_x, f_xp1, f_y, f_yp1, f_z, f_zp1, cen[n], q_0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+      uniw(seed + (long long)t * P.ncell)[io] = new_seed;
+      store_adv_l(P, prim_out, P_TR0 + t, k, lo, v * rrho, v * rrho);
     }
   }
 }

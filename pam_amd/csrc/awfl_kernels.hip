@@ -46,8 +46,20 @@ __device__ __forceinline__ long long to_global(long long t, int nens, EnsRange R
 }
 
 // Pointwise kernels: grid (ceil(nx*ne/256), ny, nz); k and j come from the block indices, (i, local member) from one
-// 32-bit division.
+// 32-bit division.  Small ensembles (P.flat_cells: nx*nens does not fill workgroups of 256): the grid is flat over every cell
+// and a thread finds (k, j, i, e) with three 32-bit divisions.
+__device__ __forceinline__ bool flat_cell(const Params &P, int nlev, CellId &c) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned sz = (unsigned)P.sz, sy = (unsigned)P.sy, ne = (unsigned)P.nens;
+  const unsigned k = t / sz, r = t - k * sz;
+  if (k >= (unsigned)nlev) return false;
+  const unsigned j = r / sy, r2 = r - j * sy, i = r2 / ne;
+  c.k = (int)k; c.j = (int)j; c.i = (int)i; c.e = (int)(r2 - i * ne);
+  c.idx = (long long)t;
+  return true;
+}
 __device__ __forceinline__ bool grid_cell(const Params &P, EnsRange R, CellId &c) {
+  if (P.flat_cells) return flat_cell(P, P.nz, c);
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (unsigned)P.nx * (unsigned)R.ne) return false;
   const unsigned i = t / (unsigned)R.ne;
@@ -55,8 +67,10 @@ __device__ __forceinline__ bool grid_cell(const Params &P, EnsRange R, CellId &c
   c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
   return true;
 }
-static inline dim3 cell_grid(const Params &P, EnsRange r) {
-  return dim3((unsigned)(((long long)P.nx * r.ne + 255) / 256), (unsigned)P.ny, (unsigned)P.nz);
+static inline dim3 cell_grid(const Params &P, EnsRange r, int nlev = 0) {
+  if (nlev <= 0) nlev = P.nz;
+  if (P.flat_cells) return dim3((unsigned)(((long long)nlev * P.sz + 255) / 256), 1, 1);
+  return dim3((unsigned)(((long long)P.nx * r.ne + 255) / 256), (unsigned)P.ny, (unsigned)nlev);
 }
 
 struct FluxGrid {
@@ -71,11 +85,14 @@ struct FluxGrid {
 
 // DIFF (the fused stage's y/z sweeps): momentum and theta leave as per-cell flux differences (flux_line_body); there is no x
 // sweep in that mode (the fused x-sweep kernel does it).
-template <bool VZ_PER_ENS, bool DIFF>
+// FLAT (small ensembles, DIFF only): the lanes of a wavefront are 64 consecutive items of the sweep's flat index space
+// ((level, x, member) for y, (y, x, member) for z: flat_lane) instead of 64 members of one line; G.nsy / G.nsz spans per item group.
+template <bool VZ_PER_ENS, bool DIFF, bool FLAT>
 __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
                                                                      const double *__restrict__ prim,
                                                                      double *__restrict__ fx, double *__restrict__ fy,
                                                                      double *__restrict__ fz) {
+  static_assert(DIFF || !FLAT, "flat lanes exist for the fused stage's y/z sweeps only");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nblk = (R.ne + 63) >> 6;          // blocks of 64 members per line
@@ -102,17 +119,31 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
     const int u = (b - G.nbx) * FLUX_WAVES + wave;
     if (u < G.nuy) {
       const int up = (G.part == 1) ? uni_int(u / G.npy) : u, psel = (G.part == 1) ? 1 + (u - up * G.npy) : G.part;
-      const int grp = uni_int(up / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne)
-        flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, line, R.e0 + el, (up - grp * G.nsy) * G.spy, G.spy, psel);
+      const int grp = uni_int(up / G.nsy);
+      if (FLAT) {
+        const unsigned q = (unsigned)grp * 64u + (unsigned)lane;
+        if (q < (unsigned)flat_items(P, 1))
+          flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, flat_lane<1>(P, q), (up - grp * G.nsy) * G.spy, G.spy, psel);
+      } else {
+        const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+        if (el < R.ne)
+          flux_line_body<1, VZ_PER_ENS, DIFF>(P, prim, fy, line, R.e0 + el, (up - grp * G.nsy) * G.spy, G.spy, psel);
+      }
     }
   } else {
     const int u = (b - G.nbx - G.nby) * FLUX_WAVES + wave;
     if (u < G.nuz) {
       const int up = (G.part == 1) ? uni_int(u / G.npz) : u, psel = (G.part == 1) ? 1 + (u - up * G.npz) : G.part;
-      const int grp = uni_int(up / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne)
-        flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
+      const int grp = uni_int(up / G.nsz);
+      if (FLAT) {
+        const unsigned q = (unsigned)grp * 64u + (unsigned)lane;
+        if (q < (unsigned)flat_items(P, 2))
+          flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, flat_lane<2>(P, q), (up - grp * G.nsz) * G.spz, G.spz, psel);
+      } else {
+        const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+        if (el < R.ne)
+          flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
+      }
     }
   }
 }
@@ -191,10 +222,13 @@ __global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, d
   __syncthreads();
   P.pw = &sh_tab;
   CellId c;
-  if (!grid_cell(P, R, c)) return;
+  const int ngrp = (P.nz + TAIL_LEVELS - 1) / TAIL_LEVELS;       // groups of levels
+  if (P.flat_cells) { if (!flat_cell(P, ngrp, c)) return; }
+  else if (!grid_cell(P, R, c)) return;
+  const int kg = P.flat_cells ? c.k : (int)blockIdx.z;
 #pragma unroll
   for (int kk = 0; kk < TAIL_LEVELS; kk++) {
-    c.k = (int)blockIdx.z * TAIL_LEVELS + kk;
+    c.k = kg * TAIL_LEVELS + kk;
     if (c.k >= P.nz) return;
     c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
     pressure_tail_body(P, prim_out, c);
@@ -217,6 +251,106 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
   tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, k, j, R.e0 + el);
 }
+// the same fix-up with one lane per cell (small ensembles; tracer_fixup_cell_body)
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_trfix_flat_kernel(Params P, const double *__restrict__ prim_in,
+                                                              const double *__restrict__ prim0, double *prim_out,
+                                                              const double *__restrict__ fx, const double *__restrict__ fy,
+                                                              const double *__restrict__ fz, const double *__restrict__ mult,
+                                                              FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  CellId c;
+  if (!flat_cell(P, P.nz, c)) return;
+  if (rows.any[c.e >> 6] != rows.seq) return;     // no row of this member block was flagged in this stage
+  tracer_fixup_cell_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, c);
+}
+
+// TILE form of the fused x-sweep (xtile_* in awfl_device.h): a lane per cell, right-edge values and face fluxes exchanged through
+// LDS (XT_NS doubles per lane, used twice).  grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
+template <int STAGE>
+__global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
+                                                              const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                              double *__restrict__ fx, const double *__restrict__ fy,
+                                                              const double *__restrict__ fz, double *__restrict__ seed,
+                                                              double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                              double dt_stage) {
+  extern __shared__ double xt_lds[];
+  const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
+  const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
+  double L[XT_NS], R[XT_NS], cen[6], F[XT_NF];
+  if (X.poly) {
+    xtile_state_polys(P, prim_in, X, L, R, cen);
+#pragma unroll
+    for (int f = 0; f < XT_NS; f++) xt_lds[f * T + X.slot] = R[f];
+  }
+  __syncthreads();
+  if (X.face) {
+#pragma unroll
+    for (int f = 0; f < XT_NS; f++) R[f] = xt_lds[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
+  }
+  __syncthreads();
+  if (X.face) {
+    xtile_state_face(P, fx, X, L, R, X.upd, F);
+#pragma unroll
+    for (int f = 0; f < XT_NF; f++) xt_lds[f * T + X.slot] = F[f];
+  }
+  __syncthreads();
+  if (X.upd) {
+    double Fhi[XT_NF];
+#pragma unroll
+    for (int f = 0; f < XT_NF; f++) Fhi[f] = xt_lds[f * T + X.slot_r];
+    xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage);
+  }
+}
+// TILE form of the further tracers' x sweeps: blockIdx.z = pair of tracers
+template <int STAGE, int PHASE, int NF>
+__device__ __forceinline__ void xtr_tile_run(const Params &P, const XTileGeom &G, const double *__restrict__ prim_in,
+                                             const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                             const double *__restrict__ fx, const double *__restrict__ fy,
+                                             const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
+                                             const FctRows &rows, double dt_dyn, double dt_stage, const int *fa, double *lds) {
+  const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
+  const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
+  double L[NF], R[NF], cen[NF], F[NF];
+  if (X.poly) {
+    xtile_tracer_polys<NF>(P, prim_in, X, fa, L, R, cen);
+#pragma unroll
+    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = R[f];
+  }
+  __syncthreads();
+  if (X.face) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) R[f] = lds[f * T + X.slot_l];
+  }
+  __syncthreads();
+  if (X.face) {
+    xtile_tracer_face<NF>(P, fx, X, L, R, F);
+#pragma unroll
+    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = F[f];
+  }
+  __syncthreads();
+  if (X.upd) {
+    double Fhi[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) Fhi[f] = lds[f * T + X.slot_r];
+    xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
+  }
+}
+template <int STAGE, int PHASE>
+__global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
+                                                             const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                             const double *__restrict__ fx, const double *__restrict__ fy,
+                                                             const double *__restrict__ fz, double *__restrict__ seed,
+                                                             double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                             double dt_stage) {
+  extern __shared__ double xt_lds[];
+  const int pair = (int)blockIdx.z;
+  const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
+  if (2 * pair + 1 < P.nt - 1)
+    xtr_tile_run<STAGE, PHASE, 2>(P, G, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+  else
+    xtr_tile_run<STAGE, PHASE, 1>(P, G, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+}
+
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
 // (weno5_table, the z sweep; level = vertical matrix index 0..nz+1 as in Dycore.h:454-469).
@@ -382,6 +516,13 @@ struct pam_amd_awfl {
   int chunks_requested = 0;    // 0: automatic
   bool use_priorities = true;  // flux streams get the device's highest stream priority (see Chunk)
   bool interleave_xy = true;
+  int lane_mode = 0;           // 0 automatic, 1 member lanes, 2 flat (x, member) lanes (pam_amd_awfl_set_lane_mapping)
+  bool flat = false;           // resolved lane mapping of the fused stage: flat lanes over (x, member) (small ensembles)
+  bool flat_supported = false; // every lane offset fits the 28 bits of the scalar-base + lane-offset addressing
+  int xtile_mode = 0;          // 0 automatic, 1 sweep kernels (a wavefront per line span), 2 tile kernels (a lane per cell)
+  bool xtile = false;          // resolved: the x direction of the fused stage runs as tile kernels
+  int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
+  XTileGeom xg;
   bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
   bool fused_supported = false;
   size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
@@ -490,21 +631,28 @@ static void choose_span(int nfaces, long long nlines, int nens, int min_span, in
   nspan = (nfaces + span - 1) / span;
 }
 
-// sweeps: bit 0 x, bit 1 y, bit 2 z (the fused stage runs y and z here and x in awfl_xupd_kernel)
+// sweeps: bit 0 x, bit 1 y, bit 2 z (the fused stage runs y and z here and x in awfl_xupd_kernel / awfl_xupd_tile_kernel)
 int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, int sweeps = 7, bool diff = false) {
   const Params &P = h->P;
   FluxGrid G;
   if (diff && (sweeps & 1)) return fail(PAM_AMD_EINVAL, "flux launch: the difference form has no x sweep");
+  // flat lanes (small ensembles): the y/z sweeps of the fused stage take 64 consecutive items of (level | y, x, member) per
+  // wavefront instead of 64 members of one line; one range = the whole ensemble
+  const bool flat = h->flat && diff;
+  if (flat && (r.e0 != 0 || r.ne != P.nens)) return fail(PAM_AMD_EINVAL, "flux launch: flat lanes sweep the whole ensemble in one range");
+  const long long gy = flat ? (flat_items(P, 1) + 63) / 64 : (long long)P.nz * P.nx;   // groups of 64 lanes per member block (member lanes: lines)
+  const long long gz = flat ? (flat_items(P, 2) + 63) / 64 : (long long)P.ny * P.nx;
+  const int ens_for_span = flat ? 1 : P.nens;
   // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
   choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, G.spx, G.nsx);
-  choose_span(P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, G.spy, G.nsy);
-  choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, G.spz, G.nsz);
+  choose_span(P.ny, gy, ens_for_span, P.seg, h->span_override, G.spy, G.nsy);
+  choose_span(P.nz + 1, gz, ens_for_span, P.seg, h->span_override, G.spz, G.nsz);
   if (diff) { G.spy = P.ny; G.nsy = 1; }   // difference form: a periodic line is swept whole (its last cell needs face n == face 0)
-  const long long nblk = (r.ne + 63) / 64;     // a wavefront = 64 consecutive members of ONE line
-  const long long nblk_all = (P.nens + 63) / 64;
+  const long long nblk = flat ? 1 : (r.ne + 63) / 64;     // member lanes: a wavefront = 64 consecutive members of ONE line
+  const long long nblk_all = flat ? 1 : (P.nens + 63) / 64;
   const long long ux0 = (sweeps & 1) ? (long long)P.nz * P.ny * G.nsx : 0;
-  const long long uy0 = (P.sim2d || !(sweeps & 2)) ? 0 : (long long)P.nz * P.nx * G.nsy;
-  const long long uz0 = (sweeps & 4) ? (long long)P.ny * P.nx * G.nsz : 0;
+  const long long uy0 = (P.sim2d || !(sweeps & 2)) ? 0 : gy * G.nsy;
+  const long long uz0 = (sweeps & 4) ? gz * G.nsz : 0;
   // Small ensembles: a wavefront that sweeps its span for pass 1 and then for every pair of advected fields, one after the
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
@@ -531,10 +679,11 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   }
   if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
   const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
-#define PAMA_LAUNCH_FLUX(VZ, DF)                                                                                        \
-  hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
-  if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true); else PAMA_LAUNCH_FLUX(true, false); }
-  else { if (diff) PAMA_LAUNCH_FLUX(false, true); else PAMA_LAUNCH_FLUX(false, false); }
+#define PAMA_LAUNCH_FLUX(VZ, DF, FL)                                                                                    \
+  hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF, FL>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
+  if (flat) { if (P.vz_per_ens) PAMA_LAUNCH_FLUX(true, true, true); else PAMA_LAUNCH_FLUX(false, true, true); }
+  else if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true, false); else PAMA_LAUNCH_FLUX(true, false, false); }
+  else { if (diff) PAMA_LAUNCH_FLUX(false, true, false); else PAMA_LAUNCH_FLUX(false, false, false); }
 #undef PAMA_LAUNCH_FLUX
   HIP_TRY(hipGetLastError());
   }
@@ -587,6 +736,41 @@ template <int STAGE>
 int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, double dt_stage,
                 EnsRange r, hipStream_t s) {
   const Params &P = h->P;
+  if (h->xtile) {
+    // tile kernels: a lane per cell, the whole ensemble in one launch (small ensembles; launches the sweeps cannot fill the chip with)
+    if (r.e0 != 0 || r.ne != P.nens) return fail(PAM_AMD_EINVAL, "x-tile launch: the tile kernels take the whole ensemble in one range");
+    const XTileGeom &G = h->xg;
+    const int nlines = P.nz * P.ny, threads = xtile_threads(G);
+    const dim3 block((unsigned)G.W, (unsigned)xtile_rows(G), (unsigned)G.lpb);
+    const dim3 grid((unsigned)(G.ntl * G.nmb), (unsigned)((nlines + G.lpb - 1) / G.lpb), 1);
+    if (grid.y > 65535u) return fail(PAM_AMD_EINVAL, "x-tile launch: more than 65535 groups of x lines");
+    // a wavefront is one row of FCT flags only when a row of the tile is exactly one 64-member block
+    const bool wave_is_row = (G.W == 64 && P.nens % 64 == 0);
+    {
+      ScopedTimer st(h, "xupd", s);
+      hipLaunchKernelGGL(awfl_xupd_tile_kernel<STAGE>, grid, block, (size_t)XT_NS * threads * sizeof(double), s, P, G, prim_in, prim0,
+                         prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+      HIP_TRY(hipGetLastError());
+    }
+    const int npairs = (P.nt - 1 + 1) / 2;
+    if (npairs > 65535) return fail(PAM_AMD_EINVAL, "x-tile launch: too many tracer pairs");
+    if (npairs > 0) {
+      const dim3 tgrid(grid.x, grid.y, (unsigned)npairs);
+      {
+        ScopedTimer st(h, "xtr1", s);
+        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * threads * sizeof(double), s, P, G, prim_in, prim0,
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+        HIP_TRY(hipGetLastError());
+      }
+      {
+        ScopedTimer st(h, "xtr2", s);
+        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid, block, (size_t)2 * threads * sizeof(double), s, P, G, prim_in, prim0,
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    return PAM_AMD_OK;
+  }
   // wavefronts: (x line, block of 64 members, span of cells).  Normally a wavefront owns a whole line; when the ensemble alone
   // does not fill the chip the lines are cut into spans (each recomputes its closing face) as choose_span decides from the
   // WHOLE ensemble, so that results and schedule do not depend on the chunking
@@ -634,17 +818,21 @@ int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
                 hipStream_t s) {
   {
     ScopedTimer st(h, "ptail", s);
-    dim3 g = cell_grid(h->P, r);
-    g.z = (g.z + TAIL_LEVELS - 1) / TAIL_LEVELS;
+    const dim3 g = cell_grid(h->P, r, (h->P.nz + TAIL_LEVELS - 1) / TAIL_LEVELS);
     hipLaunchKernelGGL(awfl_ptail_kernel, g, dim3(256), 0, s, h->P, r, prim_out);
     HIP_TRY(hipGetLastError());
   }
   {
     ScopedTimer st(h, "trfix", s);
-    const long long units = (long long)h->P.nz * h->P.ny * ((r.ne + 63) / 64);   // water vapour only (the others are complete)
-    if (units > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "fix-up launch: more than 2^30 wavefronts");
-    hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, dim3(nblocks(units, 4)), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
-                       h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+    if (h->P.flat_cells) {      // small ensembles: a lane per cell
+      hipLaunchKernelGGL(awfl_trfix_flat_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, prim_in, prim0, prim_out,
+                         h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+    } else {
+      const long long units = (long long)h->P.nz * h->P.ny * ((r.ne + 63) / 64);   // water vapour only (the others are complete)
+      if (units > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "fix-up launch: more than 2^30 wavefronts");
+      hipLaunchKernelGGL(awfl_trfix_kernel<STAGE>, dim3(nblocks(units, 4)), dim3(256), 0, s, h->P, r, prim_in, prim0, prim_out,
+                         h->flux_x, h->flux_y, h->flux_z, h->mult, fct_rows(h, r, false), h->seed, dt_dyn);
+    }
     HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;
@@ -682,6 +870,21 @@ void destroy_chunks(pam_amd_awfl *h) {
   h->chunks.clear();
 }
 
+// Lane mapping of the fused stage (decided from the WHOLE ensemble; results never depend on it):
+//   flat   the y/z sweeps take 64 consecutive (x, member) items per wavefront (flat_lane) instead of 64 members of one line
+//   xtile  the x direction runs as tile kernels (a lane per cell) instead of sweeps (a wavefront per line span)
+//   P.flat_cells  the pointwise kernels run on a grid that is flat over every cell
+// Automatic: all three for ensembles of fewer than 64 members (a member-lane wavefront would be mostly idle lanes).
+void resolve_lane_mapping(pam_amd_awfl *h) {
+  Params &P = h->P;
+  const bool small = P.nens < 64;
+  h->flat_supported = P.prim_fs < (1ll << 28) && P.fz_fs < (1ll << 28);
+  h->flat = h->flat_supported && (h->lane_mode == 2 || (h->lane_mode == 0 && small));
+  h->xtile = xtile_supported(P) && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
+  h->xg = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
+  P.flat_cells = (h->lane_mode != 1 && (long long)P.nx * P.nens < 256 && P.ncell < (1ll << 31)) ? 1 : 0;
+}
+
 // (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
 int build_chunks(pam_amd_awfl *h) {
   (void)hipStreamSynchronize(h->stream);
@@ -713,6 +916,8 @@ int build_chunks(pam_amd_awfl *h) {
     if (n < 1 || h->fused) n = 1;
     if (n > 16) n = 16;
   }
+  if (h->fused && (h->flat || h->xtile)) n = 1;    // flat lanes and tile kernels take the whole ensemble in one launch
+  if (h->P.flat_cells) n = 1;                      // (pointwise kernels with a flat grid over every cell)
   const int per = (((nens + n - 1) / n + 63) / 64) * 64;
   for (int e0 = 0; e0 < nens; e0 += per) {
     Chunk c;
@@ -888,15 +1093,16 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->n_vert_s2c = vt.s2c.size(); h->n_vert_wrl = vt.wrl.size();
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 0;   // no residency cap by default
+  resolve_lane_mapping(h);
   if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }
   *out = h;
   return PAM_AMD_OK;
@@ -1278,6 +1484,42 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
   h->chunks_requested = chunks;
   h->flux_lds_floor = (size_t)flux_lds_floor_bytes;
   return build_chunks(h);
+}
+
+int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (yz_lanes < 0 || yz_lanes > 2 || x_kernels < 0 || x_kernels > 2)
+    return fail(PAM_AMD_EINVAL, "set_lane_mapping: 0 = automatic, 1 = member lanes / sweep kernels, 2 = flat lanes / tile kernels");
+  USE_DEVICE(h);
+  const int old_l = h->lane_mode, old_x = h->xtile_mode;
+  h->lane_mode = yz_lanes;
+  h->xtile_mode = x_kernels;
+  resolve_lane_mapping(h);
+  if ((yz_lanes == 2 && !h->flat) || (x_kernels == 2 && !h->xtile)) {
+    h->lane_mode = old_l; h->xtile_mode = old_x;
+    resolve_lane_mapping(h);
+    return fail(PAM_AMD_EINVAL, "set_lane_mapping: flat lanes / tile kernels need every field below 2^28 doubles (32-bit lane offsets)");
+  }
+  return build_chunks(h);
+}
+
+int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
+  const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group);
+  if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
+  h->xt_w = row_lanes; h->xt_tc = cells_per_tile; h->xt_lpb = lines_per_group;
+  resolve_lane_mapping(h);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (yz_flat) *yz_flat = h->flat ? 1 : 0;
+  if (x_tiles) *x_tiles = h->xtile ? 1 : 0;
+  if (flat_cells) *flat_cells = h->P.flat_cells;
+  if (geom) { geom[0] = h->xg.W; geom[1] = h->xg.nmb; geom[2] = h->xg.tc; geom[3] = h->xg.halo; geom[4] = h->xg.ntl; geom[5] = h->xg.lpb; }
+  return PAM_AMD_OK;
 }
 
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {

@@ -22,6 +22,7 @@ class Dycore {
   // the handle and the pointer scratch are implementation state behind that interface
   mutable pam_amd_awfl_t *h = nullptr;
   mutable std::vector<double *> trc;   // device pointers of the tracer arrays, coupler registration order
+  int ncycles_ = 0;
 
   static void chk(int rc) { if (rc) endrun(pam_amd_awfl_last_error()); }          // pam_const.h:249-252
 
@@ -82,7 +83,7 @@ class Dycore {
     cfg.idWV = idWV;
     cfg.tracer_positive = pos.data(); cfg.tracer_adds_mass = mass.data();
     cfg.vertical_cell_dz = coupler.get_data_manager_device_readonly().get<real const, 2>("vertical_cell_dz").data();
-    cfg.stream = nullptr;                                                          // the default stream (what YAKL uses)
+    cfg.stream = nullptr;                                                          // the default stream of the CURRENT device (what YAKL uses)
     chk(pam_amd_awfl_init(&cfg, &h));
     // what the reference writes back into the coupler (awfl/Dycore.h:866-891,974)
     coupler.set_option<bool>("balance_hydrostasis_with_gravity", true);
@@ -121,8 +122,19 @@ class Dycore {
   void timeStep(pam::PamCoupler &coupler) {
     chk(sync_balance_option(coupler));
     auto f = fields(coupler);
-    chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), /*dt_dyn_hint=*/0., nullptr, nullptr));
+    chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), /*dt_dyn_hint=*/0., &ncycles_, nullptr));
   }
+
+  // Not in the reference (one process, one device): the ensemble sharded by member index over several devices, one coupler and
+  // one Dycore per device.  The dynamics step is a minimum over ALL members (awfl/Dycore.h:86-101,141-145): the host takes the
+  // minimum of the devices' compute_time_step() values (N host doubles; examples/driver.cpp --gpus N) and passes it in, so every
+  // shard sub-cycles as the unsharded ensemble would.
+  void timeStep(pam::PamCoupler &coupler, real dt_dyn_all_members) {
+    chk(sync_balance_option(coupler));
+    auto f = fields(coupler);
+    chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), dt_dyn_all_members, &ncycles_, nullptr));
+  }
+  int last_ncycles() const { return ncycles_; }        // sub-cycles of the most recent timeStep (awfl/Dycore.h:144)
 
   // awfl/Dycore.h:65
   real compute_time_step(pam::PamCoupler const &coupler, real cfl = 0.8) const {

@@ -183,6 +183,8 @@ class Dycore:
         if state is None and tracers is None:
             check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics(self._h, C.byref(f)))
             return
+        if state is None or tracers is None:
+            endrun("ERROR: convert_coupler_to_dynamics takes (coupler) or (coupler, state, tracers)")
         self._halo_arrays(coupler, state, tracers)
         check(self._lib.pam_amd_awfl_convert_coupler_to_dynamics_arrays(self._h, C.byref(f), state.data_ptr(), tracers.data_ptr()))
 
@@ -194,6 +196,8 @@ class Dycore:
         if state is None and tracers is None:
             check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler(self._h, C.byref(f)))
             return
+        if state is None or tracers is None:
+            endrun("ERROR: convert_dynamics_to_coupler takes (coupler) or (coupler, state, tracers)")
         self._halo_arrays(coupler, state, tracers)
         check(self._lib.pam_amd_awfl_convert_dynamics_to_coupler_arrays(self._h, C.byref(f), state.data_ptr(), tracers.data_ptr()))
 
@@ -237,6 +241,24 @@ class Dycore:
 
     def set_fused_stage(self, enable):
         check(self._lib.pam_amd_awfl_set_fused_stage(self._h, int(bool(enable))))
+
+    LANES = {"auto": 0, "member": 1, "flat": 2}
+    XKERNELS = {"auto": 0, "sweep": 1, "tile": 2}
+
+    def set_lane_mapping(self, yz_lanes="auto", x_kernels="auto"):
+        """lane mapping of the fused stage (include/pam_amd_awfl.h): yz_lanes "member" | "flat", x_kernels "sweep" | "tile";
+        "auto" = flat / tile for ensembles of fewer than 64 members.  Results do not depend on it."""
+        check(self._lib.pam_amd_awfl_set_lane_mapping(self._h, self.LANES[yz_lanes], self.XKERNELS[x_kernels]))
+
+    def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
+        check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
+
+    def get_lane_mapping(self):
+        flat, tile, cells = C.c_int(), C.c_int(), C.c_int()
+        g = (C.c_int * 6)()
+        check(self._lib.pam_amd_awfl_get_lane_mapping(self._h, C.byref(flat), C.byref(tile), C.byref(cells), g))
+        return {"yz_flat": bool(flat.value), "x_tiles": bool(tile.value), "flat_cells": bool(cells.value),
+                "tile": dict(zip(("W", "nmb", "tc", "halo", "ntl", "lpb"), list(g)))}
 
     def debug_buffer(self, name):
         ptr, n = C.c_void_p(), C.c_size_t()

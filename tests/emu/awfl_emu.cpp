@@ -7,6 +7,7 @@
 // Differences to the device build: true division instead of v_rcp_f64+Newton, glibc pow, and whatever
 // contraction g++ applies -- i.e. rounding-level only.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,9 @@ struct Emu {
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
   int xtr_split = 0;   // fused stage: tracers 1.. swept in a launch of their own (awfl_xtr_kernel) instead of inline
   int fused = 0;  // stage structure of awfl_kernels.hip: 1 = flux(y,z) -> fused x-sweep + state update -> FCT -> tracer update
+  int flat = 0;   // fused stage: the y/z sweeps run with flat (x, member) lanes (flat_lane) and the fix-up with a lane per cell
+  int xtile = 0;  // fused stage: the x direction runs as tile kernels (a lane per cell; xtile_* bodies) instead of sweeps
+  int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides
   std::vector<int> fct_flags;   // row flags of the FCT multiplier (FctRows)
   int fct_seq = 0;
 };
@@ -50,6 +54,21 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
     if (diff && dir == 1) span = nfaces;                 // difference form: periodic lines are swept whole
     const int nspan = (nfaces + span - 1) / span;
     double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());
+    if (h->flat && diff && dir != 0) {     // awfl_flux_kernel<., true, FLAT>: a lane per item of the sweep's flat index space
+      const long long items = flat_items(P, dir);
+      for (int sp = 0; sp < nspan; sp++)
+        for (long long q = 0; q < items; q++) {
+          const int f0 = sp * span;
+          if (dir == 1) {
+            if (P.vz_per_ens) flux_line_body<1, true, true>(P, prim, fl, flat_lane<1>(P, (unsigned)q), f0, span);
+            else flux_line_body<1, false, true>(P, prim, fl, flat_lane<1>(P, (unsigned)q), f0, span);
+          } else {
+            if (P.vz_per_ens) flux_line_body<2, true, true>(P, prim, fl, flat_lane<2>(P, (unsigned)q), f0, span);
+            else flux_line_body<2, false, true>(P, prim, fl, flat_lane<2>(P, (unsigned)q), f0, span);
+          }
+        }
+      continue;
+    }
     // one wavefront per (line, block of 64 members, span); lanes = members
     for (int line = 0; line < nlines; line++)
       for (int sp = 0; sp < nspan; sp++)
@@ -94,10 +113,100 @@ static void update_launch(Emu *h, const double *in, const double *p0, double *ou
                        cell_of(h->P, idx));
 }
 
+// awfl_xupd_tile_kernel / awfl_xtr_tile_kernel: the workgroup's phases run one after the other over all its lanes, with the LDS
+// exchange between them (what __syncthreads orders on the device)
+template <int STAGE>
+static void xupd_tile_launch(Emu *h, const double *in, const double *p0, double *out, double dt, double dt_stage) {
+  const Params &P = h->P;
+  const XTileGeom G = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
+  const int rows = xtile_rows(G), T = xtile_threads(G);
+  const int gx = G.ntl * G.nmb, gy = (P.nz * P.ny + G.lpb - 1) / G.lpb;
+  struct Lane { XLane X; double L[XT_NS], R[XT_NS], cen[6], F[XT_NF]; };
+  std::vector<Lane> st(T);
+  std::vector<double> lds((size_t)XT_NS * T);
+  const FctRows fr = fct_rows(h);
+  const int npairs = (P.nt - 1 + 1) / 2;
+  for (int by = 0; by < gy; by++)
+    for (int bx = 0; bx < gx; bx++) {
+      std::fill(lds.begin(), lds.end(), NAN);
+      for (int tz = 0; tz < G.lpb; tz++)
+        for (int ty = 0; ty < rows; ty++)
+          for (int tx = 0; tx < G.W; tx++) {
+            const int t = (tz * rows + ty) * G.W + tx;
+            Lane &l = st[t];
+            l.X = xtile_lane(P, G, bx, by, tx, ty, tz);
+            if (l.X.slot != t) abort();
+            if (!l.X.poly) continue;
+            xtile_state_polys(P, in, l.X, l.L, l.R, l.cen);
+            for (int f = 0; f < XT_NS; f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+          }
+      for (int t = 0; t < T; t++)
+        if (st[t].X.face)
+          for (int f = 0; f < XT_NS; f++) st[t].R[f] = lds[(size_t)f * T + st[t].X.slot_l];
+      for (int t = 0; t < T; t++)
+        if (st[t].X.face) {
+          xtile_state_face(P, h->fx.data(), st[t].X, st[t].L, st[t].R, st[t].X.upd, st[t].F);
+          for (int f = 0; f < XT_NF; f++) lds[(size_t)f * T + st[t].X.slot] = st[t].F[f];
+        }
+      for (int t = 0; t < T; t++)
+        if (st[t].X.upd) {
+          double Fhi[XT_NF];
+          for (int f = 0; f < XT_NF; f++) Fhi[f] = lds[(size_t)f * T + st[t].X.slot_r];
+          xtile_state_finish<STAGE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, st[t].X, st[t].F,
+                                    Fhi, st[t].cen, dt, dt_stage);
+        }
+    }
+  auto tracer_phase = [&](auto phase_tag) {
+    constexpr int PHASE = decltype(phase_tag)::value;
+    struct TL { XLane X; double L[2], R[2], cen[2], F[2]; };
+    std::vector<TL> tl(T);
+    for (int pair = 0; pair < npairs; pair++) {
+      const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
+      const bool two = 2 * pair + 1 < P.nt - 1;
+      for (int by = 0; by < gy; by++)
+        for (int bx = 0; bx < gx; bx++) {
+          std::fill(lds.begin(), lds.end(), NAN);
+          for (int tz = 0; tz < G.lpb; tz++)
+            for (int ty = 0; ty < rows; ty++)
+              for (int tx = 0; tx < G.W; tx++) {
+                TL &l = tl[(tz * rows + ty) * G.W + tx];
+                l.X = xtile_lane(P, G, bx, by, tx, ty, tz);
+                if (!l.X.poly) continue;
+                if (two) xtile_tracer_polys<2>(P, in, l.X, fa, l.L, l.R, l.cen);
+                else xtile_tracer_polys<1>(P, in, l.X, fa, reinterpret_cast<double (&)[1]>(l.L), reinterpret_cast<double (&)[1]>(l.R), reinterpret_cast<double (&)[1]>(l.cen));
+                for (int f = 0; f < (two ? 2 : 1); f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+              }
+          for (int t = 0; t < T; t++)
+            if (tl[t].X.face)
+              for (int f = 0; f < (two ? 2 : 1); f++) tl[t].R[f] = lds[(size_t)f * T + tl[t].X.slot_l];
+          for (int t = 0; t < T; t++)
+            if (tl[t].X.face) {
+              TL &l = tl[t];
+              if (two) xtile_tracer_face<2>(P, h->fx.data(), l.X, l.L, l.R, l.F);
+              else xtile_tracer_face<1>(P, h->fx.data(), l.X, reinterpret_cast<double (&)[1]>(l.L), reinterpret_cast<double (&)[1]>(l.R), reinterpret_cast<double (&)[1]>(l.F));
+              for (int f = 0; f < (two ? 2 : 1); f++) lds[(size_t)f * T + l.X.slot] = l.F[f];
+            }
+          for (int t = 0; t < T; t++)
+            if (tl[t].X.upd) {
+              TL &l = tl[t];
+              double Fhi[2] = {0.0, 0.0};
+              for (int f = 0; f < (two ? 2 : 1); f++) Fhi[f] = lds[(size_t)f * T + l.X.slot_r];
+              if (two) xtile_tracer_finish<2, STAGE, PHASE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, l.X, fa, l.F, Fhi, l.cen, dt, dt_stage);
+              else xtile_tracer_finish<1, STAGE, PHASE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, l.X, fa, reinterpret_cast<double (&)[1]>(l.F), reinterpret_cast<double (&)[1]>(Fhi), reinterpret_cast<double (&)[1]>(l.cen), dt, dt_stage);
+            }
+        }
+    }
+  };
+  if (npairs > 0) tracer_phase(std::integral_constant<int, 1>{});
+  poison_unflagged_mult(h);
+  if (npairs > 0) tracer_phase(std::integral_constant<int, 2>{});
+}
+
 // launch geometry of awfl_xupd_kernel: one wavefront per (x line, block of 64 members); lanes = members
 template <int STAGE>
 static void xupd_launch(Emu *h, const double *in, const double *p0, double *out, double dt, double dt_stage) {
   const Params &P = h->P;
+  if (h->xtile) { xupd_tile_launch<STAGE>(h, in, p0, out, dt, dt_stage); return; }
   const int span = h->span > 0 ? h->span : P.nx, nspan = (P.nx + span - 1) / span;   // emu_set_span cuts the x lines too
   for (int line = 0; line < P.nz * P.ny; line++)
     for (int sp = 0; sp < nspan; sp++)
@@ -137,6 +246,11 @@ static void tail_launch(Emu *h, const double *in, const double *p0, double *out,
   bool any = false;
   for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || rows.any[b] == rows.seq;
   if (!any) return;
+  if (h->flat) {      // awfl_trfix_flat_kernel: a lane per cell
+    for (long long idx = 0; idx < P.ncell; idx++)
+      tracer_fixup_cell_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), rows, h->seed.data(), dt, P.idWV, cell_of(P, idx));
+    return;
+  }
   for (int k = 0; k < P.nz; k++)       // water vapour only: the others were completed by phase 2 of their sweeps
     for (int j = 0; j < P.ny; j++)
       for (int e = 0; e < P.nens; e++)
@@ -201,6 +315,12 @@ void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
 void emu_set_span(Emu *h, int span) { h->span = span; }
 void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
 void emu_set_xtr_split(Emu *h, int split) { h->xtr_split = split; }
+void emu_set_lane_mapping(Emu *h, int flat, int xtile) { h->flat = flat; h->xtile = xtile; }
+void emu_set_x_tile(Emu *h, int w, int tc, int lpb) { h->xt_w = w; h->xt_tc = tc; h->xt_lpb = lpb; }
+void emu_x_tile_geometry(Emu *h, int *g) {
+  const XTileGeom G = xtile_geometry(h->P, h->xt_w, h->xt_tc, h->xt_lpb);
+  g[0] = G.W; g[1] = G.nmb; g[2] = G.tc; g[3] = G.halo; g[4] = G.ntl; g[5] = G.lpb;
+}
 int emu_vz_per_ens(Emu *h) { return h->P.vz_per_ens; }
 double *emu_buffer(Emu *h, const char *name) {
   std::string k(name);

@@ -34,6 +34,9 @@ def load():
         lib.emu_pow.argtypes = [_DP, C.c_int, C.c_double, _DP]
         lib.emu_set_fused.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_xtr_split.argtypes = [C.c_void_p, C.c_int]
+        lib.emu_set_lane_mapping.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.emu_set_x_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.emu_x_tile_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.emu_vz_per_ens.argtypes = [C.c_void_p]
         lib.emu_buffer.restype = _DP
         lib.emu_buffer.argtypes = [C.c_void_p, C.c_char_p]
@@ -88,6 +91,18 @@ class EmuDycore:
 
     def set_xtr_split(self, on):
         self.lib.emu_set_xtr_split(self.h, int(bool(on)))
+
+    def set_lane_mapping(self, flat, xtile):
+        """fused stage: flat (x, member) lanes in the y/z sweeps and the fix-up; tile kernels in x"""
+        self.lib.emu_set_lane_mapping(self.h, int(bool(flat)), int(bool(xtile)))
+
+    def set_x_tile(self, w=0, tc=0, lpb=0):
+        self.lib.emu_set_x_tile(self.h, int(w), int(tc), int(lpb))
+
+    def x_tile_geometry(self):
+        g = (C.c_int * 6)()
+        self.lib.emu_x_tile_geometry(self.h, g)
+        return dict(zip(("W", "nmb", "tc", "halo", "ntl", "lpb"), list(g)))
 
     @property
     def vz_per_ens(self):

@@ -1,0 +1,162 @@
+"""GPU: the lane mappings of the fused stage (include/pam_amd_awfl.h: pam_amd_awfl_set_lane_mapping).
+
+Small ensembles (nens < 64: every input file the reference ships has nens = 1, standalone/mmf_simplified/inputs/input_pama.yaml:14)
+run with FLAT lanes in the y/z sweeps and TILE kernels in x (a lane per cell, neighbours at lane distance nens through LDS);
+large ones with MEMBER lanes and sweeps.  Same helpers, same rounding points: the two must agree BIT FOR BIT
+  * on the same input (both mappings forced on small, 64-aligned and ragged ensembles, several tile geometries),
+  * on a tiled input (nens = 2 with flat lanes against the same two members tiled to 64 and run with member lanes),
+and the small-ensemble defaults must really be flat / tile, with wavefronts >= 90 % full whenever nx*nens >= 64.
+Parity of the new path against the ORACLE: tests/test_gpu_parity.py -- its cases with nens < 64 (C1 exactly among them) run it by
+default."""
+import numpy as np
+import pytest
+
+from pam_amd import idealized as idz
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (nens, nx, ny, nz, tracers, zint, per_ens, mode_a, consts, limiter on vapour, tile geometries (W, tc, lpb) besides the automatic one)
+    "nens1_c2grid_slab": (1, 32, 6, 20, idz.TRACERS_NONE, idz.stretched_interfaces(20, 15000.0), False, True, idz.CONSTS_DEFAULT, False, [(0, 5, 0), (0, 0, 1)]),
+    "nens1_ref_shape_nt4": (1, 250, 1, 16, idz.TRACERS_KESSLER_SHOC, idz.uniform_interfaces(16, 16000.0), False, True, idz.CONSTS_DEFAULT, False, [(0, 100, 0)]),
+    "nens2_c1_like": (2, 32, 8, 12, idz.TRACERS_NONE, idz.uniform_interfaces(12, 12000.0), False, True, idz.CONSTS_DEFAULT, False, [(1, 0, 0)]),
+    "nens8_nt4_B": (8, 12, 6, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, False, idz.CONSTS_DEFAULT, False, [(0, 4, 0), (4, 0, 0)]),
+    "nens32_nt10_2d_p3_perens": (32, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), True, True, idz.CONSTS_P3, False, [(0, 7, 0)]),
+    "nens5_vapour_limited": (5, 16, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT, True, [(0, 3, 0)]),
+    "nens40_vapour_limited_B": (40, 32, 3, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, False, idz.CONSTS_DEFAULT, True, [(0, 6, 0)]),
+    # large ensembles with the small-ensemble mappings forced: 64-aligned (a wavefront of a 64-lane row IS a row of FCT flags: sparse
+    # multiplier stores), ragged, rows of 32 members (a whole 32-cell line in one workgroup)
+    "nens128_nt4_rows": (128, 32, 4, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, True, idz.CONSTS_DEFAULT, False, [(32, 0, 0), (64, 6, 0)]),
+    "nens70_ragged_vapour_limited": (70, 12, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT, True, [(35, 0, 0)]),
+    "nens192_nt10_2d": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), False, False, idz.CONSTS_P3, False, [(64, 14, 0)]),
+}
+
+
+def _fields(case):
+    nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
+    xlen = nx * 500.0
+    ylen = ny * 500.0 if ny > 1 else xlen
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if limiter:
+        f["uvel"] -= 25.0
+        f["vvel"] += 7.0
+        idz.carve_dry_air(f, tr)
+    return f, xlen, ylen
+
+
+def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None):
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
+    if nens_override:
+        nens = nens_override
+    zi = np.asarray(zint)[:, None] * np.ones((1, nens))
+    if per_ens:
+        zi = zi * (1 + 0.01 * np.arange(nens))[None, :]
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 2.0)
+    for k, v in consts.items():
+        coupler.set_option(k, v)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(xlen, ylen, zi)
+    for n, p, m in tr:
+        coupler.add_tracer(n, "", p, m)
+    dycore = Dycore()
+    dycore.init(coupler)
+    dycore.set_lane_mapping(yz, xk)
+    dycore.set_x_tile(*tile)
+    mapping = dycore.get_lane_mapping()
+    coupler.load_fields(f)
+    if not mode_a:
+        coupler.set_option("balance_hydrostasis_with_gravity", False)
+    dycore.declare_current_profile_as_hydrostatic(coupler)
+    ncyc = []
+    for crm_dt in (2.0, 0.7):
+        coupler.set_option("crm_dt", crm_dt)
+        ncyc.append(dycore.timeStep(coupler))
+    torch.cuda.synchronize()
+    rows = dycore.debug_fct_rows()
+    out = coupler.dump_fields()
+    dycore.finalize(coupler)
+    return ncyc, out, mapping, rows
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(case):
+    f, xlen, ylen = _fields(case)
+    tiles = CASES[case][-1]
+    n0, ref, m0, rows = _run(case, f, xlen, ylen, "member", "sweep")
+    assert not m0["yz_flat"] and not m0["x_tiles"]
+    if CASES[case][-2]:
+        assert 0 < rows[0] <= rows[1] and rows[2], rows     # the limiter acted on vapour in the last stage: the sparse paths ran
+    variants = [("flat", "sweep", (0, 0, 0)), ("member", "tile", (0, 0, 0)), ("flat", "tile", (0, 0, 0))]
+    variants += [("flat", "tile", t) for t in tiles]
+    for yz, xk, tile in variants:
+        n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile)
+        assert m1["yz_flat"] == (yz == "flat") and m1["x_tiles"] == (xk == "tile"), m1
+        assert n0 == n1
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+            assert np.isfinite(got[k]).all(), (yz, xk, tile, k)
+            assert np.array_equal(ref[k], got[k]), (yz, xk, tile, m1, k, np.abs(ref[k] - got[k]).max())
+
+
+def test_small_ensemble_defaults_are_flat_and_tile_and_large_ones_member_and_sweep():
+    for case, small in (("nens1_c2grid_slab", True), ("nens2_c1_like", True), ("nens40_vapour_limited_B", True),
+                        ("nens128_nt4_rows", False), ("nens70_ragged_vapour_limited", False)):
+        f, xlen, ylen = _fields(case)
+        _, _, m, _ = _run(case, f, xlen, ylen, "auto", "auto")
+        assert m["yz_flat"] == small and m["x_tiles"] == small, (case, m)
+
+
+def test_nens2_flat_lanes_equal_the_same_members_tiled_to_64_member_lanes():
+    """the (x, member)-lane path against the member-lane path on a tiled input"""
+    case = "nens2_c1_like"
+    f, xlen, ylen = _fields(case)
+    n0, a, m0, _ = _run(case, f, xlen, ylen, "auto", "auto")
+    assert m0["yz_flat"] and m0["x_tiles"]
+    f64 = {k: np.ascontiguousarray(np.tile(v, 32)) for k, v in f.items()}     # members 0,1,0,1,...
+    n1, b, m1, _ = _run(case, f64, xlen, ylen, "auto", "auto", nens_override=64)
+    assert not m1["yz_flat"] and not m1["x_tiles"]
+    assert n0 == n1
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.array_equal(a[k], b[k][..., :2]) and np.array_equal(a[k], b[k][..., 62:]), k
+
+
+def _lane_use(nens, nx, ny, nz):
+    """fraction of launched lanes that are active in the three kinds of kernels of a small-ensemble stage (from the geometry)"""
+    from pam_amd import Dycore, PamCoupler
+    zint = idz.uniform_interfaces(nz, 1000.0 * nz)
+    coupler = PamCoupler("cuda:0")
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(1000.0 * nx, 1000.0 * max(ny, 1), zint)
+    coupler.add_tracer("water_vapor", "", True, True)
+    d = Dycore()
+    d.init(coupler)
+    m = d.get_lane_mapping()
+    d.finalize(coupler)
+    coupler.dm.finalize()
+    assert m["yz_flat"] and m["x_tiles"]
+    g = m["tile"]
+    t = g["W"] * (g["tc"] + 2 * g["halo"]) * g["lpb"]
+    x_use = t / (64.0 * -(-t // 64))
+    row = nx * nens
+    items_y, items_z = nz * row, ny * row
+    y_use = items_y / (64.0 * -(-items_y // 64)) if ny > 1 else 1.0
+    z_use = items_z / (64.0 * -(-items_z // 64))
+    return x_use, y_use, z_use, g
+
+
+@pytest.mark.parametrize("nens,nx,ny,nz", [(1, 250, 1, 50), (1, 65, 1, 50), (1, 64, 1, 50), (2, 32, 32, 60), (1, 32, 32, 60), (3, 32, 4, 20),
+                                           (8, 32, 32, 60), (32, 32, 32, 60), (33, 32, 1, 60), (63, 32, 1, 60), (7, 100, 3, 10), (1, 96, 1, 60)])
+def test_wavefronts_are_at_least_90_percent_full_when_nx_times_nens_reaches_64(nens, nx, ny, nz):
+    x_use, y_use, z_use, g = _lane_use(nens, nx, ny, nz)
+    # x tiles and y sweeps: rows shorter than a wavefront are packed (lines per workgroup; levels in the flat index space), so they are
+    # full whatever nx*nens is.  The z sweep has ny*nx*nens columns in ALL: its only loss is the last, partial wavefront -- below 10 %
+    # from 576 columns on; a 2-D CRM of 65 columns (the reference's CI input) is two wavefronts whatever the mapping.
+    assert x_use >= 0.90 and y_use >= 0.90, (x_use, y_use, z_use, g)
+    cols = ny * nx * nens
+    if cols >= 576 or cols % 64 == 0:
+        assert z_use >= 0.90, (z_use, cols)
+    else:
+        assert z_use == cols / (64.0 * -(-cols // 64))
