@@ -105,20 +105,72 @@ def launch_ranks(n):
         raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
 
-def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
-    """Oracle timed on the host cores on a bounded sample (a few ensemble members of the same grid)."""
+def launch_cpp(args):
+    """--launcher cpp: the same workload through the C++ host path -- examples/driver --gpus N: one host thread, one coupler and one
+    dycore handle per device, the dt minimum over N host doubles, no collective library and no Python in the timed region.  This
+    process only writes the synthetic input (16 distinct members; the driver tiles them, +t mK on temp per tile, as Job does) and
+    turns the driver's wall time into the bench line."""
+    import struct
+    import tempfile
     import numpy as np
-    from oracle import awfl_oracle as ao
-    nens_pg, nx, ny = CONFIGS[cfg_name][:3]
+    from pam_amd import idealized as idz
+    nens_pg, nx, ny, trname, cname, crm_dt, desc = CONFIGS[args.config][:7]
+    nz, grid, xlen_cfg = CONFIGS[args.config][7:] or (60, "l60", None)
+    if args.nens > 0:
+        nens_pg = args.nens
+    nens_total = nens_pg if args.scaling == "strong" else nens_pg * args.gpus
+    nens_gen = min(16, nens_total)
+    if nens_total % nens_gen:
+        raise SystemExit("bench.py --launcher cpp: the ensemble (%d) must be a multiple of %d generated members" % (nens_total, nens_gen))
+    tracers = {"none": idz.TRACERS_NONE, "kessler_shoc": idz.TRACERS_KESSLER_SHOC, "p3_shoc": idz.TRACERS_P3_SHOC}[trname]
+    consts = {"default": idz.CONSTS_DEFAULT, "p3": idz.CONSTS_P3}[cname]
+    zint = idz.l60_interfaces() if grid == "l60" else idz.uniform_interfaces(nz, 20000.0)
+    xlen = xlen_cfg if xlen_cfg else nx * 1000.0
+    ylen = ny * 1000.0 if ny > 1 else xlen
+    f = idz.supercell_fields(nens_gen, nx, ny, nz, zint, consts=consts, tracers=tracers, magnitude=0.1, id0=0)
+    if len(tracers) > 1:
+        idz.add_tracer_blobs(f, tracers, xlen, ylen, zint)
+    if args.limiter:
+        idz.carve_dry_air(f, tracers, spread=args.limiter > 1)
     names, pos, mass, idwv = idz.tracer_flags(tracers)
-    lib, kind_note = None, "generic -O2 build"
-    try:   # native-tuned build of the same source for a fair CPU number
-        out = os.path.join("/tmp", "libawfl_oracle_native_%d.so" % os.getpid())
-        ao.build(out=out, archflags="-O3 -march=native")
-        lib = ao.load(out)
-        kind_note = "gcc -O3 -march=native -ffp-contract=off"
-    except Exception:
-        lib = ao.load()
+    driver = os.path.join(ROOT, "examples", "driver")
+    if not os.path.exists(driver):
+        raise SystemExit("bench.py --launcher cpp: examples/driver is missing (python -c 'import __graft_entry__ as g; g.build()')")
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.bin")
+        with open(inp, "wb") as fh:
+            fh.write(struct.pack("<8q", nens_gen, nx, ny, nz, len(tracers), 0, 1, 1))
+            fh.write(struct.pack("<3d", xlen, ylen, crm_dt))
+            fh.write(struct.pack("<6d", *[consts[k] for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav")]))
+            fh.write(np.asarray(zint, dtype="<f8").tobytes())
+            fh.write(bytes(bytearray(v for t in range(len(tracers)) for v in (int(pos[t]), int(mass[t])))))
+            fh.write(struct.pack("<q", idwv))
+            for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+                fh.write(f[k].astype("<f8").tobytes())
+            for t in range(len(tracers)):
+                fh.write(f["tracers"][t].astype("<f8").tobytes())
+        r = subprocess.run([driver, "--gpus", str(args.gpus), "--tile", str(nens_total // nens_gen), "--bench", str(args.steps),
+                            str(args.warmup), inp, "-"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("bench.py --launcher cpp: examples/driver failed: %s" % r.stderr[-2000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    updates = float(nens_total) * nz * ny * nx * d["substeps"]
+    out = {"metric": "cell-updates/sec (AWFL dycore step)", "value": updates / d["seconds"], "unit": "cell-updates/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": d["seconds"] / args.steps * 1e3,
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": desc % (nens_total // args.gpus), "nens_per_gpu": nens_total // args.gpus, "nens_total": nens_total,
+                      "nx": nx, "ny": ny, "nz": nz, "num_tracers": len(tracers), "crm_dt": crm_dt,
+                      "substeps_per_step": d["substeps"] / float(args.steps), "parallelism": "nens-shard x%d" % args.gpus,
+                      "launcher": "cpp: examples/driver --gpus %d (one host thread + one dycore handle per device; dt = min over %d host "
+                                  "doubles; no collective library)" % (args.gpus, args.gpus),
+                      "collective": None, "ranks_seen": d["ranks"], "devices_seen": d["devices"], "limiter_input": args.limiter},
+           "roofline": None, "cpu_baseline": None,
+           "note": "roofline / cpu_baseline are measured by the default (Python) launcher of the same library"}
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def _host_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -130,27 +182,106 @@ def cpu_baseline(idz, cfg_name, nz, zint, tracers, consts, xlen, ylen, crm_dt):
             cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
     except Exception:
         pass
-    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
+    return cores
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
+def _oracle_lib():
+    """the oracle built with -O3 -march=native for a fair CPU number (once per run; shared by the worker processes)"""
+    from oracle import awfl_oracle as ao
+    out = os.path.join("/tmp", "libawfl_oracle_native_%d.so" % os.getuid())
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(ROOT, "oracle", "awfl_oracle.c")):
+            ao.build(out=out, archflags="-O3 -march=native")
+        return ao.load(out), "gcc -O3 -march=native -ffp-contract=off"
+    except Exception:
+        return ao.load(), "generic -O2 build"
+
+
+def cpu_worker(cfg_name, nens, threads):
+    """one timed oracle timeStep on `nens` members of the config's grid with `threads` OpenMP threads -> cell-updates/s
+    (a process of its own: `python bench.py --cpu-worker cfg,nens,threads`)"""
+    import numpy as np
+    from oracle import awfl_oracle as ao
+    import importlib.util     # pam_amd/idealized.py is numpy-only: load it by path, without the package (which imports torch)
+    spec = importlib.util.spec_from_file_location("pam_amd_idealized", os.path.join(ROOT, "pam_amd", "idealized.py"))
+    idz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(idz)
+    nens_pg, nx, ny, trname, cname, crm_dt = CONFIGS[cfg_name][:6]
+    nz, grid, xlen_cfg = CONFIGS[cfg_name][7:] or (60, "l60", None)
+    tracers = {"none": idz.TRACERS_NONE, "kessler_shoc": idz.TRACERS_KESSLER_SHOC, "p3_shoc": idz.TRACERS_P3_SHOC}[trname]
+    consts = {"default": idz.CONSTS_DEFAULT, "p3": idz.CONSTS_P3}[cname]
+    zint = idz.l60_interfaces() if grid == "l60" else idz.uniform_interfaces(nz, 20000.0)
+    xlen = xlen_cfg if xlen_cfg else nx * 1000.0
+    ylen = ny * 1000.0 if ny > 1 else xlen
+    names, pos, mass, idwv = idz.tracer_flags(tracers)
+    lib, note = _oracle_lib()
     try:
         import ctypes
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
     except Exception:
         pass
-    nens = 64 if ny > 1 else 1024      # ~10-30 s of host work on the GPU box's cores
     f = idz.supercell_fields(nens, nx, ny, nz, zint, consts=consts, tracers=tracers, magnitude=0.1)
     if len(tracers) > 1:
         idz.add_tracer_blobs(f, tracers, xlen, ylen, zint)
     o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), pos, mass, idwv, consts=consts, lib=lib)
     o.declare_current_profile_as_hydrostatic(f)
-    dt = 2.0
     o.time_step(copy.deepcopy(f), 0.2)      # warm-up (thread pool, page faults)
     t0 = time.time()
-    ncyc, _ = o.time_step(f, dt)
+    ncyc, _ = o.time_step(f, crm_dt)
     el = time.time() - t0
-    upd = nens * nz * ny * nx * ncyc
-    return {"value": upd / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
-            "sample": "oracle/awfl_oracle.c (%s, OpenMP %d threads), nens=%d of the same %dx%dx%d grid, one timeStep of "
-                      "crm_dt=%.2g s = %d sub-steps, %.1f s wall" % (kind_note, threads, nens, nx, ny, nz, dt, ncyc, el)}
+    return {"value": nens * nz * ny * nx * ncyc / el, "seconds": el, "substeps": ncyc, "nens": nens, "threads": threads, "build": note,
+            "grid": "%dx%dx%d" % (nx, ny, nz)}
+
+
+def _spawn_cpu_workers(cfg_name, nens, threads, nproc):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%s,%d,%d" % (cfg_name, nens, threads)],
+                              env=env, stdout=subprocess.PIPE) for _ in range(nproc)]
+    outs = []
+    for pr in procs:
+        o, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("cpu worker failed")
+        outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+    return outs
+
+
+def cpu_baseline(cfg_name):
+    """the CPU path timed on THIS host on a bounded sample of the same workload -- (a) one core, (b) P
+    processes x 1 core, each with its own members (how E3SM spreads CRMs over MPI ranks), (c) one process, OpenMP over the flux
+    loop.  The program is the oracle (oracle/awfl_oracle.c, a C restatement of the reference algorithm: kind "port"); the
+    reference itself needs YAKL, an absent submodule, and cannot be built here."""
+    nens_pg, nx, ny = CONFIGS[cfg_name][:3]
+    cores = _host_cores()
+    _oracle_lib()                                              # build once, before the workers race for it
+    n1 = 2 if ny > 1 else 32                                   # ~10 s of one core
+    one = _spawn_cpu_workers(cfg_name, n1, 1, 1)[0]
+    many = _spawn_cpu_workers(cfg_name, n1, 1, cores)
+    nomp = 64 if ny > 1 else 1024
+    omp = _spawn_cpu_workers(cfg_name, nomp, cores, 1)[0]
+    agg = sum(m["value"] for m in many)
+    model = _cpu_model()
+    best = max(agg, omp["value"])
+    return {"value": best, "unit": "cell-updates/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "one_core": {"value": one["value"], "cores": 1, "seconds": one["seconds"], "nens": n1},
+            "processes_x_1_core": {"value": agg, "processes": cores, "cores": cores, "seconds_max": max(m["seconds"] for m in many),
+                                   "nens_per_process": n1},
+            "openmp": {"value": omp["value"], "threads": cores, "seconds": omp["seconds"], "nens": nomp},
+            "sample": "oracle/awfl_oracle.c (%s; a port of the reference algorithm: the reference needs YAKL, an absent submodule) on %s, "
+                      "%s grid, one timeStep = %d sub-steps: 1 core x %d members %.1f s; %d processes x 1 core x %d members %.1f s; "
+                      "OpenMP %d threads x %d members %.1f s; `value` = the better of the two %d-core figures"
+                      % (one["build"], model, one["grid"], one["substeps"], n1, one["seconds"], cores, n1, max(m["seconds"] for m in many),
+                         cores, nomp, omp["seconds"], cores)}
 
 
 class Job:
@@ -207,6 +338,8 @@ class Job:
         self.lds_floor = args.lds_floor
         if args.chunks >= 0:
             dycore.set_ensemble_chunks(args.chunks, args.lds_floor)
+        if args.indep:
+            dycore.set_range_schedule(True)
         nens_gen = min(16, nens_pg)
         f = idz.supercell_fields(nens_gen, nx, ny, self.nz, self.zint, consts=self.consts, tracers=self.tracers,
                                  magnitude=0.1, id0=rank * 1000)
@@ -307,12 +440,13 @@ def stage_rooflines(job, alone):
         # mass flux when further tracers follow))
         state = (7 * pb + (2.0 / 3.0) * 6 * pb + nyz * 6 * fb + fb + 7 * pb + 2 * fb + (fb if nt > 1 else 0), cells * (7 * poly + 6 * 60.0 + 40.0))
         # sweeps of the further tracers.  Phase 1 (FCT multipliers): per tracer the stage input, its y/z faces and seed, per pair
-        # the face mass flux; writes only multipliers of limited rows.  Phase 2 (complete update): per tracer the stage input, the
-        # sub-step start, its y/z faces (+ multipliers in flagged neighbourhoods), per pair the mass flux and the three densities;
-        # writes the new value and seed
+        # the face mass flux; writes the multiplier of EVERY cell (own_multiplier_cell<DENSE>: a complete field).  Phase 2 (complete
+        # update): per tracer the stage input, the sub-step start, its y/z faces and the multipliers of its own line (those of the
+        # y/z neighbours are re-reads of other lines' values: L2-shared, not counted), per pair the mass flux and the three
+        # densities; writes the new value and seed
         ntr, npair = nt - 1, nt // 2
-        ph1 = (ntr * (pb + nyz * fb + fb) + npair * fb, cells * ntr * (poly + 20.0))
-        ph2 = (ntr * (pb + (2.0 / 3.0) * pb + nyz * fb + pb + fb) + npair * (fb + (2 + 2.0 / 3.0) * pb), cells * ntr * (poly + 60.0))
+        ph1 = (ntr * (pb + nyz * fb + fb + fb) + npair * fb, cells * ntr * (poly + 20.0))
+        ph2 = (ntr * (pb + (2.0 / 3.0) * pb + nyz * fb + fb + pb + fb) + npair * (fb + (2 + 2.0 / 3.0) * pb), cells * ntr * (poly + 60.0))
         if "xtr1" in alone:
             acct["xupd"], acct["xtr1"] = state, ph1
         else:
@@ -415,6 +549,10 @@ def measure_roofline(job, args, default_workload=True):
     hbm_frac = achieved / HBM_PEAK_GBS
     bound = "fp64-valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
     roofline = {"bound": bound, "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "frac_definition": "frac = algorithmic bytes of a WHOLE tendency stage (SURVEY 8d: 64*(5+NT) B per cell-update / 3) divided by the "
+                                   "time of the stage's dominant kernel ALONE, over the 8 TB/s HBM peak: it charges one kernel with the whole "
+                                   "stage's bytes and so flatters the stage.  stage_frac = the same bytes over ALL stage kernels back to back -- "
+                                   "the figure to quote for the stage; value * 64*(5+NT) B / peak is the whole step",
                 "unit": "GB/s", "frac": hbm_frac, "hbm_frac": hbm_frac, "traffic": traffic, "traffic_note": tnote,
                 "ms_per_stage": alone[dom]["total_ms"] / nstage, "launches_per_stage": alone[dom]["launches"] / nstage,
                 "alg_bytes_per_launch": alg_bytes,
@@ -428,6 +566,73 @@ def measure_roofline(job, args, default_workload=True):
                 "stage_traffic_ratio": (stage_traffic / alg_bytes) if stage_traffic else None,
                 "valu": valu}
     return roofline, kernels, kernel_rooflines
+
+
+def modules_timing(torch, dev):
+    """the coupler modules around the dycore at the C2 grid (1024 x 32x32x60), HIP events around the C-ABI calls:
+    ms per call and the bytes each must move (fields read + written, once)."""
+    from pam_amd import PamCoupler, Microphysics, modules, idealized as idz
+    nens, nx, ny, nz = 1024, 32, 32, 60
+    zint = idz.l60_interfaces()
+    cells = nens * nx * ny * nz
+    out = {"grid": "1024 x 32x32x60 (C2)", "unit": "ms per call"}
+
+    def timeit(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    f = idz.supercell_fields(16, nx, ny, nz, zint, tracers=(("water_vapor", True, True),), magnitude=0.5)
+    c = PamCoupler(dev)
+    c.set_option("crm_dt", 2.0)
+    c.set_option("gcm_physics_dt", 1200.0)
+    c.allocate_coupler_state(nz, ny, nx, nens)
+    c.set_grid(nx * 1000.0, ny * 1000.0, zint)
+    micro = Microphysics()
+    micro.init(c)
+    dm = c.get_data_manager_device_readwrite()
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+        dm.get(k).copy_(torch.from_numpy(f[k]).to(dev).repeat(1, 1, 1, nens // 16))
+    dm.get("water_vapor").copy_(torch.from_numpy(f["tracers"][0]).to(dev).repeat(1, 1, 1, nens // 16) * 1.3)
+    dm.get("precip_liquid").copy_(dm.get("density_dry") * 1e-3)
+    t = timeit(lambda: micro.timeStep(c))
+    out["kessler_time_step"] = {"ms": t, "bytes": cells * 26 * 8.0, "GBps": cells * 26 * 8.0 / t / 1e6,
+                                "note": "prep kernel 6 reads + 5 writes, column kernel 11 reads + 4 writes per cell (1 sub-cycle)"}
+    t = timeit(lambda: modules.sponge_layer(c))
+    nsp = 5                   # sponge_layer.h:8-95: the top 5 of 60 levels
+    out["sponge_layer"] = {"ms": t, "bytes": nens * nx * ny * nsp * 4 * 3 * 8.0, "GBps": nens * nx * ny * nsp * 4 * 3 * 8.0 / t / 1e6,
+                           "note": "u, v, w, T of the top 5 levels: read for the mean, read + written for the relaxation"}
+    del micro, dm, c
+    torch.cuda.empty_cache()
+    c = PamCoupler(dev)
+    c.set_option("crm_dt", 2.0)
+    c.set_option("gcm_physics_dt", 1200.0)
+    c.allocate_coupler_state(nz, ny, nx, nens)
+    c.set_grid(nx * 1000.0, ny * 1000.0, zint)
+    for n in ("water_vapor", "cloud_water", "ice", "cloud_water_num", "ice_num", "rain_num"):
+        c.add_tracer(n, "", True, n in ("water_vapor", "cloud_water", "ice"))
+    dm = c.get_data_manager_device_readwrite()
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+        dm.get(k).copy_(torch.from_numpy(f[k]).to(dev).repeat(1, 1, 1, nens // 16))
+    dm.get("water_vapor").copy_(torch.from_numpy(f["tracers"][0]).to(dev).repeat(1, 1, 1, nens // 16))
+    for k in ("gcm_density_dry", "gcm_temp", "gcm_water_vapor"):
+        src = {"gcm_density_dry": "density_dry", "gcm_temp": "temp", "gcm_water_vapor": "water_vapor"}[k]
+        dm.get(k).copy_(dm.get(src).mean(dim=(1, 2)) * 1.01)
+    modules.compute_gcm_forcing_tendencies(c)
+    t = timeit(lambda: modules.compute_gcm_forcing_tendencies(c), 3)
+    out["compute_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 5 * 8.0, "GBps": cells * 5 * 8.0 / t / 1e6,
+                                             "note": "column means of rho_d, u, v, T, rho_v: 5 fields read"}
+    t = timeit(lambda: modules.apply_gcm_forcing_tendencies(c), 3)
+    out["apply_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 10 * 8.0, "GBps": cells * 10 * 8.0 / t / 1e6,
+                                           "note": "5 fields read and written (hole filling included)"}
+    del dm, c
+    torch.cuda.empty_cache()
+    return out
 
 
 def worker(args):
@@ -509,7 +714,7 @@ def worker(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(idz, args.config, job.nz, job.zint, job.tracers, job.consts, job.xlen, job.ylen, job.crm_dt)
+            cpu = cpu_baseline(args.config)
         except Exception as e:   # the baseline is a reported extra; never fail the bench line for it
             cpu = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
@@ -523,21 +728,48 @@ def worker(args):
     others = None
     if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs and not args.limiter:
         others = {}
-        for c in ("c3", "c4"):
+
+        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, roofline_profile=True):
             try:
-                j = Job(c, args, dev, 0, 1)
-                u, el, sub = j.timed(3, 1)
-                others[c] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / 3 * 1e3, "workload": j.desc % j.nens,
-                             "num_tracers": j.nt, "substeps_per_step": sub / 3.0,
-                             "hbm_frac": u / el * 64.0 * (5 + j.nt) / 1e9 / HBM_PEAK_GBS}
+                a2 = copy.copy(args)
+                a2.limiter = limiter
+                j = Job(cfg, a2, dev, 0, 1, nens)
+                u, el, sub = j.timed(steps, 1)
+                rows = j.dycore.debug_fct_rows()
+                others[key] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / steps * 1e3, "workload": j.desc % j.nens,
+                               "num_tracers": j.nt, "substeps_per_step": sub / float(steps),
+                               "hbm_frac": u / el * 64.0 * (5 + j.nt) / 1e9 / HBM_PEAK_GBS,
+                               "fct_rows_flagged_last_stage": rows[0], "fct_rows": rows[1]}
+                if note:
+                    others[key]["note"] = note
                 if not args.no_kernel_timing:
-                    rf, _, krf = measure_roofline(j, args)
-                    others[c]["roofline"] = rf
-                    others[c]["kernel_rooflines"] = krf
+                    rf, _, krf = measure_roofline(j, a2, default_workload=roofline_profile)
+                    others[key]["roofline"] = rf
+                    others[key]["kernel_rooflines"] = krf
                 j.close()
                 del j
             except Exception as e:
-                others[c] = {"value": None, "error": repr(e)}
+                others[key] = {"value": None, "error": repr(e)}
+        run_other("c3", "c3")
+        run_other("c4", "c4")
+        # the N = 1 denominators of the two strong-scaling rows and the per-GPU workload of C2 over 8 GPUs
+        run_other("c4_full", "c4", nens=4096, steps=2, roofline_profile=False,
+                  note="BASELINE config C4 whole (nens = 4096, NT = 10) on ONE GPU: what c4 (one GPU's 512-member shard) is 1/8 of")
+        run_other("c2_shard128", "c2", nens=128, roofline_profile=False,
+                  note="what one GPU runs of C2 strong-scaled over 8 GPUs (1024 / 8 members)")
+        # the limiter acting on water vapour itself (NT = 1): the flagged paths of the state pass and the fix-up pass
+        run_other("c2_limiter1", "c2", limiter=1, steps=2, roofline_profile=False,
+                  note="C2 with dry slabs in the vapour at the same place in every member (--limiter 1)")
+        run_other("c2_limiter2", "c2", limiter=2, steps=2, roofline_profile=False,
+                  note="C2 with dry slabs at member-dependent places: nearly every row of 64 members flagged (--limiter 2)")
+        # small ensembles (flat lanes + tile kernels): the reference's own input shape and the C2 grid with one member
+        run_other("ref_nens1", "ref", roofline_profile=False, steps=5,
+                  note="the shape of the reference's input file (input_pama.yaml: 250x1, nens = 1, 50 levels), Kessler + SHOC tracers")
+        run_other("c2grid_nens1", "c2", nens=1, roofline_profile=False, steps=5, note="C2's 32x32x60 grid with ONE member")
+        try:
+            others["modules"] = modules_timing(torch, dev)
+        except Exception as e:
+            others["modules"] = {"error": repr(e)}
 
     if rank == 0:
         out = {"metric": "cell-updates/sec (AWFL dycore step)", "value": value, "unit": "cell-updates/s",
@@ -582,12 +814,26 @@ def main():
     ap.add_argument("--xkernels", default="auto", choices=("auto", "sweep", "tile"),
                     help="x direction: a wavefront per line span / a lane per cell with LDS exchange (auto: tile when nens < 64)")
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
+    ap.add_argument("--launcher", default="python", choices=("python", "cpp"),
+                    help="python: one process per GPU, dt exchange through torch.distributed (RCCL); cpp: examples/driver --gpus N, one "
+                         "host thread per GPU in ONE process, dt exchange over N host doubles")
+    ap.add_argument("--indep", type=int, default=0, help="1: with --chunks > 1, every member range runs its stage on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
+    if args.cpu_worker:
+        c, n, t = args.cpu_worker.split(",")
+        print(json.dumps(cpu_worker(c, int(n), int(t))))
+        return
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.launcher == "cpp":
+        if "WORLD_SIZE" in os.environ and int(os.environ.get("RANK", "0")) != 0:
+            return                      # under torch.distributed.run: rank 0 alone drives every device through the C++ path
+        launch_cpp(args)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus)
         return

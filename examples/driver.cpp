@@ -92,7 +92,10 @@ struct Job {
   std::vector<real> zint;
   std::vector<unsigned char> flags;
   int64_t idWV;
-  std::vector<std::vector<real>> fields;     // density_dry, uvel, vvel, wvel, temp, tracers...: (nz,ny,nx,nens) each, in and out
+  int nens_in = 0;                           // members in the input file; member e of the run is input member e % nens_in, tile e / nens_in
+  std::vector<std::vector<real>> raw;        // the input: density_dry, uvel, vvel, wvel, temp, tracers...: (nz,ny,nx,nens_in) each
+  bool want_output = true;
+  std::vector<std::vector<real>> fields;     // the output, same order: (nz,ny,nx,nens) each (only when want_output)
   std::vector<real> precl;                   // (ny,nx,nens), Kessler only
   int bench_steps = 0, bench_warmup = 0;
 };
@@ -129,8 +132,12 @@ static void run_rank(Job &J, int rank, int world, int ndev, HostMin &hmin, Bench
   std::vector<std::string> names = {"density_dry", "uvel", "vvel", "wvel", "temp"};
   for (auto &n : coupler.get_tracer_names()) names.push_back(n);
   for (size_t f = 0; f < names.size(); f++) {                              // this rank's members of every field
-    const real *src = J.fields[f].data();
-    for (size_t c = 0; c < ncol; c++) std::memcpy(&buf[c * ne], &src[c * J.nens + lo], ne * sizeof(real));
+    const real *src = J.raw[f].data();
+    for (size_t c = 0; c < ncol; c++)
+      for (int e = 0; e < ne; e++) {
+        const int eg = lo + e, tile_i = eg / J.nens_in;                    // tile t gets +t mK on temp: no two CRMs are equal
+        buf[c * ne + e] = src[c * J.nens_in + (eg - tile_i * J.nens_in)] + ((f == 4) ? 1.0e-3 * tile_i : 0.0);
+      }
     if (hipMemcpy(dm.get<real, 4>(names[f]).data(), buf.data(), ncell * sizeof(real), hipMemcpyHostToDevice) != hipSuccess) endrun("memcpy");
   }
 #ifdef PAMC_DYCORE
@@ -188,12 +195,12 @@ static void run_rank(Job &J, int rank, int world, int ndev, HostMin &hmin, Bench
     for (int s = 0; s < J.nsteps; s++) one_step();
   }
   if (hipDeviceSynchronize() != hipSuccess) endrun("device error");
-  for (size_t f = 0; f < names.size(); f++) {
+  for (size_t f = 0; f < names.size() && J.want_output; f++) {
     if (hipMemcpy(buf.data(), dm.get<real, 4>(names[f]).data(), ncell * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) endrun("memcpy");
     real *dst = J.fields[f].data();
     for (size_t c = 0; c < ncol; c++) std::memcpy(&dst[c * J.nens + lo], &buf[c * ne], ne * sizeof(real));
   }
-  if (J.with_micro) {
+  if (J.with_micro && J.want_output) {
     const size_t n2 = (size_t)ny * nx;
     if (hipMemcpy(buf.data(), dm.get<real, 3>("precl").data(), n2 * ne * sizeof(real), hipMemcpyDeviceToHost) != hipSuccess) endrun("memcpy");
     for (size_t c = 0; c < n2; c++) std::memcpy(&J.precl[c * J.nens + lo], &buf[c * ne], ne * sizeof(real));
@@ -229,17 +236,17 @@ int main(int argc, char **argv) {
   in.read((char *)J.flags.data(), J.flags.size());
   in.read((char *)&J.idWV, sizeof(J.idWV));
   const size_t ncol = (size_t)J.nz * J.ny * J.nx;
-  J.fields.assign(5 + J.nt, std::vector<real>());
-  std::vector<real> raw(ncol * nens_in);
+  J.nens_in = nens_in;
+  J.raw.assign(5 + J.nt, std::vector<real>(ncol * nens_in));
   for (int f = 0; f < 5 + J.nt; f++) {
-    in.read((char *)raw.data(), raw.size() * sizeof(real));
+    in.read((char *)J.raw[f].data(), J.raw[f].size() * sizeof(real));
     if (!in) die("short input file");
-    J.fields[f].resize(ncol * J.nens);
-    for (size_t c = 0; c < ncol; c++)
-      for (int t = 0; t < tile; t++)
-        for (int e = 0; e < nens_in; e++) J.fields[f][c * J.nens + (size_t)t * nens_in + e] = raw[c * nens_in + e] + ((f == 4) ? 1.0e-3 * t : 0.0);
   }
-  J.precl.assign((size_t)J.ny * J.nx * J.nens, 0.0);
+  J.want_output = std::string(argv[a + 1]) != "-";        // "-": no output file (bench runs of large ensembles)
+  if (J.want_output) {
+    J.fields.assign(5 + J.nt, std::vector<real>(ncol * J.nens));
+    J.precl.assign((size_t)J.ny * J.nx * J.nens, 0.0);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) die("no HIP device");
   HostMin hmin(gpus);
@@ -267,8 +274,10 @@ int main(int argc, char **argv) {
                 "\"num_tracers\": %d, \"steps\": %d, \"warmup\": %d, \"seconds\": %.9g, \"substeps\": %ld}\n",
                 gpus, ndev, J.nens, J.nx, J.ny, J.nz, J.nt, J.bench_steps, J.bench_warmup, sec, bench[0].substeps);
   }
-  std::ofstream out(argv[a + 1], std::ios::binary);
-  for (auto &f : J.fields) out.write((char *)f.data(), f.size() * sizeof(real));
-  if (J.with_micro) out.write((char *)J.precl.data(), J.precl.size() * sizeof(real));
+  if (J.want_output) {
+    std::ofstream out(argv[a + 1], std::ios::binary);
+    for (auto &f : J.fields) out.write((char *)f.data(), f.size() * sizeof(real));
+    if (J.with_micro) out.write((char *)J.precl.data(), J.precl.size() * sizeof(real));
+  }
   return 0;
 }

@@ -153,6 +153,10 @@ int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
  * workgroup when chunks > 1 (the kernel itself uses none: it caps the flux kernel's residency per CU so that another range's
  * blocks can co-reside; default 0 = no cap).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
+/* Fused stage with several member ranges: independent = 1 runs every range's whole stage on the range's own stream (no shared
+ * compute stream, no events between ranges), so that launches which do not fill the chip overlap their ramp-up and drain phases
+ * with another range's kernels; 0 (default): the polynomial kernels of all ranges back to back on one stream.  Same results. */
+int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent);
 
 /* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + update of the state and of the first tracer (incl.
  * its FCT multiplier) -> [FCT multiplier of further tracers] -> pointwise tail (further tracers, the first tracer where the
@@ -174,6 +178,10 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
  * completes (a tile shorter than the line gets one halo row on each side), lines per workgroup (whole-line tiles only). */
 int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels);
 int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group);
+/* With flat y/z lanes the y and z fluxes of a stage run as ONE tile kernel as well (a lane per cell; rows of a tile follow the sweep
+ * direction, the lanes of a row are contiguous (x, member) / (y, x, member) items): enable = 0 falls back to flat-lane SWEEPS (a lane
+ * per item walks its line serially); cells per y tile / levels per z tile, 0 = automatic.  Same bits either way. */
+int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile);
 /* the resolved mapping: flat y/z lanes, x tile kernels, pointwise kernels on a grid flat over every cell (0/1 each) and the tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]);
@@ -182,8 +190,9 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
 /* name: "prim0","prim1","prim2","flux_x","flux_y","flux_z","seed","mult". */
 int pam_amd_awfl_debug_get_buffer(pam_amd_awfl_t *h, const char *name, double **device_ptr, size_t *nelem);
 /* Row flags of the FCT limiter (a row = (tracer, cell, 64 consecutive members)) as the MOST RECENT tendency
- * stage left them: rows in which some member was limited in that stage, all rows, and the "some row was flagged" word (fused
- * stage: some row of the FIRST tracer -- the word the fix-up pass looks at; three-kernel stage: of any tracer).
+ * stage left them: rows in which some member was limited in that stage, all rows, and the "some row was flagged" words OR-ed over
+ * the member blocks (fused stage: some row of WATER VAPOUR (idWV) in any block of 64 members -- the words the fix-up pass looks at;
+ * three-kernel stage: of any tracer).
  * Synchronises the handle's stream.  Tests use it to prove that a case exercises the limiter's sparse paths. */
 int pam_amd_awfl_debug_fct_rows(pam_amd_awfl_t *h, long long *rows_flagged, long long *rows_total, int *any_flagged);
 /* The device WENO reconstruction on n stencils of 5 values (DEVICE, (n,5)): left[i]/right[i] = value at the left/right edge

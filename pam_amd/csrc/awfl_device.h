@@ -169,15 +169,18 @@ PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
   p = fma(p, f, 2.4022650695910071e-1);
   p = fma(p, f, 6.9314718055994531e-1);
   p = p * f;
-  const int k = (int)kd;
-  const int j = k & 63, n = k >> 6;                         // k = 64 n + j, 0 <= j < 64 (arithmetic shift)
-  const double t2h = T->ex[j].th, t2l = T->ex[j].tl;
-  const double res = ldexp(fma(t2h, p, t2l) + t2h, n);
   // a base that is not positive and finite only occurs in a state that has already blown up: keep the C library's answers
-  // (0 -> 0 and +inf -> +inf for y > 0, the other way round for y < 0; negative or NaN -> NaN)
+  // (0 -> 0 and +inf -> +inf for y > 0, the other way round for y < 0; negative or NaN -> NaN) -- decided BEFORE kd is converted
+  // to an integer (a NaN / infinite kd would be undefined behaviour in the host build of this function)
   if (!(x > 0.0)) return (x == 0.0) ? (y > 0.0 ? 0.0 : INFINITY) : NAN;
   if (!(x < INFINITY)) return y > 0.0 ? INFINITY : 0.0;
-  return res;
+  // (a finite positive x with an exponent product beyond the double range: clamp kd so that the conversion is defined; ldexp
+  // then delivers the overflow / underflow)
+  const double kc = kd > 131072.0 ? 131072.0 : (kd < -131072.0 ? -131072.0 : kd);
+  const int k = (int)kc;
+  const int j = k & 63, n = k >> 6;                         // k = 64 n + j, 0 <= j < 64 (arithmetic shift)
+  const double t2h = T->ex[j].th, t2l = T->ex[j].tl;
+  return ldexp(fma(t2h, p, t2l) + t2h, n);
 }
 
 PAMA_D double pow_pos(const Params &P, double x, double y) { return pow_pos_fast(x, y, P.pw); }
@@ -2217,6 +2220,217 @@ PAMA_D void xtile_tracer_finish(const Params &P, const double *__restrict__ prim
       store_adv_l(P, prim_out, P_TR0 + t, k, lo, v * rrho, v * rrho);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TILE form of the fused stage's y and z sweeps (flux_line_body<DIR, ., DIFF = true>, cell by cell): a lane per CELL.
+// The lanes of a row are W consecutive doubles of the axis that is contiguous across the sweep direction ((x, member) for a y
+// sweep, (y, x, member) for a z sweep), the rows of a tile follow the sweep direction: the stencil neighbours of a lane's cell are
+// the same lane of the rows above and below, sy / sz doubles away in memory.  Every lane builds the ONE polynomial of its cell per
+// quantity, hands the right-edge values to the next row through LDS, forms the fluxes through its LOWER face, and -- for the four
+// state variables that leave as flux differences -- takes the flux of its upper face back from the next row.  Quantities go in
+// groups of FT_NG: group 0 = the acoustic triple (rho*u_n, p, u_n: face mass flux + normal momentum flux), then the other advected
+// state variables, then the tracers (faces only).  Same helpers on the same five values as the sweep: same bits.
+// y tiles are periodic like the x tiles (whole lines, or cells + one halo row per side); z tiles are `tc` levels + one halo row
+// below and above (the ghost levels exist in prim; the walls are faces 0 and nz), a row being exactly one wavefront (W = 64) so
+// that the level's WENO table is fetched with scalar loads as in the sweep.
+// Reference: Dycore.h:387-519 (y and z fluxes), WenoLimiter.h:98-181.
+constexpr int FT_NG = 3;
+struct FTileGeom {
+  int W;       // lanes per row
+  int nch;     // chunks of W lanes of the contiguous axis
+  int tc;      // cells (y) / levels (z) a tile completes
+  int halo;    // y: 0 = whole periodic line, 1 = halo rows; z: always 1
+  int ntl;     // tiles along the sweep direction
+  int lpb;     // y: levels per workgroup (whole-line tiles of short rows); z: 1
+};
+PAMA_HD int ftile_rows(const FTileGeom &G) { return G.tc + 2 * G.halo; }
+PAMA_HD int ftile_threads(const FTileGeom &G) { return G.W * ftile_rows(G) * G.lpb; }
+PAMA_HD FTileGeom ftile_geometry(const Params &P, int dir, int tc_req) {
+  FTileGeom G;
+  const long long plane = (dir == 1) ? (long long)P.nx * P.nens : P.sz;     // contiguous lanes across the sweep direction
+  const int n = (dir == 1) ? P.ny : P.nz;
+  if (dir == 1) {
+    const int nchunk = (int)((plane + 63) / 64);
+    G.W = (int)((plane + nchunk - 1) / nchunk);                              // even chunks of at most 64 lanes
+    G.nch = nchunk;
+    if (tc_req <= 0 && n * G.W <= 256) {                                      // short lines: whole periodic lines, several levels per workgroup
+      G.halo = 0; G.tc = n; G.ntl = 1;
+      G.lpb = 256 / (n * G.W);
+      if (G.lpb < 1) G.lpb = 1;
+      if (G.lpb > P.nz) G.lpb = P.nz;
+    } else {
+      G.halo = 1; G.lpb = 1;
+      int tc = tc_req > 0 ? tc_req : 256 / G.W - 2;
+      if (tc < 2) tc = 2;
+      if (tc > n) tc = n;
+      while (tc > 1 && (tc + 2) * G.W > 1024) tc--;
+      G.ntl = (n + tc - 1) / tc;
+      G.tc = tc_req > 0 ? tc : (n + G.ntl - 1) / G.ntl;
+    }
+  } else {
+    G.W = 64; G.nch = (int)((plane + 63) / 64);
+    G.halo = 1; G.lpb = 1;
+    int tc = tc_req > 0 ? tc_req : 6;
+    if (tc > n) tc = n;
+    if (tc > 14) tc = 14;
+    G.ntl = (n + tc - 1) / tc;
+    G.tc = tc_req > 0 ? tc : (n + G.ntl - 1) / G.ntl;
+  }
+  return G;
+}
+
+struct FLane {
+  bool poly, face, own, pay, wall;     // builds polynomials / forms its lower face / stores that face / stores its cell's differences
+  int slot, slot_l, slot_r;            // LDS slots: own, of the row below (towards lower indices), of the row above
+  int lev, et;                         // z: index of the cell's vertical table (level + 1); member (per-member tables)
+  unsigned o5[5];                      // prim offsets of the cells c-2 .. c+2 along the sweep direction
+  unsigned fo;                         // offset of the lane's lower face / of its cell inside a flux field of this direction
+};
+template <int DIR>
+PAMA_D FLane ftile_lane(const Params &P, const FTileGeom &G, int bx, int by, int tx, int ty, int tz) {
+  static_assert(DIR == 1 || DIR == 2, "y and z sweeps");
+  FLane X;
+  const int rows = ftile_rows(G);
+  const int chunk = bx / G.ntl, tl = bx - chunk * G.ntl;
+  const int c0 = tl * G.tc;
+  const unsigned sz = (unsigned)P.sz, sy = (unsigned)P.sy;
+  X.slot = (tz * rows + ty) * G.W + tx;
+  X.wall = false; X.lev = 0; X.own = false;
+  if (DIR == 1) {
+    const int k = by * G.lpb + tz;
+    const unsigned q = (unsigned)(chunk * G.W + tx);
+    const int tcl = (c0 + G.tc <= P.ny) ? G.tc : P.ny - c0;
+    const int nrow = tcl + 2 * G.halo;
+    const bool valid = k < P.nz && q < (unsigned)P.nx * (unsigned)P.nens && tx < G.W && ty < nrow;
+    const int c = c0 - G.halo + (valid ? ty : G.halo);
+    const int j = c < 0 ? c + P.ny : (c >= P.ny ? c - P.ny : c);
+    X.poly = valid;
+    X.face = valid && (G.halo == 0 || ty >= 1);
+    X.pay = valid && ty >= G.halo && ty < G.halo + tcl;
+    X.own = X.pay;
+    X.slot_l = (ty > 0) ? X.slot - G.W : X.slot + (nrow - 1) * G.W;
+    X.slot_r = (ty < nrow - 1) ? X.slot + G.W : X.slot - (nrow - 1) * G.W;
+    const unsigned kk = valid ? (unsigned)k : 0u, qq = valid ? q : 0u;
+    const unsigned base = (kk + HS) * sz + qq;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+      const int jj = j + s - 2;
+      X.o5[s] = member_offset((int)(base + (unsigned)(jj < 0 ? jj + P.ny : (jj >= P.ny ? jj - P.ny : jj)) * sy));
+    }
+    X.fo = member_offset((int)(kk * sz + (unsigned)j * sy + qq));
+    X.et = (int)(qq % (unsigned)P.nens);
+  } else {
+    const unsigned p = (unsigned)(chunk * G.W + tx);
+    const int tcl = (c0 + G.tc <= P.nz) ? G.tc : P.nz - c0;
+    const int nrow = tcl + 2;
+    const bool valid = p < sz && ty < nrow;
+    const int c = c0 - 1 + (valid ? ty : 1);                                  // -1 .. nz
+    X.poly = valid;
+    X.face = valid && ty >= 1;
+    X.pay = valid && ty >= 1 && ty <= tcl;
+    X.own = X.pay || (valid && ty == tcl + 1 && c0 + tcl == P.nz);            // the top row of the top tile stores face nz
+    X.wall = (c == 0 || c == P.nz);
+    X.slot_l = X.slot - G.W;
+    X.slot_r = X.slot + G.W;
+    const unsigned pp = valid ? p : 0u;
+#pragma unroll
+    for (int s = 0; s < 5; s++) X.o5[s] = member_offset((int)((unsigned)(c + s - 2 + HS) * sz + pp));
+    X.fo = member_offset((int)((unsigned)(c < 0 ? 0 : c) * sz + pp));
+    X.lev = c + 1;
+    X.et = (int)(pp % (unsigned)P.nens);
+  }
+  return X;
+}
+// the polynomial of the lane's cell: uniform-grid constants in y, the level's table in z (scalar loads when the table is the same
+// for every member: a row of a z tile is one wavefront, the level is wave-uniform)
+template <int DIR, bool VZ_PER_ENS>
+PAMA_D void ftile_weno(const Params &P, const FLane &X, const WenoConsts &wc, const double (&u)[5], double &L, double &R) {
+  if (DIR != 2) { weno5_const(u, wc, L, R); return; }
+  if (VZ_PER_ENS) {
+    weno5_table(u, P.vz + (long long)X.lev * VZ_STRIDE * P.nens + X.et, (long long)P.nens, wc, L, R);
+  } else {
+    weno5_table(u, as_constant(P.vz + (long long)uni_int(X.lev) * VZ_STRIDE), 1, wc, L, R);
+  }
+}
+// group 0, A: rho*u_n, p, u_n
+template <int DIR, bool VZ_PER_ENS>
+PAMA_D void ftile_acoustic_polys(const Params &P, const double *__restrict__ prim, const FLane &X, double (&L)[FT_NG], double (&R)[FT_NG]) {
+  const WenoConsts wc = weno_consts();
+  const int ncomp = (DIR == 1) ? P_V : P_W;
+  gc_ptr fr = uni(prim + (long long)P_RHO * P.prim_fs), fn = uni(prim + (long long)ncomp * P.prim_fs), fp = uni(prim + (long long)P_PRES * P.prim_fs);
+  double m[5], p[5], n[5];
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    n[s] = fn[X.o5[s]];
+    m[s] = mul_rn(fr[X.o5[s]], n[s]);
+    p[s] = fp[X.o5[s]];
+  }
+  ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, m, L[0], R[0]);
+  ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, p, L[1], R[1]);
+  ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, n, L[2], R[2]);
+}
+// group 0, B: face mass flux (stored as a face by the lane that owns it) and normal-momentum flux (Dycore.h:341-366,:477-496)
+template <int DIR>
+PAMA_D void ftile_acoustic_face(const Params &P, double *__restrict__ flux, const FLane &X, const double (&L)[FT_NG],
+                                const double (&Rl)[FT_NG], double &ruf, double &fn) {
+  double ppf;
+  acoustic_face(Rl[0], L[0], Rl[1], L[1], (DIR == 2) && X.wall, ruf, ppf);
+  const double val = (ruf > 0.0) ? Rl[2] : L[2];            // upwind (Dycore.h:368)
+  fn = fma(ruf, val, ppf);
+  if (X.own) uniw(flux)[X.fo] = ruf;
+}
+// the advected quantities fa[0..nf) (advected-field indices: 0 u, 1 v, 2 w, 3 theta, 4.. tracers)
+template <int DIR, bool VZ_PER_ENS>
+PAMA_D void ftile_adv_polys(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf,
+                            double (&L)[FT_NG], double (&R)[FT_NG]) {
+  const WenoConsts wc = weno_consts();
+#pragma unroll
+  for (int n = 0; n < FT_NG; n++) {
+    if (n >= nf) { L[n] = R[n] = 0.0; continue; }
+    gc_ptr f = uni(prim + (long long)(P_U + fa[n]) * P.prim_fs);
+    double w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = f[X.o5[s]];
+    ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, w, L[n], R[n]);
+  }
+}
+// their fluxes through the lane's lower face; tracers leave as faces at once, state variables wait for the difference
+template <int DIR>
+PAMA_D void ftile_adv_face(const Params &P, double *__restrict__ flux, const FLane &X, const int *fa, int nf, const double (&L)[FT_NG],
+                           const double (&Rl)[FT_NG], double ruf, double (&F)[FT_NG]) {
+  const bool up = ruf > 0.0;
+  const long long fs = (DIR == 2) ? P.fz_fs : P.ncell;
+#pragma unroll
+  for (int n = 0; n < FT_NG; n++) {
+    if (n >= nf) { F[n] = 0.0; continue; }
+    F[n] = mul_rn(ruf, up ? Rl[n] : L[n]);
+    if (fa[n] >= 4 && X.own) uniw(flux + (long long)(1 + fa[n]) * fs)[X.fo] = F[n];
+  }
+}
+// the cell's flux difference F[c] - F[c+1] of one state variable (advected index a; the normal velocity included)
+template <int DIR>
+PAMA_D void ftile_store_diff(const Params &P, double *__restrict__ flux, const FLane &X, int a, double F_lo, double F_hi) {
+  const long long fs = (DIR == 2) ? P.fz_fs : P.ncell;
+  uniw(flux + (long long)(1 + a) * fs)[X.fo] = F_lo - F_hi;
+}
+// the groups of a sweep after the acoustic one: advected indices in sweep order, FT_NG per group; the state variables come first
+// and all sit in group 1.  Returns the number of groups (>= 1); grp[g][n] = advected index or -1
+PAMA_HD int ftile_groups(const Params &P, int dir, int (*grp)[FT_NG], int max_groups) {
+  const int ncomp_a = (dir == 1) ? 1 : 2;                    // advected index of the normal velocity
+  int ng = 0, nf = 0;
+  for (int n = 0; n < FT_NG; n++) grp[0][n] = -1;
+  for (int a = 0; a < 4 + P.nt; a++) {
+    if (a == ncomp_a) continue;
+    if (a == 1 && P.sim2d) continue;                          // 2-D: v is neither reconstructed nor stored (skip_advected_v)
+    if (nf == FT_NG) {
+      ng++; nf = 0;
+      if (ng >= max_groups) return ng;
+      for (int n = 0; n < FT_NG; n++) grp[ng][n] = -1;
+    }
+    grp[ng][nf++] = a;
+  }
+  return ng + 1;
 }
 
 // ------------------------------------------------------------------------------------------------

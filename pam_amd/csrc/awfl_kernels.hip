@@ -351,6 +351,75 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
     xtr_tile_run<STAGE, PHASE, 1>(P, G, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
 }
 
+// TILE form of the fused stage's y and z sweeps (ftile_* in awfl_device.h): a lane per cell, one launch for both directions --
+// workgroups [0, nby) are y tiles, the rest z tiles.  1-D workgroups of T lanes (the larger of the two tile sizes).  LDS per lane:
+// two ping-pong sets of FT_NG right-edge values + 4 face fluxes (the state variables' differences).
+constexpr int FT_MAXG = (4 + MAXT + FT_NG - 1) / FT_NG + 1;
+struct FTileGroups { int ny_groups, nz_groups; int gy[FT_MAXG][FT_NG], gz[FT_MAXG][FT_NG]; };
+template <int DIR, bool VZ_PER_ENS>
+__device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &G, int bx, int by, int T, const int (*grp)[FT_NG],
+                                              int ngroups, const double *__restrict__ prim, double *__restrict__ flux, double *lds) {
+  const int rows = ftile_rows(G), per = rows * G.W;
+  const int t = (int)threadIdx.x;
+  const int tz = t / per, r = t - tz * per, ty = r / G.W, tx = r - ty * G.W;
+  FLane X = ftile_lane<DIR>(P, G, bx, by, tx, ty, tz < G.lpb ? tz : 0);
+  if (tz >= G.lpb) { X.poly = X.face = X.own = X.pay = false; X.slot = X.slot_l = X.slot_r = 0; }
+  double *ldsR[2] = {lds, lds + FT_NG * T}, *ldsF = lds + 2 * FT_NG * T;
+  const int ncomp_a = (DIR == 1) ? 1 : 2;
+  double L[FT_NG], R[FT_NG], F[FT_NG], ruf = 0.0, fn = 0.0;
+  if (X.poly) {
+    ftile_acoustic_polys<DIR, VZ_PER_ENS>(P, prim, X, L, R);
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) ldsR[0][n * T + X.slot] = R[n];
+  }
+  __syncthreads();
+  if (X.face) {
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) R[n] = ldsR[0][n * T + X.slot_l];
+    ftile_acoustic_face<DIR>(P, flux, X, L, R, ruf, fn);
+    ldsF[X.slot] = fn;
+  }
+  for (int g = 0; g < ngroups; g++) {
+    double *buf = ldsR[(g + 1) & 1];
+    int fa[FT_NG], nf = 0;
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; }
+    if (X.poly) {
+      ftile_adv_polys<DIR, VZ_PER_ENS>(P, prim, X, fa, nf, L, R);
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++) buf[n * T + X.slot] = R[n];
+    }
+    __syncthreads();
+    if (X.face) {
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++) R[n] = buf[n * T + X.slot_l];
+      ftile_adv_face<DIR>(P, flux, X, fa, nf, L, R, ruf, F);
+    }
+    if (g == 0) {              // every state variable is in group 0 of the advected ones: close the cells' flux differences
+      if (X.face) {
+#pragma unroll
+        for (int n = 0; n < FT_NG; n++) ldsF[(1 + n) * T + X.slot] = F[n];
+      }
+      __syncthreads();
+      if (X.pay) {
+        ftile_store_diff<DIR>(P, flux, X, ncomp_a, fn, ldsF[X.slot_r]);
+#pragma unroll
+        for (int n = 0; n < FT_NG; n++)
+          if (fa[n] >= 0 && fa[n] < 4) ftile_store_diff<DIR>(P, flux, X, fa[n], F[n], ldsF[(1 + n) * T + X.slot_r]);
+      }
+    }
+  }
+}
+template <bool VZ_PER_ENS>
+__global__ void __launch_bounds__(1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
+                                                              const double *__restrict__ prim, double *__restrict__ fy,
+                                                              double *__restrict__ fz) {
+  extern __shared__ double ft_lds[];
+  const int T = (int)blockDim.x, b = (int)blockIdx.x;
+  if (b < nby) flux_tile_run<1, VZ_PER_ENS>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
+  else flux_tile_run<2, VZ_PER_ENS>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
+}
+
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
 // level < 0: uniform-grid constants (weno5_const, the x/y sweeps); else the per-level table `level` of member 0
 // (weno5_table, the z sweep; level = vertical matrix index 0..nz+1 as in Dycore.h:454-469).
@@ -522,6 +591,9 @@ struct pam_amd_awfl {
   int xtile_mode = 0;          // 0 automatic, 1 sweep kernels (a wavefront per line span), 2 tile kernels (a lane per cell)
   bool xtile = false;          // resolved: the x direction of the fused stage runs as tile kernels
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
+  bool independent_ranges = false;   // fused stage, several member ranges: each range's whole stage on its own stream
+  bool ftile = true;           // flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
+  int ft_tc_y = 0, ft_tc_z = 0;          // cells / levels per y / z tile (0 = automatic)
   XTileGeom xg;
   bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
   bool fused_supported = false;
@@ -640,6 +712,24 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // wavefront instead of 64 members of one line; one range = the whole ensemble
   const bool flat = h->flat && diff;
   if (flat && (r.e0 != 0 || r.ne != P.nens)) return fail(PAM_AMD_EINVAL, "flux launch: flat lanes sweep the whole ensemble in one range");
+  if (flat && h->ftile && sweeps == 6) {
+    // tile kernel: a lane per cell, both directions in one launch (small ensembles)
+    const FTileGeom Gy = ftile_geometry(P, 1, h->ft_tc_y), Gz = ftile_geometry(P, 2, h->ft_tc_z);
+    FTileGroups Q;
+    Q.ny_groups = ftile_groups(P, 1, Q.gy, FT_MAXG);
+    Q.nz_groups = ftile_groups(P, 2, Q.gz, FT_MAXG);
+    const int gyx = Gy.nch * Gy.ntl, nby = P.sim2d ? 0 : gyx * ((P.nz + Gy.lpb - 1) / Gy.lpb), nbz = Gz.nch * Gz.ntl;
+    int T = ftile_threads(Gz);
+    if (!P.sim2d && ftile_threads(Gy) > T) T = ftile_threads(Gy);
+    T = ((T + 63) / 64) * 64;
+    if (T > 1024) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes");
+    const size_t lds = (size_t)(2 * FT_NG + 4) * T * sizeof(double);
+    ScopedTimer st(h, "flux", s);
+    if (P.vz_per_ens) hipLaunchKernelGGL(awfl_flux_tile_kernel<true>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
+    else hipLaunchKernelGGL(awfl_flux_tile_kernel<false>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
+    HIP_TRY(hipGetLastError());
+    return PAM_AMD_OK;
+  }
   const long long gy = flat ? (flat_items(P, 1) + 63) / 64 : (long long)P.nz * P.nx;   // groups of 64 lanes per member block (member lanes: lines)
   const long long gz = flat ? (flat_items(P, 2) + 63) / 64 : (long long)P.ny * P.nx;
   const int ens_for_span = flat ? 1 : P.nens;
@@ -1305,14 +1395,17 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
         // high-priority compute stream, chunk after chunk; a chunk's tail (pressure pass, tracer fix-up)
         // runs on the chunk's own stream beside the NEXT chunk's flux kernel.  The x-sweep is both VALU- and HBM-heavy and
         // gets the chip to itself.
-        hipStream_t cs = forked ? h->chunks[0].fstream : c.stream;
-        if (forked) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
+        // (independent_ranges: every range runs its whole stage on its own stream -- no shared compute stream, no events between
+        // ranges: launches that do not fill the chip overlap their ramp-up and drain phases with another range's kernels)
+        const bool indep = forked && h->independent_ranges;
+        hipStream_t cs = indep ? c.stream : (forked ? h->chunks[0].fstream : c.stream);
+        if (forked && !indep) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
         if ((r2 = launch_flux(h, pin, c.r, cs, 6, true))) return r2;
         if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
         else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
         else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
         if (r2) return r2;
-        if (forked) {
+        if (forked && !indep) {
           HIP_TRY(hipEventRecord(c.flux_done, cs));
           HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
         }
@@ -1513,12 +1606,27 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   return PAM_AMD_OK;
 }
 
+int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (cells_per_y_tile < 0 || levels_per_z_tile < 0) return fail(PAM_AMD_EINVAL, "set_flux_tile: tile sizes must be >= 0 (0 = automatic)");
+  h->ftile = enable != 0;
+  h->ft_tc_y = cells_per_y_tile;
+  h->ft_tc_z = levels_per_z_tile;
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (yz_flat) *yz_flat = h->flat ? 1 : 0;
   if (x_tiles) *x_tiles = h->xtile ? 1 : 0;
   if (flat_cells) *flat_cells = h->P.flat_cells;
   if (geom) { geom[0] = h->xg.W; geom[1] = h->xg.nmb; geom[2] = h->xg.tc; geom[3] = h->xg.halo; geom[4] = h->xg.ntl; geom[5] = h->xg.lpb; }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  h->independent_ranges = independent != 0;
   return PAM_AMD_OK;
 }
 

@@ -506,10 +506,12 @@ extern "C" int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fi
   }
   hipStream_t s = (hipStream_t)stream;
   const long long n1 = (long long)num_fields * num_layers * nens;
-  // strips of the horizontal walks: enough threads for ~4 wavefronts per SIMD, never fewer than 8 cells each
+  // strips of the horizontal walks: at most 64 per (field, layer, member), never fewer than 8 cells each.  The count follows from
+  // (nx, ny) ALONE: the order in which a member's mean is summed must not depend on how many members this call holds, or a CRM
+  // would not be bit-reproducible between a 1-GPU run and a run sharded by members over N GPUs
   const long long cells = (long long)ny * nx;
-  long long want = (262144 + n1 - 1) / n1;
-  if (want > cells / 8) want = cells / 8;
+  long long want = cells / 8;
+  if (want > 64) want = 64;
   if (want < 1) want = 1;
   const int cpt = (int)((cells + want - 1) / want), nstrip = (int)((cells + cpt - 1) / cpt);
   double *part = nullptr;     // partial sums of the strips: stream-ordered scratch

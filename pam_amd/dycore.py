@@ -239,6 +239,9 @@ class Dycore:
     def set_ensemble_chunks(self, chunks, flux_lds_floor_bytes=0):
         check(self._lib.pam_amd_awfl_set_ensemble_chunks(self._h, int(chunks), int(flux_lds_floor_bytes)))
 
+    def set_range_schedule(self, independent):
+        check(self._lib.pam_amd_awfl_set_range_schedule(self._h, int(bool(independent))))
+
     def set_fused_stage(self, enable):
         check(self._lib.pam_amd_awfl_set_fused_stage(self._h, int(bool(enable))))
 
@@ -252,6 +255,9 @@ class Dycore:
 
     def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
         check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
+
+    def set_flux_tile(self, enable=True, cells_per_y_tile=0, levels_per_z_tile=0):
+        check(self._lib.pam_amd_awfl_set_flux_tile(self._h, int(bool(enable)), int(cells_per_y_tile), int(levels_per_z_tile)))
 
     def get_lane_mapping(self):
         flat, tile, cells = C.c_int(), C.c_int(), C.c_int()

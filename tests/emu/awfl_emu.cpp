@@ -28,6 +28,7 @@ struct Emu {
   int flat = 0;   // fused stage: the y/z sweeps run with flat (x, member) lanes (flat_lane) and the fix-up with a lane per cell
   int xtile = 0;  // fused stage: the x direction runs as tile kernels (a lane per cell; xtile_* bodies) instead of sweeps
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides
+  int ftile = 0, ft_tc_y = 0, ft_tc_z = 0;   // flat lanes: the y/z fluxes as tile kernels (ftile_* bodies); cells / levels per tile
   std::vector<int> fct_flags;   // row flags of the FCT multiplier (FctRows)
   int fct_seq = 0;
 };
@@ -39,6 +40,73 @@ static FctRows fct_rows(Emu *h) {   // layout as on the device: rows, the "any" 
   r.flags = h->fct_flags.data(); r.any = h->fct_flags.data() + nrows; r.lines = h->fct_flags.data() + nrows + nany;
   r.seq = h->fct_seq; r.sparse_store = 0;
   return r;
+}
+
+// awfl_flux_tile_kernel: the phases of a workgroup one after the other over all its lanes, LDS exchange in between
+template <int DIR, bool VZ>
+static void flux_tile_dir(Emu *h, const double *prim, double *flux, int tc_req) {
+  const Params &P = h->P;
+  const FTileGeom G = ftile_geometry(P, DIR, tc_req);
+  const int rows = ftile_rows(G), T = ftile_threads(G);
+  int grp[64][FT_NG];
+  const int ngroups = ftile_groups(P, DIR, grp, 64);
+  const int gx = G.nch * G.ntl, gy = (DIR == 1) ? (P.nz + G.lpb - 1) / G.lpb : 1;
+  const int ncomp_a = (DIR == 1) ? 1 : 2;
+  struct Lane { FLane X; double L[FT_NG], R[FT_NG], F[FT_NG], ruf, fn; };
+  std::vector<Lane> st(T);
+  std::vector<double> ldsR[2] = {std::vector<double>((size_t)FT_NG * T), std::vector<double>((size_t)FT_NG * T)}, ldsF((size_t)4 * T);
+  for (int by = 0; by < gy; by++)
+    for (int bx = 0; bx < gx; bx++) {
+      for (auto &v : ldsR) std::fill(v.begin(), v.end(), NAN);
+      std::fill(ldsF.begin(), ldsF.end(), NAN);
+      for (int tz = 0; tz < G.lpb; tz++)
+        for (int ty = 0; ty < rows; ty++)
+          for (int tx = 0; tx < G.W; tx++) {
+            const int t = (tz * rows + ty) * G.W + tx;
+            Lane &l = st[t];
+            l.X = ftile_lane<DIR>(P, G, bx, by, tx, ty, tz);
+            if (l.X.slot != t) abort();
+            l.ruf = l.fn = 0.0;
+            if (!l.X.poly) continue;
+            ftile_acoustic_polys<DIR, VZ>(P, prim, l.X, l.L, l.R);
+            for (int n = 0; n < FT_NG; n++) ldsR[0][(size_t)n * T + t] = l.R[n];
+          }
+      for (int t = 0; t < T; t++)
+        if (st[t].X.face) {
+          Lane &l = st[t];
+          for (int n = 0; n < FT_NG; n++) l.R[n] = ldsR[0][(size_t)n * T + l.X.slot_l];
+          ftile_acoustic_face<DIR>(P, flux, l.X, l.L, l.R, l.ruf, l.fn);
+          ldsF[t] = l.fn;
+        }
+      for (int g = 0; g < ngroups; g++) {
+        std::vector<double> &buf = ldsR[(g + 1) & 1];
+        int nf = 0;
+        for (int n = 0; n < FT_NG; n++) nf += grp[g][n] >= 0 ? 1 : 0;
+        for (int t = 0; t < T; t++)
+          if (st[t].X.poly) {
+            ftile_adv_polys<DIR, VZ>(P, prim, st[t].X, grp[g], nf, st[t].L, st[t].R);
+            for (int n = 0; n < FT_NG; n++) buf[(size_t)n * T + t] = st[t].R[n];
+          }
+        for (int t = 0; t < T; t++)
+          if (st[t].X.face) {
+            Lane &l = st[t];
+            for (int n = 0; n < FT_NG; n++) l.R[n] = buf[(size_t)n * T + l.X.slot_l];
+            ftile_adv_face<DIR>(P, flux, l.X, grp[g], nf, l.L, l.R, l.ruf, l.F);
+          }
+        if (g == 0) {
+          for (int t = 0; t < T; t++)
+            if (st[t].X.face)
+              for (int n = 0; n < FT_NG; n++) ldsF[(size_t)(1 + n) * T + t] = st[t].F[n];
+          for (int t = 0; t < T; t++)
+            if (st[t].X.pay) {
+              Lane &l = st[t];
+              ftile_store_diff<DIR>(P, flux, l.X, ncomp_a, l.fn, ldsF[l.X.slot_r]);
+              for (int n = 0; n < FT_NG; n++)
+                if (grp[g][n] >= 0 && grp[g][n] < 4) ftile_store_diff<DIR>(P, flux, l.X, grp[g][n], l.F[n], ldsF[(size_t)(1 + n) * T + l.X.slot_r]);
+            }
+        }
+      }
+    }
 }
 
 static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = false) {
@@ -54,6 +122,11 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
     if (diff && dir == 1) span = nfaces;                 // difference form: periodic lines are swept whole
     const int nspan = (nfaces + span - 1) / span;
     double *fl = dir == 0 ? h->fx.data() : (dir == 1 ? h->fy.data() : h->fz.data());
+    if (h->flat && h->ftile && diff && dir != 0) {     // awfl_flux_tile_kernel: a lane per cell
+      if (dir == 1) { if (P.vz_per_ens) flux_tile_dir<1, true>(h, prim, fl, h->ft_tc_y); else flux_tile_dir<1, false>(h, prim, fl, h->ft_tc_y); }
+      else { if (P.vz_per_ens) flux_tile_dir<2, true>(h, prim, fl, h->ft_tc_z); else flux_tile_dir<2, false>(h, prim, fl, h->ft_tc_z); }
+      continue;
+    }
     if (h->flat && diff && dir != 0) {     // awfl_flux_kernel<., true, FLAT>: a lane per item of the sweep's flat index space
       const long long items = flat_items(P, dir);
       for (int sp = 0; sp < nspan; sp++)
@@ -317,6 +390,7 @@ void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
 void emu_set_xtr_split(Emu *h, int split) { h->xtr_split = split; }
 void emu_set_lane_mapping(Emu *h, int flat, int xtile) { h->flat = flat; h->xtile = xtile; }
 void emu_set_x_tile(Emu *h, int w, int tc, int lpb) { h->xt_w = w; h->xt_tc = tc; h->xt_lpb = lpb; }
+void emu_set_flux_tile(Emu *h, int on, int tc_y, int tc_z) { h->ftile = on; h->ft_tc_y = tc_y; h->ft_tc_z = tc_z; }
 void emu_x_tile_geometry(Emu *h, int *g) {
   const XTileGeom G = xtile_geometry(h->P, h->xt_w, h->xt_tc, h->xt_lpb);
   g[0] = G.W; g[1] = G.nmb; g[2] = G.tc; g[3] = G.halo; g[4] = G.ntl; g[5] = G.lpb;

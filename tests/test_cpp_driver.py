@@ -189,3 +189,68 @@ def test_cpp_driver_spam_surface_swap_in(tmp_path):
     exp = [f["density_dry"], f["uvel"], f["vvel"], f["wvel"], f["temp"]] + [f["tracers"][t] for t in range(3)]
     for i, e in enumerate(exp):
         assert np.abs(got[i] - e).max() <= 1e-12 * max(np.abs(e).max(), 1e-300), i
+
+
+def _write_input(path, f, tr, zint, xlen, ylen, crm_dt, nsteps, flags, consts=None):
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    nz, ny, nx, nens = f["density_dry"].shape
+    c = consts or idz.CONSTS_DEFAULT
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<8q", nens, nx, ny, nz, len(tr), nsteps, flags, 1))
+        fh.write(struct.pack("<3d", xlen, ylen, crm_dt))
+        fh.write(struct.pack("<6d", c["R_d"], c["cp_d"], c["R_v"], c["cp_v"], c["p0"], c["grav"]))
+        fh.write(np.asarray(zint, dtype="<f8").tobytes())
+        fh.write(bytes(bytearray(v for t in range(len(tr)) for v in (int(pos[t]), int(mass[t])))))
+        fh.write(struct.pack("<q", idwv))
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp"):
+            fh.write(f[k].astype("<f8").tobytes())
+        for t in range(len(tr)):
+            fh.write(f["tracers"][t].astype("<f8").tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nens,ranks", [(130, (2, 3)), (6, (2, 4))], ids=["member_lane_shards", "flat_lane_shards"])
+def test_cpp_driver_sharded_over_handles_equals_unsharded_bit_for_bit(tmp_path, nens, ranks):
+    """examples/driver --gpus N: N host threads, one coupler + one dycore handle each (hipSetDevice before init; on this 1-GPU box
+    they share device 0), the ensemble sharded by member index, the dynamics step = min over N host doubles -- no collective library
+    (Dycore.h:86-101,141-145; standalone/mmf_simplified/driver.cpp:237-272).  One member is made the CFL-limiting
+    one, so that a shard without it would sub-cycle differently if the exchange were missing.  Results equal the single-handle run
+    bit for bit, with even and ragged shard sizes (130 -> 65+65 and 44+43+43; 6 -> 3+3 and 2+2+1+1)."""
+    assert os.path.exists(DRIVER), "examples/driver missing: run __graft_entry__.build()"
+    nx, ny, nz, nsteps, crm_dt = 8, 4, 10, 2, 2.0
+    tr = idz.TRACERS_KESSLER_SHOC
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    xlen, ylen = nx * 500.0, ny * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    f["uvel"][..., 1] += 40.0                      # member 1 alone sets the ensemble's CFL step
+    inp = str(tmp_path / "in.bin")
+    _write_input(inp, f, tr, zint, xlen, ylen, crm_dt, nsteps, 1)
+    outs = []
+    for n in (1,) + tuple(ranks):
+        outp = str(tmp_path / ("out%d.bin" % n))
+        r = subprocess.run([DRIVER, "--gpus", str(n), inp, outp], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(outp, dtype="<f8"))
+    assert np.isfinite(outs[0]).all() and not np.array_equal(outs[0][:f["density_dry"].size], f["density_dry"].ravel())
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_bench_mode_tiles_the_input_and_reports_one_json_line(tmp_path):
+    """--tile R --bench K W: what bench.py --launcher cpp runs"""
+    import json
+    nens, nx, ny, nz = 4, 8, 1, 10
+    tr = idz.TRACERS_NONE
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_input(inp, f, tr, zint, nx * 500.0, nx * 500.0, 2.0, 0, 1)
+    r = subprocess.run([DRIVER, "--gpus", "2", "--tile", "3", "--bench", "2", "1", inp, outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["launcher"] == "cpp" and d["ranks"] == 2 and d["nens_total"] == 12 and d["steps"] == 2 and d["seconds"] > 0 and d["substeps"] >= 2
+    assert np.fromfile(outp, dtype="<f8").size == 6 * nz * ny * nx * 12

@@ -43,7 +43,7 @@ def _setup(case):
     return (nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, consts, mode_a), f, tiles
 
 
-def _run_emu(args, f, flat, xtile, tile=(0, 0, 0), span=0):
+def _run_emu(args, f, flat, xtile, tile=(0, 0, 0), span=0, ftile=None):
     nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, consts, mode_a = args
     ff = copy.deepcopy(f)
     g = eh.EmuDycore(nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, consts=consts)
@@ -52,6 +52,8 @@ def _run_emu(args, f, flat, xtile, tile=(0, 0, 0), span=0):
     g.set_span(span)
     g.set_lane_mapping(flat, xtile)
     g.set_x_tile(*tile)
+    if ftile is not None:
+        g.set_flux_tile(True, *ftile)
     g.declare_current_profile_as_hydrostatic(ff)
     ncyc = [g.time_step(ff, dt)[0] for dt in (2.0, 0.7)]
     return ncyc, ff, g
@@ -61,10 +63,13 @@ def _run_emu(args, f, flat, xtile, tile=(0, 0, 0), span=0):
 def test_flat_lanes_and_tile_kernels_equal_member_lane_sweeps_bit_for_bit(case):
     args, f, tiles = _setup(case)
     n0, ref, _ = _run_emu(args, f, False, False)
-    variants = [("flat y/z lanes", True, False, (0, 0, 0)), ("tile x kernels", False, True, (0, 0, 0)),
-                ("flat + tile", True, True, (0, 0, 0))] + [("flat + tile %r" % (t,), True, True, t) for t in tiles]
-    for name, flat, xtile, tile in variants:
-        n1, got, g = _run_emu(args, f, flat, xtile, tile)
+    variants = [("flat y/z lanes", True, False, (0, 0, 0), None), ("tile x kernels", False, True, (0, 0, 0), None),
+                ("flat + tile", True, True, (0, 0, 0), None)] + [("flat + tile %r" % (t,), True, True, t, None) for t in tiles]
+    # the y/z fluxes as tile kernels too: automatic tiles, short tiles (several per line / column, halo rows), whole columns
+    variants += [("y/z tiles", True, True, (0, 0, 0), (0, 0)), ("y/z tiles of 2 / 3", True, False, (0, 0, 0), (2, 3)),
+                 ("y/z tiles of 3 / 14", True, True, (0, 0, 0), (3, 14))]
+    for name, flat, xtile, tile, ftile in variants:
+        n1, got, g = _run_emu(args, f, flat, xtile, tile, ftile=ftile)
         assert n0 == n1, name
         for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
             assert np.isfinite(got[k]).all(), (name, k)

@@ -45,7 +45,7 @@ def _fields(case):
     return f, xlen, ylen
 
 
-def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None):
+def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=(True, 0, 0)):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
@@ -66,6 +66,7 @@ def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None):
     dycore.init(coupler)
     dycore.set_lane_mapping(yz, xk)
     dycore.set_x_tile(*tile)
+    dycore.set_flux_tile(*ftile)
     mapping = dycore.get_lane_mapping()
     coupler.load_fields(f)
     if not mode_a:
@@ -90,15 +91,17 @@ def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(c
     assert not m0["yz_flat"] and not m0["x_tiles"]
     if CASES[case][-2]:
         assert 0 < rows[0] <= rows[1] and rows[2], rows     # the limiter acted on vapour in the last stage: the sparse paths ran
-    variants = [("flat", "sweep", (0, 0, 0)), ("member", "tile", (0, 0, 0)), ("flat", "tile", (0, 0, 0))]
-    variants += [("flat", "tile", t) for t in tiles]
-    for yz, xk, tile in variants:
-        n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile)
+    # (y/z lanes, x kernels, x tile geometry, (y/z fluxes as ONE tile kernel, cells per y tile, levels per z tile))
+    variants = [("flat", "sweep", (0, 0, 0), (True, 0, 0)), ("member", "tile", (0, 0, 0), (True, 0, 0)), ("flat", "tile", (0, 0, 0), (True, 0, 0)),
+                ("flat", "tile", (0, 0, 0), (False, 0, 0)), ("flat", "sweep", (0, 0, 0), (True, 2, 3)), ("flat", "tile", (0, 0, 0), (True, 5, 14))]
+    variants += [("flat", "tile", t, (True, 0, 0)) for t in tiles]
+    for yz, xk, tile, ftile in variants:
+        n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile, ftile=ftile)
         assert m1["yz_flat"] == (yz == "flat") and m1["x_tiles"] == (xk == "tile"), m1
         assert n0 == n1
         for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
-            assert np.isfinite(got[k]).all(), (yz, xk, tile, k)
-            assert np.array_equal(ref[k], got[k]), (yz, xk, tile, m1, k, np.abs(ref[k] - got[k]).max())
+            assert np.isfinite(got[k]).all(), (yz, xk, tile, ftile, k)
+            assert np.array_equal(ref[k], got[k]), (yz, xk, tile, ftile, m1, k, np.abs(ref[k] - got[k]).max())
 
 
 def test_small_ensemble_defaults_are_flat_and_tile_and_large_ones_member_and_sweep():

@@ -35,12 +35,14 @@ def test_oracle_sponge_layer_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ny", [1, 4])
-def test_gpu_sponge_layer_matches_oracle(ny):
+@pytest.mark.parametrize("ny,nens,nx", [(1, 70, 5), (4, 70, 5), (6, 3, 11), (12, 1, 24)],
+                         ids=["2d", "3d", "strips_small_ensemble", "strips_one_member"])
+def test_gpu_sponge_layer_matches_oracle(ny, nens, nx):
+    """the last two cases have ny*nx >= 16: the horizontal means are summed in STRIPS (sponge_mean_kernel + sponge_mean_finish_kernel)"""
     import torch
     from pam_amd import PamCoupler, modules
     tr = idz.TRACERS_KESSLER_SHOC
-    nens, nx, nz = 70, 5, 12
+    nz = 12
     zint, zi, zm, f = _case(nens=nens, nx=nx, ny=ny, nz=nz, tr=tr)
     coupler = PamCoupler("cuda:0")
     coupler.set_option("crm_dt", 2.0)
@@ -280,3 +282,30 @@ def test_driver_supercell_column_matches_oracle(grid):
         assert np.isfinite(g).all(), name
         assert np.abs(g - e).max() <= 1e-13 * max(np.abs(e).max(), 1e-300), (name, np.abs(g - e).max())
     assert exp[5].max() > 0 and exp[0][0] > 1.0      # a moist, ground-based column
+
+
+@pytest.mark.gpu
+def test_gpu_sponge_layer_does_not_depend_on_how_the_ensemble_is_sharded():
+    """the strips of the horizontal means follow from (nx, ny) alone, so a member's result is bit-identical whether the call
+    holds the whole ensemble or a shard of it (1-GPU run vs members sharded over N GPUs)"""
+    import torch
+    from pam_amd import PamCoupler, modules
+    tr = idz.TRACERS_NONE
+    nens, nx, ny, nz = 96, 12, 10, 12
+    zint, zi, zm, f = _case(nens=nens, nx=nx, ny=ny, nz=nz, tr=tr)
+
+    def run(lo, hi):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 2.0)
+        coupler.allocate_coupler_state(nz, ny, nx, hi - lo)
+        coupler.set_grid(nx * 500.0, ny * 500.0, zi[:, lo:hi])
+        coupler.add_tracer("water_vapor", "", True, True)
+        coupler.load_fields({k: np.ascontiguousarray(v[..., lo:hi]) for k, v in f.items()})
+        coupler.run_module("sponge_layer", modules.sponge_layer)
+        torch.cuda.synchronize()
+        return coupler.dump_fields()
+    whole = run(0, nens)
+    for lo, hi in ((0, 5), (5, 96), (40, 41)):
+        part = run(lo, hi)
+        for k in whole:
+            assert np.array_equal(whole[k][..., lo:hi], part[k]), (k, lo, hi)

@@ -27,6 +27,6 @@ for cfg in $CFGS; do
   ( cd $R && PMC_SOURCE_CONFIG=$cfg python3 tools/pmc_summary.py $OUT/${cfg}_pmc_FETCH_SIZE.csv $OUT/${cfg}_pmc_WRITE_SIZE.csv $OUT/${cfg}_pmc_SQ.csv $OUT/${cfg}_pmc_GRBM_GUI_ACTIVE.csv --traffic-json $HASH > $OUT/${cfg}_pmc_summary.txt )
   tail -1 $OUT/${cfg}_pmc_summary.txt > $OUT/${cfg}_traffic.json
   sed -i '$ d' $OUT/${cfg}_pmc_summary.txt
-  echo "== $cfg"; grep -E 'derived|wave-cycle' $OUT/${cfg}_pmc_summary.txt | grep -E 'flux|xupd|xtr|fct|trupd|ptail|trfix' || true
+  echo "== $cfg"; grep -E 'derived|wave-cycle' $OUT/${cfg}_pmc_summary.txt | grep -E 'flux|xupd|xtr|fct|ptail|trfix' || true
 done
 ls $OUT
