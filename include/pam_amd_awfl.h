@@ -178,11 +178,13 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
  * completes (a tile shorter than the line gets one halo row on each side), lines per workgroup (whole-line tiles only). */
 int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels);
 int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group);
-/* With flat y/z lanes the y and z fluxes of a stage run as ONE tile kernel as well (a lane per cell; rows of a tile follow the sweep
- * direction, the lanes of a row are contiguous (x, member) / (y, x, member) items): enable = 0 falls back to flat-lane SWEEPS (a lane
- * per item walks its line serially); cells per y tile / levels per z tile, 0 = automatic.  Same bits either way. */
+/* With flat y/z lanes the y and z fluxes of a stage can run as ONE tile kernel as well (a lane per cell; rows of a tile follow the
+ * sweep direction, the lanes of a row are contiguous (x, member) / (y, x, member) items) instead of flat-lane SWEEPS (a lane per item
+ * walks its line serially): enable = 0 automatic (tile kernel while the whole ensemble is below ~2.6e5 cells), 1 sweeps, 2 tile
+ * kernel; cells per y tile / levels per z tile, 0 = automatic.  Same bits either way. */
 int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile);
-/* the resolved mapping: flat y/z lanes, x tile kernels, pointwise kernels on a grid flat over every cell (0/1 each) and the tile
+/* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels, pointwise kernels on a
+ * grid flat over every cell (0/1 each) and the x tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]);
 

@@ -1479,7 +1479,9 @@ PAMA_D void own_multiplier_cell(const Params &P, int t, double *__restrict__ mul
       if (!DENSE && rows.lines) rows.lines[(long long)t * fct_lines_per_tracer(P) + fct_line(P, k, j, e)] = rows.seq;
       if (!DENSE) rows.any[e >> 6] = rows.seq;  // ("some row of water vapour in this member block": the fix-up pass has work)
     }
-    if (DENSE || wave_any(limited)) uniw(mt)[eu] = m_t;
+    // (sparse: only where a wavefront IS a row -- 64 members of one cell.  In the tile kernels a row may be narrower than a
+    // wavefront and straddle two of them: the half without a limited member must still store its multipliers, the row is flagged)
+    if (DENSE || !rows.sparse_store || wave_any(limited)) uniw(mt)[eu] = m_t;
   } else {
     uniw(mt)[eu] = m_t;
   }
@@ -2261,7 +2263,7 @@ PAMA_HD FTileGeom ftile_geometry(const Params &P, int dir, int tc_req) {
       if (G.lpb > P.nz) G.lpb = P.nz;
     } else {
       G.halo = 1; G.lpb = 1;
-      int tc = tc_req > 0 ? tc_req : 256 / G.W - 2;
+      int tc = tc_req > 0 ? tc_req : (G.W >= 32 ? 512 : 256) / G.W - 2;
       if (tc < 2) tc = 2;
       if (tc > n) tc = n;
       while (tc > 1 && (tc + 2) * G.W > 1024) tc--;

@@ -11,6 +11,8 @@ oracle's own response to 1-ulp input noise over the same steps is ~2e-15 (rho, T
    uvel, wvel, vvel, other tracers: max|a-b| <= 1e-9  * max|b|          (small, noise-dominated fields)
 """
 import copy
+import json
+import os
 
 import numpy as np
 import pytest
@@ -20,8 +22,20 @@ from pam_amd import idealized as idz
 pytestmark = pytest.mark.gpu
 
 TOL_TIGHT = 1e-12
-TOL_LOOSE = 1e-9
 
+
+def tol_noise_fields(nsub):
+    """Gate of the small, noise-dominated fields (u, v, w, tracers other than water vapour) after `nsub` SSPRK3 sub-steps, relative to
+    max|field|.  It follows the MEASURED curve, not a flat bound: profiles/r03_error_growth_c1.txt (BASELINE config C1, HIP vs oracle
+    beside the oracle's own response to ONE ulp of T) has u, v, w at 4.5e-13 ... 6.8e-12 over 3 ... 30 sub-steps, i.e. within
+    1e-12 (1 + nsub/3) throughout; the gate is that envelope times 10 (the other cases' worst, recorded on MI355X with
+    PAM_AMD_PARITY_RECORD: profiles/r04_parity_worst.json, stay below a fifth of it).  A 100x regression fails (round 3's flat 1e-9
+    would have let it through), and so does a relative perturbation of 1e-10 injected into one field
+    (test_the_gate_turns_red_on_an_injected_1e10_perturbation)."""
+    return 1.0e-11 * (1.0 + nsub / 3.0)
+
+
+_RECORD = {}
 
 def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True, per_ens=False, mag=0.5, crm_dt=2.0,
            dxy=500.0, dry_air=False):
@@ -59,7 +73,7 @@ def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True
     return coupler, dycore, oracle, copy.deepcopy(f), names
 
 
-def _compare(got, exp, names):
+def _worst(got, exp, names):
     worst = {}
     for k in ("density_dry", "temp", "uvel", "vvel", "wvel"):
         scale = max(np.abs(exp[k]).max(), 1e-300)
@@ -67,14 +81,24 @@ def _compare(got, exp, names):
     for t, n in enumerate(names):
         scale = max(np.abs(exp["tracers"][t]).max(), 1e-300)
         worst[n] = np.abs(got["tracers"][t] - exp["tracers"][t]).max() / scale
+    for k in ("density_dry", "temp"):   # bounded away from zero: also ELEMENT-WISE
+        worst[k + "_elementwise"] = np.abs((got[k] - exp[k]) / exp[k]).max()
+    return worst
+
+
+def _compare(got, exp, names, nsub, case=None):
+    """north_star gate: rho_d, T (max-norm and element-wise) and water vapour within 1e-12; the noise-dominated fields within
+    tol_noise_fields(nsub)."""
+    worst = _worst(got, exp, names)
+    if case is not None:
+        _RECORD[case] = dict(worst, nsub=nsub)
+        path = os.environ.get("PAM_AMD_PARITY_RECORD")
+        if path:
+            json.dump(_RECORD, open(path, "w"), indent=1, sort_keys=True)
+    loose = tol_noise_fields(nsub)
     for k, e in worst.items():
-        tol = TOL_TIGHT if k in ("density_dry", "temp", "water_vapor") else TOL_LOOSE
-        assert e <= tol, (k, e, worst)
-    # rho_d and T are bounded away from zero: for them "rtol 1e-12" is asserted ELEMENT-WISE as well
-    for k in ("density_dry", "temp"):
-        el = np.abs((got[k] - exp[k]) / exp[k]).max()
-        assert el <= TOL_TIGHT, (k, "element-wise", el)
-        worst[k + "_elementwise"] = el
+        tol = TOL_TIGHT if k.split("_elementwise")[0] in ("density_dry", "temp", "water_vapor") else loose
+        assert e <= tol, (k, e, tol, worst)
     return worst
 
 
@@ -130,16 +154,30 @@ def test_time_step_matches_oracle(case):
     ov = oracle.variable_gravity if mode_a else oracle.hy_dens_cells
     assert np.abs(gv - ov).max() <= 1e-12 * np.abs(ov).max()
     assert abs(dycore.compute_time_step(coupler) - oracle.compute_time_step(fo)) <= 1e-14 * oracle.compute_time_step(fo)
+    nsub = 0
     for _ in range(nsteps):
         n_gpu = dycore.timeStep(coupler)
         n_cpu, dt_cpu = oracle.time_step(fo, coupler.get_option("crm_dt"))
         assert n_gpu == n_cpu
+        nsub += n_gpu
         assert abs(dycore.last_dt_dyn - dt_cpu) <= 1e-15 * dt_cpu
         if kw.get("dry_air"):
             flagged, total, any_word = dycore.debug_fct_rows()      # the last stage of this timeStep limited vapour somewhere
             assert 0 < flagged < total and any_word, (flagged, total)
     torch.cuda.synchronize()
-    _compare(coupler.dump_fields(), fo, names)
+    got = coupler.dump_fields()
+    _compare(got, fo, names, nsub, case)
+    if case == "3d_nt4_stretched_B":
+        # the gate itself: a relative perturbation of 1e-10 in ONE field must turn the case red
+        for k in ("uvel", "wvel", "temp"):
+            bad = copy.deepcopy(got)
+            bad[k] = bad[k] * (1.0 + 1.0e-10)
+            with pytest.raises(AssertionError):
+                _compare(bad, fo, names, nsub)
+        bad = copy.deepcopy(got)
+        bad["tracers"][1] = bad["tracers"][1] * (1.0 + 1.0e-10)
+        with pytest.raises(AssertionError):
+            _compare(bad, fo, names, nsub)
     dycore.finalize(coupler)
 
 
@@ -408,7 +446,7 @@ def test_full_size_c2_vapour_limited_member_ranges_do_not_interfere():
     dycore.finalize(coupler)
 
 
-@pytest.mark.parametrize("cfg", ["c3_nens4096_kessler_shoc", "c4_shard512_p3_shoc"])
+@pytest.mark.parametrize("cfg", ["c3_nens4096_kessler_shoc", "c4_shard512_p3_shoc", "c4_total_nens4096_p3_shoc"])
 def test_full_baseline_size_c3_c4_properties(cfg):
     """BASELINE.json configs[2] (nens=4096, 2-D 32x1x60, 4 tracers) and one GPU's shard of configs[3] (512 of 4096 members, 10
     tracers, P3 constants) at full size: too large for the oracle, so size-independent properties.  Tracers carry blobs with exact
@@ -418,7 +456,10 @@ def test_full_baseline_size_c3_c4_properties(cfg):
     (16 distinct members tiled); (iv) the fused stage equals the three-kernel stage bit for bit at this size too."""
     import torch
     from pam_amd import Dycore, PamCoupler
-    nens, tr, consts = (4096, idz.TRACERS_KESSLER_SHOC, idz.CONSTS_DEFAULT) if cfg.startswith("c3") else (512, idz.TRACERS_P3_SHOC, idz.CONSTS_P3)
+    # (c4_total: BASELINE.json configs[3] WHOLE -- nens = 4096 with the 10 P3 + SHOC tracers -- on one GPU: the N = 1 end of its
+    # strong-scaling row; ~7 GB of resident arrays)
+    nens, tr, consts = (4096, idz.TRACERS_KESSLER_SHOC, idz.CONSTS_DEFAULT) if cfg.startswith("c3") else (
+        (512 if "shard" in cfg else 4096), idz.TRACERS_P3_SHOC, idz.CONSTS_P3)
     nx, ny, nz, ngen = 32, 1, 60, 16
     zint = idz.l60_interfaces()
     xlen = nx * 1000.0

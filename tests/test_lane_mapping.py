@@ -45,7 +45,7 @@ def _fields(case):
     return f, xlen, ylen
 
 
-def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=(True, 0, 0)):
+def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=("auto", 0, 0)):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
@@ -92,12 +92,14 @@ def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(c
     if CASES[case][-2]:
         assert 0 < rows[0] <= rows[1] and rows[2], rows     # the limiter acted on vapour in the last stage: the sparse paths ran
     # (y/z lanes, x kernels, x tile geometry, (y/z fluxes as ONE tile kernel, cells per y tile, levels per z tile))
-    variants = [("flat", "sweep", (0, 0, 0), (True, 0, 0)), ("member", "tile", (0, 0, 0), (True, 0, 0)), ("flat", "tile", (0, 0, 0), (True, 0, 0)),
-                ("flat", "tile", (0, 0, 0), (False, 0, 0)), ("flat", "sweep", (0, 0, 0), (True, 2, 3)), ("flat", "tile", (0, 0, 0), (True, 5, 14))]
-    variants += [("flat", "tile", t, (True, 0, 0)) for t in tiles]
+    variants = [("flat", "sweep", (0, 0, 0), ("tile", 0, 0)), ("member", "tile", (0, 0, 0), ("auto", 0, 0)), ("flat", "tile", (0, 0, 0), ("tile", 0, 0)),
+                ("flat", "tile", (0, 0, 0), ("sweep", 0, 0)), ("flat", "sweep", (0, 0, 0), ("tile", 2, 3)), ("flat", "tile", (0, 0, 0), ("tile", 5, 14))]
+    variants += [("flat", "tile", t, ("auto", 0, 0)) for t in tiles]
     for yz, xk, tile, ftile in variants:
         n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile, ftile=ftile)
         assert m1["yz_flat"] == (yz == "flat") and m1["x_tiles"] == (xk == "tile"), m1
+        if yz == "flat" and ftile[0] != "auto":
+            assert m1["yz_tile_kernel"] == (ftile[0] == "tile"), m1
         assert n0 == n1
         for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
             assert np.isfinite(got[k]).all(), (yz, xk, tile, ftile, k)
