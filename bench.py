@@ -386,10 +386,12 @@ class Job:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         updates = float(self.nens * self.nz * self.ny * self.nx * substeps)
+        self.rank_elapsed = (elapsed, elapsed)
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            t = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, emin = float(t[0].item()), -float(t[1].item())
+            self.rank_elapsed = (emin, elapsed)     # fastest and slowest rank: load imbalance is visible in the line
             u = torch.tensor([updates], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(u, op=dist.ReduceOp.SUM)
             updates = float(u.item())
@@ -718,6 +720,7 @@ def worker(args):
         except Exception as e:   # the baseline is a reported extra; never fail the bench line for it
             cpu = {"value": None, "unit": "cell-updates/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
+    rank_ms = [e / args.steps * 1e3 for e in job.rank_elapsed]
     desc, nens_pg, nens_total = job.desc % job.nens, job.nens, job.nens_total
     lane_mapping = job.lane_mapping
     ny, nx, nz, crm_dt = job.ny, job.nx, job.nz, job.crm_dt
@@ -782,7 +785,8 @@ def worker(args):
                           "limiter_input": args.limiter, "fct_rows_flagged_last_stage": fct_rows[0], "fct_rows": fct_rows[1],
                           "collective": None if world == 1 else "all-reduce(MIN) of dt, 8 B per timeStep, backend %s%s" % (
                               backend, "" if ndev >= world else " (rehearsal: %d ranks share %d GPU)" % (world, ndev)),
-                          "ranks_seen": ranks_seen, "device": str(dev), "lane_mapping": lane_mapping},
+                          "ranks_seen": ranks_seen, "device": str(dev), "lane_mapping": lane_mapping,
+                          "rank_ms_per_step": {"min": rank_ms[0], "max": rank_ms[1]}},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
                "other_configs": others}
         print(json.dumps(out))

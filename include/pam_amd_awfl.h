@@ -147,15 +147,16 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces);
 int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
 /* Ensemble ranges inside one handle: the members are split into `chunks` contiguous ranges advanced on internal HIP
- * streams (forked from / joined to the handle's stream with events).  chunks = 0: automatic -- ONE range for the fused stage
- * (its kernels gain nothing from sharing the chip); 1-16 for the three-kernel stage, whose HBM-bound
+ * streams (forked from / joined to the handle's stream with events).  chunks = 0: automatic -- two independent ranges for the
+ * fused stage from 128 members on, one below; 1-16 for the three-kernel stage, whose HBM-bound
  * update kernel overlaps the FP64-bound flux kernel of another range.  flux_lds_floor_bytes: dynamic LDS requested per flux
  * workgroup when chunks > 1 (the kernel itself uses none: it caps the flux kernel's residency per CU so that another range's
  * blocks can co-reside; default 0 = no cap).  Results do not depend on either. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
-/* Fused stage with several member ranges: independent = 1 runs every range's whole stage on the range's own stream (no shared
- * compute stream, no events between ranges), so that launches which do not fill the chip overlap their ramp-up and drain phases
- * with another range's kernels; 0 (default): the polynomial kernels of all ranges back to back on one stream.  Same results. */
+/* Fused stage with several member ranges: independent = 1 (default) runs every range's whole stage on the range's own stream (no
+ * shared compute stream, no events between ranges), so that launches which do not fill the chip overlap their ramp-up and drain
+ * phases with another range's kernels; 0: the polynomial kernels of all ranges back to back on one stream (round 2's schedule).
+ * Same results.  The automatic range count (set_ensemble_chunks(0)) of the fused stage is 2 from 128 members on. */
 int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent);
 
 /* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + update of the state and of the first tracer (incl.
@@ -183,6 +184,11 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
  * walks its line serially): enable = 0 automatic (tile kernel while the whole ensemble is below ~2.6e5 cells), 1 sweeps, 2 tile
  * kernel; cells per y tile / levels per z tile, 0 = automatic.  Same bits either way. */
 int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile);
+/* x tile kernels of small ensembles, where a launch costs more than its work: the state kernel (awfl_xupd_tile_kernel) also makes the
+ * next stage's pressure + density / pressure ghosts (Dycore.h:310-321, :682-709; otherwise awfl_ptail_kernel) and phase 1 of the
+ * further tracers (their FCT multipliers, Dycore.h:525-540; otherwise awfl_xtr_tile_kernel<., 1>): two launches less per stage.
+ * mode 2 = fused, 1 = separate launches, 0 = automatic (fused while the ensemble is below ~1e6 cells).  Same bits either way. */
+int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode);
 /* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels, pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */

@@ -2014,6 +2014,36 @@ PAMA_D void store_adv_l(const Params &P, double *prim, int pf, int k, unsigned l
     for (int kk = 0; kk < HS; kk++) f[member_offset((int)((unsigned)(HS + P.nz + kk) * sz + lo))] = ghost_val;     // Dycore.h:671,676
 }
 
+// store_rho_pres<false> with a per-lane offset (the pressure pass of a cell inside the tile kernel: pressure_tail_body's arithmetic
+// on the values the lane still holds): `lo` = offset of the cell inside a level, `ke` = (level, member) entry
+PAMA_D void store_pres_l(const Params &P, double *prim, int k, unsigned lo, unsigned ke, double rho, double th, double rho_theta,
+                         bool subtract_hy) {
+#pragma clang fp contract(off)
+  g_ptr fr = uniw(prim + (long long)P_RHO * P.prim_fs), fp = uniw(prim + (long long)P_PRES * P.prim_fs);
+  const unsigned sz = (unsigned)P.sz;
+  double pres = P.C0 * pow_pos(P, rho_theta, P.gamma);
+  if (subtract_hy) pres -= P.hy_pres[ke];
+  fp[member_offset((int)((unsigned)(k + HS) * sz + lo))] = pres;
+  const bool bot = (k == 0), top = (k == P.nz - 1);
+  if (bot || top) {
+    const double gm1 = P.gamma - 1.0;
+    const double rho0_gm1 = pow_pos(P, rho, gm1);
+    const double theta0_g = pow_pos(P, th, P.gamma);
+    const double dzk = P.dz[ke];
+    const double coef = P.grav * gm1 * dzk / (P.gamma * P.C0 * theta0_g);
+    for (int kk = 0; kk < HS; kk++) {
+      const int kz = bot ? (HS - 1 - kk) : (HS + P.nz + kk);
+      const unsigned og = member_offset((int)((unsigned)kz * sz + lo));
+      const double arg = bot ? rho0_gm1 + coef * (kk + 1) : rho0_gm1 - coef * (kk + 1);
+      const double rho_g = pow_pos(P, arg, 1.0 / gm1);
+      double p_g = pres;                                          // mode B: copy (Dycore.h:678-681)
+      if (P.grav_balance) p_g = P.C0 * pow_pos(P, rho_g * th, P.gamma);    // mode A (Dycore.h:691-694)
+      fr[og] = rho_g;
+      fp[og] = p_g;
+    }
+  }
+}
+
 // ---- state tile (the arithmetic of flux_x_update_body's state pass, cell by cell) --------------------------------------------
 // fields of the state tile, in LDS order: 0 rho*u, 1 pressure, 2 u, 3 v, 4 w, 5 theta, 6 water vapour
 constexpr int XT_NS = 7;    // right-edge values a lane hands to its right neighbour
@@ -2083,7 +2113,7 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
                                double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
                                double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
                                const double (&Flo)[XT_NF], const double (&Fhi)[XT_NF], const double (&cen)[6], double dt_dyn,
-                               double dt_stage) {
+                               double dt_stage, bool with_pressure) {
   const bool have_y = !P.sim2d;
   const int k = X.k, j = X.j;
   const unsigned po = X.po, io = X.io;
@@ -2127,7 +2157,12 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
     const double m_0 = (STAGE > 1) ? mul_rn(q0[n], rho_0) : 0.0;
     const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
     store_adv_l(P, prim_out, P_U + n, k, lo, v * rrho, (l == 3) ? 0.0 : v * rrho);
-    if (l == 4) uniw(prim_out + (long long)P_PRES * P.prim_fs)[po] = v;   // the new rho*theta: pressure_tail_body makes the pressure of it
+    if (l == 4) {
+      // the new rho*theta: with_pressure -- the next stage's pressure and the density / pressure ghosts at once (small ensembles: one
+      // launch less per stage; the arithmetic of pressure_tail_body on the same doubles); else pressure_tail_body makes them of it
+      if (with_pressure) store_pres_l(P, prim_out, k, lo, X.ke, qn, v * rrho, v, !P.grav_balance);
+      else uniw(prim_out + (long long)P_PRES * P.prim_fs)[po] = v;
+    }
   }
   // water vapour (finish_tracer_cell): its own multiplier (sparse store + flags) and the update an unlimited neighbourhood gets
   own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, tseed, dzk, rdzk, dt_stage);
@@ -2154,10 +2189,12 @@ PAMA_D void xtile_tracer_polys(const Params &P, const double *__restrict__ prim_
   }
 }
 // the fluxes through the lane's left face, upwinded by the face mass flux the state kernel left in flux_x field 0 (Dycore.h:367-385)
+//   have_ruf / ruf_reg: the mass flux through the lane's left face handed over in a register (phase 1 inline in the state kernel: the
+//   lane has just formed it); else it is read from flux_x (a launch of its own)
 template <int NF>
 PAMA_D void xtile_tracer_face(const Params &P, const double *__restrict__ fx, const XLane &X, const double (&L)[NF],
-                              const double (&Rl)[NF], double (&F)[NF]) {
-  const double ruf = uni(fx)[X.io];
+                              const double (&Rl)[NF], double (&F)[NF], bool have_ruf = false, double ruf_reg = 0.0) {
+  const double ruf = have_ruf ? ruf_reg : uni(fx)[X.io];
   const bool up = ruf > 0.0;
 #pragma unroll
   for (int n = 0; n < NF; n++) F[n] = mul_rn(ruf, up ? Rl[n] : L[n]);

@@ -264,6 +264,39 @@ __global__ void __launch_bounds__(256) awfl_trfix_flat_kernel(Params P, const do
   tracer_fixup_cell_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, c);
 }
 
+// TILE form of the further tracers' x sweeps (one pair of tracers); have_ruf: inline in the state kernel (phase 1 only)
+template <int STAGE, int PHASE, int NF>
+__device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, int T, const double *__restrict__ prim_in,
+                                             const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                             const double *__restrict__ fx, const double *__restrict__ fy,
+                                             const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
+                                             const FctRows &rows, double dt_dyn, double dt_stage, const int *fa, double *lds,
+                                             bool have_ruf, double ruf_reg) {
+  double L[NF], R[NF], cen[NF], F[NF];
+  if (X.poly) {
+    xtile_tracer_polys<NF>(P, prim_in, X, fa, L, R, cen);
+#pragma unroll
+    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = R[f];
+  }
+  __syncthreads();
+  if (X.face) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) R[f] = lds[f * T + X.slot_l];
+  }
+  __syncthreads();
+  if (X.face) {
+    xtile_tracer_face<NF>(P, fx, X, L, R, F, have_ruf, ruf_reg);
+#pragma unroll
+    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = F[f];
+  }
+  __syncthreads();
+  if (X.upd) {
+    double Fhi[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) Fhi[f] = lds[f * T + X.slot_r];
+    xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
+  }
+}
 // TILE form of the fused x-sweep (xtile_* in awfl_device.h): a lane per cell, right-edge values and face fluxes exchanged through
 // LDS (XT_NS doubles per lane, used twice).  grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
 template <int STAGE>
@@ -272,7 +305,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
                                                               double *__restrict__ fx, const double *__restrict__ fy,
                                                               const double *__restrict__ fz, double *__restrict__ seed,
                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
-                                                              double dt_stage) {
+                                                              double dt_stage, int with_pressure, int tracers_inline) {
   extern __shared__ double xt_lds[];
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
@@ -298,41 +331,19 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
     double Fhi[XT_NF];
 #pragma unroll
     for (int f = 0; f < XT_NF; f++) Fhi[f] = xt_lds[f * T + X.slot_r];
-    xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage);
+    xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
   }
-}
-// TILE form of the further tracers' x sweeps: blockIdx.z = pair of tracers
-template <int STAGE, int PHASE, int NF>
-__device__ __forceinline__ void xtr_tile_run(const Params &P, const XTileGeom &G, const double *__restrict__ prim_in,
-                                             const double *__restrict__ prim0, double *__restrict__ prim_out,
-                                             const double *__restrict__ fx, const double *__restrict__ fy,
-                                             const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
-                                             const FctRows &rows, double dt_dyn, double dt_stage, const int *fa, double *lds) {
-  const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
-  const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
-  double L[NF], R[NF], cen[NF], F[NF];
-  if (X.poly) {
-    xtile_tracer_polys<NF>(P, prim_in, X, fa, L, R, cen);
-#pragma unroll
-    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = R[f];
-  }
-  __syncthreads();
-  if (X.face) {
-#pragma unroll
-    for (int f = 0; f < NF; f++) R[f] = lds[f * T + X.slot_l];
-  }
-  __syncthreads();
-  if (X.face) {
-    xtile_tracer_face<NF>(P, fx, X, L, R, F);
-#pragma unroll
-    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = F[f];
-  }
-  __syncthreads();
-  if (X.upd) {
-    double Fhi[NF];
-#pragma unroll
-    for (int f = 0; f < NF; f++) Fhi[f] = lds[f * T + X.slot_r];
-    xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
+  // phase 1 of the further tracers (their FCT multipliers) inline -- small ensembles, where a launch costs more than the work: the
+  // mass flux through the lane's left face is still in its register
+  if (tracers_inline) {
+    for (int i = 0; i < P.nt - 1; i += 2) {
+      const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
+      __syncthreads();
+      if (i + 1 < P.nt - 1)
+        xtr_tile_run<STAGE, 1, 2>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+      else
+        xtr_tile_run<STAGE, 1, 1>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+    }
   }
 }
 template <int STAGE, int PHASE>
@@ -344,11 +355,13 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
                                                              double dt_stage) {
   extern __shared__ double xt_lds[];
   const int pair = (int)blockIdx.z;
+  const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
+  const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
   const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
   if (2 * pair + 1 < P.nt - 1)
-    xtr_tile_run<STAGE, PHASE, 2>(P, G, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+    xtr_tile_run<STAGE, PHASE, 2>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
   else
-    xtr_tile_run<STAGE, PHASE, 1>(P, G, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+    xtr_tile_run<STAGE, PHASE, 1>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
 }
 
 // TILE form of the fused stage's y and z sweeps (ftile_* in awfl_device.h): a lane per cell, one launch for both directions --
@@ -591,7 +604,9 @@ struct pam_amd_awfl {
   int xtile_mode = 0;          // 0 automatic, 1 sweep kernels (a wavefront per line span), 2 tile kernels (a lane per cell)
   bool xtile = false;          // resolved: the x direction of the fused stage runs as tile kernels
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
-  bool independent_ranges = false;   // fused stage, several member ranges: each range's whole stage on its own stream
+  bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
+  int tile_pressure_mode = 0;  // 0 automatic, 1 separate pressure pass, 2 inside the x tile kernel
+  bool tile_pressure = true;   // x tile kernels: the next stage's pressure inside awfl_xupd_tile_kernel (no awfl_ptail_kernel launch)
   int ftile_mode = 0;          // 0 automatic, 1 flat-lane sweeps, 2 tile kernel
   bool ftile = true;           // resolved -- flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
   int ft_tc_y = 0, ft_tc_z = 0;          // cells / levels per y / z tile (0 = automatic)
@@ -692,7 +707,9 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
 // wavefronts sweep one span each.  `span_override` > 0 forces a value (tests / tuning).
 static void choose_span(int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
   const long long nib = nlines * ((nens + 63) / 64);
-  const long long want_units = 6144;
+  // (3072 since round 4, 6144 before: whole x lines and 2 z spans at C2's 128-member shard and at C3 instead of half lines --
+  // fewer redundant start-up / closing polynomials; C2@128 +1 ... +3 %, C3 +1.4 %, C4 unchanged: it stops at the shortest span)
+  const long long want_units = 3072;
   if (span_override > 0) {
     span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
   } else {
@@ -840,14 +857,15 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     {
       ScopedTimer st(h, "xupd", s);
       hipLaunchKernelGGL(awfl_xupd_tile_kernel<STAGE>, grid, block, (size_t)XT_NS * threads * sizeof(double), s, P, G, prim_in, prim0,
-                         prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+                         prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                         h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
     if (npairs > 65535) return fail(PAM_AMD_EINVAL, "x-tile launch: too many tracer pairs");
     if (npairs > 0) {
       const dim3 tgrid(grid.x, grid.y, (unsigned)npairs);
-      {
+      if (!h->tile_pressure) {       // (small ensembles: phase 1 ran inline in the state kernel, like the pressure pass)
         ScopedTimer st(h, "xtr1", s);
         hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * threads * sizeof(double), s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
@@ -907,7 +925,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
 template <int STAGE>
 int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, EnsRange r,
                 hipStream_t s) {
-  {
+  if (!(h->xtile && h->tile_pressure)) {      // (small ensembles: the x tile kernel has already made the pressure)
     ScopedTimer st(h, "ptail", s);
     const dim3 g = cell_grid(h->P, r, (h->P.nz + TAIL_LEVELS - 1) / TAIL_LEVELS);
     hipLaunchKernelGGL(awfl_ptail_kernel, g, dim3(256), 0, s, h->P, r, prim_out);
@@ -978,6 +996,9 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
   // build no halo rows; measured on MI355X, 32x32x60: 1 member 67 -> 20 us per stage, 8 members 85 -> 82, 32 members 184 -> 320)
   h->ftile = h->ftile_mode == 2 || (h->ftile_mode == 0 && P.ncell <= 262144);
+  // the pressure pass inside the x tile kernel while a stage is a handful of short launches (one launch of ~10 us less); above, the
+  // separate pass with the pow tables in LDS and 6 levels per lane is cheaper than the tile kernel's longer lanes
+  h->tile_pressure = h->tile_pressure_mode == 2 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
 }
 
 // (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
@@ -1008,8 +1029,13 @@ int build_chunks(pam_amd_awfl *h) {
     // ~11.8 k wave-units of flux work per chunk (128 members of a 32x32x60 CRM) measured best on MI355X for 256..2048
     // members; smaller jobs run as one chunk
     n = (int)((W + 8000) / 11776);
-    if (n < 1 || h->fused) n = 1;
+    if (n < 1) n = 1;
     if (n > 16) n = 16;
+    // Fused stage: TWO ranges, each running its whole stage on its own stream (independent_ranges below): the launches of a stage
+    // overlap their ramp-up and drain phases with the other range's kernels.  Measured on MI355X (round 4, 1 -> 2 independent ranges):
+    // C2 at 128 members 2.29 -> 2.37 G, at 256 2.44 -> 2.52, at 1024 2.600 -> 2.610; C3 1.84 -> 1.93; C4 0.79 -> 0.81; four
+    // ranges lose (C4 0.70, C3 1.83), and so do two ranges that share one compute stream (round 2's schedule: C4 0.65).
+    if (h->fused) n = (nens >= 128) ? 2 : 1;
   }
   if (h->fused && (h->flat || h->xtile)) n = 1;    // flat lanes and tile kernels take the whole ensemble in one launch
   if (h->P.flat_cells) n = 1;                      // (pointwise kernels with a flat grid over every cell)
@@ -1618,6 +1644,14 @@ int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_ti
   h->ftile_mode = enable;
   h->ft_tc_y = cells_per_y_tile;
   h->ft_tc_z = levels_per_z_tile;
+  resolve_lane_mapping(h);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_tile_fusion: 0 = automatic, 1 = separate pressure pass, 2 = inside the x tile kernel");
+  h->tile_pressure_mode = mode;
   resolve_lane_mapping(h);
   return PAM_AMD_OK;
 }

@@ -261,6 +261,10 @@ class Dycore:
         check(self._lib.pam_amd_awfl_set_flux_tile(self._h, {"auto": 0, "sweep": 1, "tile": 2}[mode], int(cells_per_y_tile),
                                                    int(levels_per_z_tile)))
 
+    def set_tile_fusion(self, mode="auto"):
+        """x tile kernels: the pressure pass "inside" the tile kernel | "separate" | "auto" """
+        check(self._lib.pam_amd_awfl_set_tile_fusion(self._h, {"auto": 0, "separate": 1, "inside": 2}[mode]))
+
     def get_lane_mapping(self):
         flat, tile, cells = C.c_int(), C.c_int(), C.c_int()
         g = (C.c_int * 6)()

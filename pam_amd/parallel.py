@@ -18,17 +18,35 @@ def shard_range(nens_total, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_MIN_BUF = {}
+
+
 def global_min(value, device=None, group=None):
-    """min over ranks of a python float (identity when torch.distributed is not initialised)."""
+    """min over ranks of a python float (identity when torch.distributed is not initialised).  ONE reusable 8-byte tensor per device
+    (pinned when it lives on the host): no allocation per timeStep."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    key = str(device) if device is not None else "cpu"
+    t = _MIN_BUF.get(key)
+    if t is None:
+        if device is not None:
+            t = torch.empty(1, dtype=torch.float64, device=device)
+        else:
+            t = torch.empty(1, dtype=torch.float64)
+            try:
+                t = t.pin_memory()
+            except Exception:
+                pass
+        _MIN_BUF[key] = t
+    t.fill_(float(value))
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return float(t.item())
 
 
 def sharded_time_step(dycore, coupler, cfl=0.8, group=None):
-    """Dycore::timeStep on this rank's shard with the ensemble-global dt_dyn (what the unsharded reference computes)."""
+    """Dycore::timeStep on this rank's shard with the ensemble-global dt_dyn (what the unsharded reference computes): the shard's
+    CFL minimum (one 8-byte read-back: compute_time_step), ONE all-reduce(MIN) of 8 bytes, then time_step with the agreed dt as a
+    hint -- no second read-back, no further host synchronisation until the caller asks for one."""
     dt_local = dycore.compute_time_step(coupler, cfl)
     backend = dist.get_backend(group) if (dist.is_available() and dist.is_initialized()) else None
     dev = coupler.device if backend == "nccl" else None

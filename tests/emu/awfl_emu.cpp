@@ -28,6 +28,7 @@ struct Emu {
   int flat = 0;   // fused stage: the y/z sweeps run with flat (x, member) lanes (flat_lane) and the fix-up with a lane per cell
   int xtile = 0;  // fused stage: the x direction runs as tile kernels (a lane per cell; xtile_* bodies) instead of sweeps
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides
+  int tile_pressure = 0;   // x tile kernels: the pressure pass inside xtile_state_finish (no pressure_tail_body pass)
   int ftile = 0, ft_tc_y = 0, ft_tc_z = 0;   // flat lanes: the y/z fluxes as tile kernels (ftile_* bodies); cells / levels per tile
   std::vector<int> fct_flags;   // row flags of the FCT multiplier (FctRows)
   int fct_seq = 0;
@@ -226,7 +227,7 @@ static void xupd_tile_launch(Emu *h, const double *in, const double *p0, double 
           double Fhi[XT_NF];
           for (int f = 0; f < XT_NF; f++) Fhi[f] = lds[(size_t)f * T + st[t].X.slot_r];
           xtile_state_finish<STAGE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, st[t].X, st[t].F,
-                                    Fhi, st[t].cen, dt, dt_stage);
+                                    Fhi, st[t].cen, dt, dt_stage, h->tile_pressure != 0);
         }
     }
   auto tracer_phase = [&](auto phase_tag) {
@@ -314,7 +315,8 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
 template <int STAGE>
 static void tail_launch(Emu *h, const double *in, const double *p0, double *out, double dt) {
   const Params &P = h->P;
-  for (long long idx = 0; idx < P.ncell; idx++) pressure_tail_body(P, out, cell_of(P, idx));
+  if (!(h->xtile && h->tile_pressure))
+    for (long long idx = 0; idx < P.ncell; idx++) pressure_tail_body(P, out, cell_of(P, idx));
   const FctRows rows = fct_rows(h);
   bool any = false;
   for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || rows.any[b] == rows.seq;
@@ -390,6 +392,7 @@ void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
 void emu_set_xtr_split(Emu *h, int split) { h->xtr_split = split; }
 void emu_set_lane_mapping(Emu *h, int flat, int xtile) { h->flat = flat; h->xtile = xtile; }
 void emu_set_x_tile(Emu *h, int w, int tc, int lpb) { h->xt_w = w; h->xt_tc = tc; h->xt_lpb = lpb; }
+void emu_set_tile_pressure(Emu *h, int on) { h->tile_pressure = on; }
 void emu_set_flux_tile(Emu *h, int on, int tc_y, int tc_z) { h->ftile = on; h->ft_tc_y = tc_y; h->ft_tc_z = tc_z; }
 void emu_x_tile_geometry(Emu *h, int *g) {
   const XTileGeom G = xtile_geometry(h->P, h->xt_w, h->xt_tc, h->xt_lpb);

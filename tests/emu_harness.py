@@ -38,6 +38,7 @@ def load():
         lib.emu_set_x_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         lib.emu_x_tile_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         lib.emu_set_flux_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.emu_set_tile_pressure.argtypes = [C.c_void_p, C.c_int]
         lib.emu_vz_per_ens.argtypes = [C.c_void_p]
         lib.emu_buffer.restype = _DP
         lib.emu_buffer.argtypes = [C.c_void_p, C.c_char_p]
@@ -103,6 +104,9 @@ class EmuDycore:
     def set_flux_tile(self, on, tc_y=0, tc_z=0):
         """with flat lanes: the y/z fluxes as tile kernels (a lane per cell) instead of flat-lane sweeps"""
         self.lib.emu_set_flux_tile(self.h, int(bool(on)), int(tc_y), int(tc_z))
+
+    def set_tile_pressure(self, on):
+        self.lib.emu_set_tile_pressure(self.h, int(bool(on)))
 
     def x_tile_geometry(self):
         g = (C.c_int * 6)()

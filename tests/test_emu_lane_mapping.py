@@ -54,6 +54,7 @@ def _run_emu(args, f, flat, xtile, tile=(0, 0, 0), span=0, ftile=None):
     g.set_x_tile(*tile)
     if ftile is not None:
         g.set_flux_tile(True, *ftile)
+        g.set_tile_pressure(xtile)         # (with the y/z tile kernels also: the pressure pass inside the x tile kernel)
     g.declare_current_profile_as_hydrostatic(ff)
     ncyc = [g.time_step(ff, dt)[0] for dt in (2.0, 0.7)]
     return ncyc, ff, g

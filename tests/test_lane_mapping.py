@@ -67,6 +67,7 @@ def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=
     dycore.set_lane_mapping(yz, xk)
     dycore.set_x_tile(*tile)
     dycore.set_flux_tile(*ftile)
+    dycore.set_tile_fusion("inside" if ftile[0] == "tile" else ("separate" if ftile[0] == "sweep" else "auto"))
     mapping = dycore.get_lane_mapping()
     coupler.load_fields(f)
     if not mode_a:

@@ -17,5 +17,5 @@ def test_soak_configs_two_steps_are_bit_identical_across_schedules():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_configs.py"), "2"], capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "SOAK OK" in r.stdout and r.stdout.count("bit-identical x3") == 5, r.stdout
+    assert "SOAK OK" in r.stdout and r.stdout.count("bit-identical x4") == 5, r.stdout
     assert time.time() - t0 < 240, "soak_configs.py 2 is budgeted at a few minutes (60 s of GPU work)"

@@ -1,6 +1,6 @@
 """Determinism / race check at the full sizes of C2 (with vapour limited: --limiter input), C3 and C4: the same N timeSteps run
-twice from the same inputs -- once with the default schedule, once with the fused stage on two member ranges -- must give
-bit-identical coupler fields, and both must equal the three-kernel stage (which shares no kernel with the x-sweeps' read-backs
+from the same inputs -- with the default schedule (two independent member ranges), with one range, with four ranges on a shared
+compute stream -- must give bit-identical coupler fields, and all must equal the three-kernel stage (which shares no kernel with the x-sweeps' read-backs
 of their own stores, the two-phase tracer sweeps or the line-driven fix-up).   usage: tools/soak_configs.py [nsteps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,20 +41,23 @@ for name, (nens, nx, ny, tr, consts, dry) in CONFIGS.items():
         torch.cuda.synchronize()
         return tot, {k: c.dm.get(k, readonly=True).clone() for k in names}, d.debug_fct_rows()
 
-    na, a, rows = run(True, 0)
-    nb, b, _ = run(True, 2)
-    nc, cc, _ = run(False, 1)
-    ok = na == nb == nc
+    na, a, rows = run(True, 0)          # default schedule: two independent member ranges
+    nb, b, _ = run(True, 1)             # one range
+    nc, cc, _ = run(False, 1)           # three-kernel stage
+    d.set_range_schedule(False)
+    nd, dd, _ = run(True, 4)            # four ranges, the polynomial kernels on one shared compute stream
+    d.set_range_schedule(True)
+    ok = na == nb == nc == nd
     for k in names:
-        same = torch.equal(a[k], b[k]) and torch.equal(a[k], cc[k])
+        same = torch.equal(a[k], b[k]) and torch.equal(a[k], cc[k]) and torch.equal(a[k], dd[k])
         fin = bool(torch.isfinite(a[k]).all())
         if not (same and fin):
             print(name, k, "DIFFERENT" if not same else "", "NON-FINITE" if not fin else "")
         ok = ok and same and fin
     print("%s: %d sub-steps, rows flagged in the last stage %d of %d, max|w| %.3f m/s: %s" % (
-        name, na, rows[0], rows[1], float(a["wvel"].abs().max()), "bit-identical x3" if ok else "FAILED"), flush=True)
+        name, na, rows[0], rows[1], float(a["wvel"].abs().max()), "bit-identical x4" if ok else "FAILED"), flush=True)
     allok = allok and ok
-    d.finalize(c); c.dm.finalize(); del c, d, a, b, cc, init
+    d.finalize(c); c.dm.finalize(); del c, d, a, b, cc, dd, init
     torch.cuda.empty_cache()
 print("SOAK OK" if allok else "SOAK FAILED")
 sys.exit(0 if allok else 1)
