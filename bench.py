@@ -478,7 +478,7 @@ def stage_rooflines(job, alone):
     return out
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def load_profile(cfg_name):

@@ -1964,8 +1964,17 @@ struct XLane {
   bool poly, face, upd;                 // builds polynomials / forms its left face / completes its cell
   int slot, slot_l, slot_r;             // LDS slots: own, of the row to the left, of the row to the right
   unsigned po, io, ke;                  // offsets of the cell inside a prim field / an interior-sized field; of (level, member)
-  unsigned pm2, pm1, pp1, pp2;          // prim offsets of the cells i-2, i-1, i+1, i+2 (periodic, Dycore.h:629-657)
+  // the STAGED tile: every stage-input value of the tile is loaded from global memory ONCE (each lane its own cell; in a tile with
+  // halo rows the first lanes also the two cells beyond the halo row on each side) into LDS, and the 5-point stencils are read
+  // from there (Dycore.h:629-657: periodic in x -- inside a whole-line tile the stencil wraps around the tile's rows)
+  int s5[5];                            // LDS elements (inside one staged field) of the cells i-2 .. i+2
+  int nstage;                           // cells this lane stages (0 .. 3): its own first
+  unsigned stage_po[3];                 // their prim offsets
+  int stage_el[3];                      // their LDS elements
 };
+// LDS elements of one staged field of a tile kernel's workgroup
+PAMA_HD int xtile_stage_rows(const XTileGeom &G) { return xtile_rows(G) + 4 * G.halo; }
+PAMA_HD int xtile_stage_elems(const XTileGeom &G) { return G.lpb * xtile_stage_rows(G) * G.W; }
 // (bx, by): workgroup index (tile of a line and member block; group of lines); (tx, ty, tz): lane inside it = (member of the row,
 // row, line of the group)
 PAMA_D XLane xtile_lane(const Params &P, const XTileGeom &G, int bx, int by, int tx, int ty, int tz) {
@@ -1995,11 +2004,33 @@ PAMA_D XLane xtile_lane(const Params &P, const XTileGeom &G, int bx, int by, int
   const unsigned lev_p = (unsigned)(X.k + HS) * (unsigned)P.sz, lev_i = (unsigned)X.k * (unsigned)P.sz;
   X.po = member_offset((int)(lev_p + at(X.i)));
   X.io = member_offset((int)(lev_i + at(X.i)));
-  X.pm2 = member_offset((int)(lev_p + at(X.i - 2)));
-  X.pm1 = member_offset((int)(lev_p + at(X.i - 1)));
-  X.pp1 = member_offset((int)(lev_p + at(X.i + 1)));
-  X.pp2 = member_offset((int)(lev_p + at(X.i + 2)));
   X.ke = (unsigned)X.k * (unsigned)P.nens + (unsigned)X.e;
+  // staged tile: rows of a line's slab in LDS = [2 cells below the tile's rows] + the rows + [2 cells above] with halo rows, the rows
+  // alone in a whole-line tile (the stencil wraps)
+  const int srows = xtile_stage_rows(G), sbase = tz * srows;
+  const int shift = 2 * G.halo;
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    int r = ty + s - 2;
+    if (G.halo == 0) r = r < 0 ? r + nrow : (r >= nrow ? r - nrow : r);
+    X.s5[s] = (sbase + r + shift) * G.W + tx;
+  }
+  X.nstage = 0;
+  if (valid) {
+    X.stage_po[0] = X.po;
+    X.stage_el[0] = (sbase + ty + shift) * G.W + tx;
+    X.nstage = 1;
+    if (G.halo) {
+      // the four cells beyond the halo rows (c0-3, c0-2 | c0+tcl+1, c0+tcl+2) are staged by the lanes of the first rows
+      for (int r = ty; r < 4; r += nrow) {
+        const int cc = (r < 2) ? c0 - 3 + r : c0 + tcl + 1 + (r - 2);
+        const int srow = (r < 2) ? r : nrow + r;          // (rows 0, 1 | nrow + 2, nrow + 3 of the slab)
+        X.stage_po[X.nstage] = member_offset((int)(lev_p + at(cc)));
+        X.stage_el[X.nstage] = (sbase + srow) * G.W + tx;
+        X.nstage++;
+      }
+    }
+  }
   return X;
 }
 
@@ -2048,43 +2079,60 @@ PAMA_D void store_pres_l(const Params &P, double *prim, int k, unsigned lo, unsi
 // fields of the state tile, in LDS order: 0 rho*u, 1 pressure, 2 u, 3 v, 4 w, 5 theta, 6 water vapour
 constexpr int XT_NS = 7;    // right-edge values a lane hands to its right neighbour
 constexpr int XT_NF = 6;    // face fluxes a lane hands to its left neighbour: rho, rho u, rho v, rho w, rho theta, vapour
-// A: one polynomial per field of the lane's own cell.  cen: the stage-input values the update needs again: rho*u, v, w, theta,
-// vapour (window element of the cell in the sweep) and the density
-PAMA_D void xtile_state_polys(const Params &P, const double *__restrict__ prim_in, const XLane &X, double (&L)[XT_NS],
-                              double (&R)[XT_NS], double (&cen)[6]) {
-  const WenoConsts wc = weno_consts();
-  const unsigned o5[5] = {X.pm2, X.pm1, X.po, X.pp1, X.pp2};
-  auto stencil = [&](int pf, double (&u)[5]) {
-    gc_ptr f = uni(prim_in + (long long)pf * P.prim_fs);
+// phase 0: the lane's share of the staged tile.  fields[f]: prim field index of staged field f; st: the staged fields, TS elements
+// each; own[f]: the values of the lane's own cell (kept in registers: the centre of its stencils)
+template <int NSF>
+PAMA_D void xtile_stage(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double *st, int TS,
+                        double (&own)[NSF]) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) u[s] = f[o5[s]];
+  for (int f = 0; f < NSF; f++) {
+    gc_ptr fp = uni(prim_in + (long long)fields[f] * P.prim_fs);
+    own[f] = 0.0;
+    for (int i = 0; i < X.nstage; i++) {
+      const double v = fp[X.stage_po[i]];
+      st[f * TS + X.stage_el[i]] = v;
+      if (i == 0) own[f] = v;
+    }
+  }
+}
+PAMA_D void xtile_state_fields(const Params &P, int (&fields)[XT_NS]) {
+  fields[0] = P_RHO; fields[1] = P_PRES; fields[2] = P_U; fields[3] = P_V; fields[4] = P_W; fields[5] = P_THETA; fields[6] = P_TR0 + P.idWV;
+}
+// A: one polynomial per field of the lane's own cell, stencils from the staged tile (staged fields: rho, p, u, v, w, theta, vapour).
+// cen: the stage-input values the update needs again: rho*u, v, w, theta, vapour (window element of the cell in the sweep) and the
+// density
+PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[XT_NS],
+                              double (&L)[XT_NS], double (&R)[XT_NS], double (&cen)[6]) {
+  const WenoConsts wc = weno_consts();
+  auto stencil = [&](int f, double (&u)[5]) {
+#pragma unroll
+    for (int s = 0; s < 5; s++) u[s] = (s == 2) ? own[f] : st[f * TS + X.s5[s]];
   };
   double r[5], u[5], w[5];
-  stencil(P_RHO, r);
-  stencil(P_U, u);
+  stencil(0, r);
+  stencil(2, u);
 #pragma unroll
   for (int s = 0; s < 5; s++) w[s] = mul_rn(r[s], u[s]);
   cen[0] = w[2];
   cen[5] = r[2];
   weno5_const(w, wc, L[0], R[0]);
   weno5_const(u, wc, L[2], R[2]);
-  stencil(P_PRES, w);
+  stencil(1, w);
   weno5_const(w, wc, L[1], R[1]);
+  cen[1] = own[3];
   if (!P.sim2d) {
-    stencil(P_V, w);
-    cen[1] = w[2];
+    stencil(3, w);
     weno5_const(w, wc, L[3], R[3]);
   } else {                                                  // 2-D: the v flux is never used (skip_advected_v)
-    cen[1] = uni(prim_in + (long long)P_V * P.prim_fs)[X.po];
     L[3] = R[3] = 0.0;
   }
-  stencil(P_W, w);
+  stencil(4, w);
   cen[2] = w[2];
   weno5_const(w, wc, L[4], R[4]);
-  stencil(P_THETA, w);
+  stencil(5, w);
   cen[3] = w[2];
   weno5_const(w, wc, L[5], R[5]);
-  stencil(P_TR0 + P.idWV, w);
+  stencil(6, w);
   cen[4] = w[2];
   weno5_const(w, wc, L[6], R[6]);
 }
@@ -2174,16 +2222,14 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
 
 // ---- tracer tiles (the arithmetic of x_tracer_sweep, cell by cell): NF further tracers per lane ------------------------------
 template <int NF>
-PAMA_D void xtile_tracer_polys(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int *fa, double (&L)[NF],
+PAMA_D void xtile_tracer_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[NF], double (&L)[NF],
                                double (&R)[NF], double (&cen)[NF]) {
   const WenoConsts wc = weno_consts();
-  const unsigned o5[5] = {X.pm2, X.pm1, X.po, X.pp1, X.pp2};
 #pragma unroll
   for (int n = 0; n < NF; n++) {
-    gc_ptr f = uni(prim_in + (long long)(P_U + fa[n]) * P.prim_fs);
     double w[5];
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[s] = f[o5[s]];
+    for (int s = 0; s < 5; s++) w[s] = (s == 2) ? own[n] : st[n * TS + X.s5[s]];
     cen[n] = w[2];
     weno5_const(w, wc, L[n], R[n]);
   }

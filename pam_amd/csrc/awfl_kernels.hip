@@ -266,34 +266,38 @@ __global__ void __launch_bounds__(256) awfl_trfix_flat_kernel(Params P, const do
 
 // TILE form of the further tracers' x sweeps (one pair of tracers); have_ruf: inline in the state kernel (phase 1 only)
 template <int STAGE, int PHASE, int NF>
-__device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, int T, const double *__restrict__ prim_in,
+__device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, int T, int TS, const double *__restrict__ prim_in,
                                              const double *__restrict__ prim0, double *__restrict__ prim_out,
                                              const double *__restrict__ fx, const double *__restrict__ fy,
                                              const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
                                              const FctRows &rows, double dt_dyn, double dt_stage, const int *fa, double *lds,
                                              bool have_ruf, double ruf_reg) {
-  double L[NF], R[NF], cen[NF], F[NF];
+  // lds: NF staged fields of TS elements (later: the face fluxes), then NF x T right-edge values
+  double *st = lds, *ex = lds + NF * TS;
+  double L[NF], R[NF], cen[NF], F[NF], own[NF];
+  int fields[NF];
+#pragma unroll
+  for (int n = 0; n < NF; n++) fields[n] = P_U + fa[n];
+  xtile_stage<NF>(P, prim_in, X, fields, st, TS, own);
+  __syncthreads();
   if (X.poly) {
-    xtile_tracer_polys<NF>(P, prim_in, X, fa, L, R, cen);
+    xtile_tracer_polys<NF>(P, X, st, TS, own, L, R, cen);
 #pragma unroll
-    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = R[f];
+    for (int f = 0; f < NF; f++) ex[f * T + X.slot] = R[f];
   }
   __syncthreads();
   if (X.face) {
 #pragma unroll
-    for (int f = 0; f < NF; f++) R[f] = lds[f * T + X.slot_l];
-  }
-  __syncthreads();
-  if (X.face) {
+    for (int f = 0; f < NF; f++) R[f] = ex[f * T + X.slot_l];
     xtile_tracer_face<NF>(P, fx, X, L, R, F, have_ruf, ruf_reg);
 #pragma unroll
-    for (int f = 0; f < NF; f++) lds[f * T + X.slot] = F[f];
+    for (int f = 0; f < NF; f++) st[f * T + X.slot] = F[f];
   }
   __syncthreads();
   if (X.upd) {
     double Fhi[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) Fhi[f] = lds[f * T + X.slot_r];
+    for (int f = 0; f < NF; f++) Fhi[f] = st[f * T + X.slot_r];
     xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
   }
 }
@@ -309,28 +313,32 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   extern __shared__ double xt_lds[];
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
-  double L[XT_NS], R[XT_NS], cen[6], F[XT_NF];
+  const int TS = xtile_stage_elems(G);
+  // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
+  double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
+  double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
+  int fields[XT_NS];
+  xtile_state_fields(P, fields);
+  xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
+  __syncthreads();
   if (X.poly) {
-    xtile_state_polys(P, prim_in, X, L, R, cen);
+    xtile_state_polys(P, X, st, TS, own, L, R, cen);
 #pragma unroll
-    for (int f = 0; f < XT_NS; f++) xt_lds[f * T + X.slot] = R[f];
+    for (int f = 0; f < XT_NS; f++) ex[f * T + X.slot] = R[f];
   }
   __syncthreads();
   if (X.face) {
 #pragma unroll
-    for (int f = 0; f < XT_NS; f++) R[f] = xt_lds[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
-  }
-  __syncthreads();
-  if (X.face) {
+    for (int f = 0; f < XT_NS; f++) R[f] = ex[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
     xtile_state_face(P, fx, X, L, R, X.upd, F);
 #pragma unroll
-    for (int f = 0; f < XT_NF; f++) xt_lds[f * T + X.slot] = F[f];
+    for (int f = 0; f < XT_NF; f++) st[f * T + X.slot] = F[f];          // (every stencil read of the staged tile is behind the barrier)
   }
   __syncthreads();
   if (X.upd) {
     double Fhi[XT_NF];
 #pragma unroll
-    for (int f = 0; f < XT_NF; f++) Fhi[f] = xt_lds[f * T + X.slot_r];
+    for (int f = 0; f < XT_NF; f++) Fhi[f] = st[f * T + X.slot_r];
     xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
   }
   // phase 1 of the further tracers (their FCT multipliers) inline -- small ensembles, where a launch costs more than the work: the
@@ -340,9 +348,9 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
       const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
       __syncthreads();
       if (i + 1 < P.nt - 1)
-        xtr_tile_run<STAGE, 1, 2>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+        xtr_tile_run<STAGE, 1, 2>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
       else
-        xtr_tile_run<STAGE, 1, 1>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+        xtr_tile_run<STAGE, 1, 1>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
     }
   }
 }
@@ -357,11 +365,12 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
   const int pair = (int)blockIdx.z;
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
+  const int TS = xtile_stage_elems(G);
   const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
   if (2 * pair + 1 < P.nt - 1)
-    xtr_tile_run<STAGE, PHASE, 2>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
+    xtr_tile_run<STAGE, PHASE, 2>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
   else
-    xtr_tile_run<STAGE, PHASE, 1>(P, X, T, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
+    xtr_tile_run<STAGE, PHASE, 1>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
 }
 
 // TILE form of the fused stage's y and z sweeps (ftile_* in awfl_device.h): a lane per cell, one launch for both directions --
@@ -852,11 +861,13 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     const dim3 block((unsigned)G.W, (unsigned)xtile_rows(G), (unsigned)G.lpb);
     const dim3 grid((unsigned)(G.ntl * G.nmb), (unsigned)((nlines + G.lpb - 1) / G.lpb), 1);
     if (grid.y > 65535u) return fail(PAM_AMD_EINVAL, "x-tile launch: more than 65535 groups of x lines");
+    if ((size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) > 160 * 1024)
+      return fail(PAM_AMD_EINVAL, "x-tile launch: the staged tile does not fit the 160 KB of LDS");
     // a wavefront is one row of FCT flags only when a row of the tile is exactly one 64-member block
     const bool wave_is_row = (G.W == 64 && P.nens % 64 == 0);
     {
       ScopedTimer st(h, "xupd", s);
-      hipLaunchKernelGGL(awfl_xupd_tile_kernel<STAGE>, grid, block, (size_t)XT_NS * threads * sizeof(double), s, P, G, prim_in, prim0,
+      hipLaunchKernelGGL(awfl_xupd_tile_kernel<STAGE>, grid, block, (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
                          prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
                          h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
       HIP_TRY(hipGetLastError());
@@ -867,13 +878,13 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       const dim3 tgrid(grid.x, grid.y, (unsigned)npairs);
       if (!h->tile_pressure) {       // (small ensembles: phase 1 ran inline in the state kernel, like the pressure pass)
         ScopedTimer st(h, "xtr1", s);
-        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * threads * sizeof(double), s, P, G, prim_in, prim0,
+        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
         HIP_TRY(hipGetLastError());
       }
       {
         ScopedTimer st(h, "xtr2", s);
-        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid, block, (size_t)2 * threads * sizeof(double), s, P, G, prim_in, prim0,
+        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
         HIP_TRY(hipGetLastError());
       }
@@ -1221,6 +1232,18 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // the tile kernels stage their tiles in LDS: up to 14 doubles per lane of a 1024-lane workgroup
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 0;   // no residency cap by default
   resolve_lane_mapping(h);

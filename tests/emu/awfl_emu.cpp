@@ -195,14 +195,18 @@ static void xupd_tile_launch(Emu *h, const double *in, const double *p0, double 
   const XTileGeom G = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
   const int rows = xtile_rows(G), T = xtile_threads(G);
   const int gx = G.ntl * G.nmb, gy = (P.nz * P.ny + G.lpb - 1) / G.lpb;
-  struct Lane { XLane X; double L[XT_NS], R[XT_NS], cen[6], F[XT_NF]; };
+  const int TS = xtile_stage_elems(G);
+  struct Lane { XLane X; double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS]; };
   std::vector<Lane> st(T);
-  std::vector<double> lds((size_t)XT_NS * T);
+  std::vector<double> stage((size_t)XT_NS * TS), lds((size_t)XT_NS * T);
   const FctRows fr = fct_rows(h);
   const int npairs = (P.nt - 1 + 1) / 2;
+  int sfields[XT_NS];
+  xtile_state_fields(P, sfields);
   for (int by = 0; by < gy; by++)
     for (int bx = 0; bx < gx; bx++) {
       std::fill(lds.begin(), lds.end(), NAN);
+      std::fill(stage.begin(), stage.end(), NAN);
       for (int tz = 0; tz < G.lpb; tz++)
         for (int ty = 0; ty < rows; ty++)
           for (int tx = 0; tx < G.W; tx++) {
@@ -210,65 +214,82 @@ static void xupd_tile_launch(Emu *h, const double *in, const double *p0, double 
             Lane &l = st[t];
             l.X = xtile_lane(P, G, bx, by, tx, ty, tz);
             if (l.X.slot != t) abort();
-            if (!l.X.poly) continue;
-            xtile_state_polys(P, in, l.X, l.L, l.R, l.cen);
-            for (int f = 0; f < XT_NS; f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+            xtile_stage<XT_NS>(P, in, l.X, sfields, stage.data(), TS, l.own);
           }
+      for (int t = 0; t < T; t++)
+        if (st[t].X.poly) {
+          Lane &l = st[t];
+          xtile_state_polys(P, l.X, stage.data(), TS, l.own, l.L, l.R, l.cen);
+          for (int f = 0; f < XT_NS; f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+        }
       for (int t = 0; t < T; t++)
         if (st[t].X.face)
           for (int f = 0; f < XT_NS; f++) st[t].R[f] = lds[(size_t)f * T + st[t].X.slot_l];
+      std::fill(stage.begin(), stage.end(), NAN);      // (the staged tile is dead: the face fluxes take its place)
       for (int t = 0; t < T; t++)
         if (st[t].X.face) {
           xtile_state_face(P, h->fx.data(), st[t].X, st[t].L, st[t].R, st[t].X.upd, st[t].F);
-          for (int f = 0; f < XT_NF; f++) lds[(size_t)f * T + st[t].X.slot] = st[t].F[f];
+          for (int f = 0; f < XT_NF; f++) stage[(size_t)f * T + st[t].X.slot] = st[t].F[f];
         }
       for (int t = 0; t < T; t++)
         if (st[t].X.upd) {
           double Fhi[XT_NF];
-          for (int f = 0; f < XT_NF; f++) Fhi[f] = lds[(size_t)f * T + st[t].X.slot_r];
+          for (int f = 0; f < XT_NF; f++) Fhi[f] = stage[(size_t)f * T + st[t].X.slot_r];
           xtile_state_finish<STAGE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, st[t].X, st[t].F,
                                     Fhi, st[t].cen, dt, dt_stage, h->tile_pressure != 0);
         }
     }
   auto tracer_phase = [&](auto phase_tag) {
     constexpr int PHASE = decltype(phase_tag)::value;
-    struct TL { XLane X; double L[2], R[2], cen[2], F[2]; };
+    struct TL { XLane X; double L[2], R[2], cen[2], F[2], own[2]; };
     std::vector<TL> tl(T);
-    for (int pair = 0; pair < npairs; pair++) {
-      const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
-      const bool two = 2 * pair + 1 < P.nt - 1;
+    auto run_pair = [&](auto nf_tag, const int *fa) {
+      constexpr int NF = decltype(nf_tag)::value;
+      int fields[NF];
+      for (int n = 0; n < NF; n++) fields[n] = P_U + fa[n];
       for (int by = 0; by < gy; by++)
         for (int bx = 0; bx < gx; bx++) {
           std::fill(lds.begin(), lds.end(), NAN);
+          std::fill(stage.begin(), stage.end(), NAN);
           for (int tz = 0; tz < G.lpb; tz++)
             for (int ty = 0; ty < rows; ty++)
               for (int tx = 0; tx < G.W; tx++) {
                 TL &l = tl[(tz * rows + ty) * G.W + tx];
                 l.X = xtile_lane(P, G, bx, by, tx, ty, tz);
-                if (!l.X.poly) continue;
-                if (two) xtile_tracer_polys<2>(P, in, l.X, fa, l.L, l.R, l.cen);
-                else xtile_tracer_polys<1>(P, in, l.X, fa, reinterpret_cast<double (&)[1]>(l.L), reinterpret_cast<double (&)[1]>(l.R), reinterpret_cast<double (&)[1]>(l.cen));
-                for (int f = 0; f < (two ? 2 : 1); f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+                xtile_stage<NF>(P, in, l.X, fields, stage.data(), TS, reinterpret_cast<double (&)[NF]>(l.own));
               }
           for (int t = 0; t < T; t++)
+            if (tl[t].X.poly) {
+              TL &l = tl[t];
+              xtile_tracer_polys<NF>(P, l.X, stage.data(), TS, reinterpret_cast<double (&)[NF]>(l.own), reinterpret_cast<double (&)[NF]>(l.L),
+                                     reinterpret_cast<double (&)[NF]>(l.R), reinterpret_cast<double (&)[NF]>(l.cen));
+              for (int f = 0; f < NF; f++) lds[(size_t)f * T + l.X.slot] = l.R[f];
+            }
+          for (int t = 0; t < T; t++)
             if (tl[t].X.face)
-              for (int f = 0; f < (two ? 2 : 1); f++) tl[t].R[f] = lds[(size_t)f * T + tl[t].X.slot_l];
+              for (int f = 0; f < NF; f++) tl[t].R[f] = lds[(size_t)f * T + tl[t].X.slot_l];
+          std::fill(stage.begin(), stage.end(), NAN);
           for (int t = 0; t < T; t++)
             if (tl[t].X.face) {
               TL &l = tl[t];
-              if (two) xtile_tracer_face<2>(P, h->fx.data(), l.X, l.L, l.R, l.F);
-              else xtile_tracer_face<1>(P, h->fx.data(), l.X, reinterpret_cast<double (&)[1]>(l.L), reinterpret_cast<double (&)[1]>(l.R), reinterpret_cast<double (&)[1]>(l.F));
-              for (int f = 0; f < (two ? 2 : 1); f++) lds[(size_t)f * T + l.X.slot] = l.F[f];
+              xtile_tracer_face<NF>(P, h->fx.data(), l.X, reinterpret_cast<double (&)[NF]>(l.L), reinterpret_cast<double (&)[NF]>(l.R),
+                                    reinterpret_cast<double (&)[NF]>(l.F));
+              for (int f = 0; f < NF; f++) stage[(size_t)f * T + l.X.slot] = l.F[f];
             }
           for (int t = 0; t < T; t++)
             if (tl[t].X.upd) {
               TL &l = tl[t];
-              double Fhi[2] = {0.0, 0.0};
-              for (int f = 0; f < (two ? 2 : 1); f++) Fhi[f] = lds[(size_t)f * T + l.X.slot_r];
-              if (two) xtile_tracer_finish<2, STAGE, PHASE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, l.X, fa, l.F, Fhi, l.cen, dt, dt_stage);
-              else xtile_tracer_finish<1, STAGE, PHASE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, l.X, fa, reinterpret_cast<double (&)[1]>(l.F), reinterpret_cast<double (&)[1]>(Fhi), reinterpret_cast<double (&)[1]>(l.cen), dt, dt_stage);
+              double Fhi[NF];
+              for (int f = 0; f < NF; f++) Fhi[f] = stage[(size_t)f * T + l.X.slot_r];
+              xtile_tracer_finish<NF, STAGE, PHASE>(P, in, p0, out, h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(), fr, l.X, fa,
+                                                    reinterpret_cast<double (&)[NF]>(l.F), Fhi, reinterpret_cast<double (&)[NF]>(l.cen), dt, dt_stage);
             }
         }
+    };
+    for (int pair = 0; pair < npairs; pair++) {
+      const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
+      if (2 * pair + 1 < P.nt - 1) run_pair(std::integral_constant<int, 2>{}, fa);
+      else run_pair(std::integral_constant<int, 1>{}, fa);
     }
   };
   if (npairs > 0) tracer_phase(std::integral_constant<int, 1>{});

@@ -13,14 +13,14 @@ CFGS=${@:-c3 c4}
 cd /tmp && export TMPDIR=/tmp
 for cfg in $CFGS; do
   rm -rf /tmp/ks_$cfg
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$cfg -o t -- python3 $R/bench.py --config $cfg --no-cpu-baseline --no-other-configs > $OUT/$cfg.log 2>&1 || { tail -20 $OUT/$cfg.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$cfg -o t -- python3 $R/bench.py --config $cfg --chunks 1 --no-cpu-baseline --no-other-configs > $OUT/$cfg.log 2>&1 || { tail -20 $OUT/$cfg.log; exit 1; }
   grep '^{"metric"' $OUT/$cfg.log > $OUT/${cfg}_bench_under_rocprof.json
   cp $(find /tmp/ks_$cfg -name '*kernel_stats.csv') $OUT/${cfg}_kernel_stats.csv
   rm -f $OUT/$cfg.log
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" GRBM_GUI_ACTIVE; do
     tag=$(echo $ctr | cut -d' ' -f1); [ "$tag" = SQ_INSTS_VALU ] && tag=SQ
     rm -rf /tmp/pmc_${cfg}_$tag
-    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${cfg}_$tag -o t -- python3 $R/bench.py --config $cfg --no-cpu-baseline --no-other-configs --no-kernel-timing --steps 1 --warmup 0 > $OUT/pmc_${cfg}_$tag.log 2>&1 || { tail -20 $OUT/pmc_${cfg}_$tag.log; exit 1; }
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${cfg}_$tag -o t -- python3 $R/bench.py --config $cfg --chunks 1 --no-cpu-baseline --no-other-configs --no-kernel-timing --steps 1 --warmup 0 > $OUT/pmc_${cfg}_$tag.log 2>&1 || { tail -20 $OUT/pmc_${cfg}_$tag.log; exit 1; }
     cp $(find /tmp/pmc_${cfg}_$tag -name '*counter_collection.csv') $OUT/${cfg}_pmc_${tag}.csv
     rm -f $OUT/pmc_${cfg}_$tag.log
   done
