@@ -2021,14 +2021,16 @@ PAMA_D XLane xtile_lane(const Params &P, const XTileGeom &G, int bx, int by, int
     X.stage_el[0] = (sbase + ty + shift) * G.W + tx;
     X.nstage = 1;
     if (G.halo) {
-      // the four cells beyond the halo rows (c0-3, c0-2 | c0+tcl+1, c0+tcl+2) are staged by the lanes of the first rows
-      for (int r = ty; r < 4; r += nrow) {
+      // the four cells beyond the halo rows (c0-3, c0-2 | c0+tcl+1, c0+tcl+2) are staged by the lanes of the first rows: row r of
+      // the four by the lanes with ty == r, and (a tile of three rows only) the fourth by the lanes of row 0 as well
+      auto extra = [&](int r, int n) {
         const int cc = (r < 2) ? c0 - 3 + r : c0 + tcl + 1 + (r - 2);
         const int srow = (r < 2) ? r : nrow + r;          // (rows 0, 1 | nrow + 2, nrow + 3 of the slab)
-        X.stage_po[X.nstage] = member_offset((int)(lev_p + at(cc)));
-        X.stage_el[X.nstage] = (sbase + srow) * G.W + tx;
-        X.nstage++;
-      }
+        X.stage_po[n] = member_offset((int)(lev_p + at(cc)));
+        X.stage_el[n] = (sbase + srow) * G.W + tx;
+      };
+      if (ty < 4) { extra(ty, 1); X.nstage = 2; }
+      if (ty + nrow < 4) { extra(ty + nrow, 2); X.nstage = 3; }
     }
   }
   return X;
@@ -2084,15 +2086,21 @@ constexpr int XT_NF = 6;    // face fluxes a lane hands to its left neighbour: r
 template <int NSF>
 PAMA_D void xtile_stage(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double *st, int TS,
                         double (&own)[NSF]) {
+  // every load is issued before the first LDS store (a loop of load -> store per cell would wait for each load in turn)
+  double v1[NSF], v2[NSF];
+  const bool has0 = X.nstage > 0, has1 = X.nstage > 1, has2 = X.nstage > 2;
 #pragma unroll
   for (int f = 0; f < NSF; f++) {
     gc_ptr fp = uni(prim_in + (long long)fields[f] * P.prim_fs);
-    own[f] = 0.0;
-    for (int i = 0; i < X.nstage; i++) {
-      const double v = fp[X.stage_po[i]];
-      st[f * TS + X.stage_el[i]] = v;
-      if (i == 0) own[f] = v;
-    }
+    own[f] = has0 ? fp[X.stage_po[0]] : 0.0;
+    v1[f] = has1 ? fp[X.stage_po[1]] : 0.0;
+    v2[f] = has2 ? fp[X.stage_po[2]] : 0.0;
+  }
+#pragma unroll
+  for (int f = 0; f < NSF; f++) {
+    if (has0) st[f * TS + X.stage_el[0]] = own[f];
+    if (has1) st[f * TS + X.stage_el[1]] = v1[f];
+    if (has2) st[f * TS + X.stage_el[2]] = v2[f];
   }
 }
 PAMA_D void xtile_state_fields(const Params &P, int (&fields)[XT_NS]) {
