@@ -1000,8 +1000,10 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   const bool small = P.nens < 64;
   h->flat_supported = P.prim_fs < (1ll << 28) && P.fz_fs < (1ll << 28);
   h->flat = h->flat_supported && (h->lane_mode == 2 || (h->lane_mode == 0 && small));
-  h->xtile = xtile_supported(P) && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
   h->xg = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
+  // (the groups of x lines are the y dimension of the tile kernels' launch grid: at most 65535)
+  const bool grid_ok = ((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb <= 65535;
+  h->xtile = xtile_supported(P) && grid_ok && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
   P.flat_cells = (h->lane_mode != 1 && (long long)P.nx * P.nens < 256 && P.ncell < (1ll << 31)) ? 1 : 0;
   // the y/z fluxes of a flat-lane stage: ONE tile kernel (a lane per cell) while the whole ensemble is below ~2.6e5 cells -- a flat-lane
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
