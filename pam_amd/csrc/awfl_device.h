@@ -174,10 +174,9 @@ PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
   // to an integer (a NaN / infinite kd would be undefined behaviour in the host build of this function)
   if (!(x > 0.0)) return (x == 0.0) ? (y > 0.0 ? 0.0 : INFINITY) : NAN;
   if (!(x < INFINITY)) return y > 0.0 ? INFINITY : 0.0;
-  // (a finite positive x with an exponent product beyond the double range: clamp kd so that the conversion is defined; ldexp
-  // then delivers the overflow / underflow)
-  const double kc = kd > 131072.0 ? 131072.0 : (kd < -131072.0 ? -131072.0 : kd);
-  const int k = (int)kc;
+  // (x finite and positive from here on: |log2 x| <= 1075, so kd = 64 y log2 x fits an int for every |y| < 3e4 -- the step's exponents
+  // are gamma, gamma - 1 and their reciprocals)
+  const int k = (int)kd;
   const int j = k & 63, n = k >> 6;                         // k = 64 n + j, 0 <= j < 64 (arithmetic shift)
   const double t2h = T->ex[j].th, t2l = T->ex[j].tl;
   return ldexp(fma(t2h, p, t2l) + t2h, n);
