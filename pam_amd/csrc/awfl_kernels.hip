@@ -999,7 +999,11 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   Params &P = h->P;
   const bool small = P.nens < 64;
   h->flat_supported = P.prim_fs < (1ll << 28) && P.fz_fs < (1ll << 28);
-  h->flat = h->flat_supported && (h->lane_mode == 2 || (h->lane_mode == 0 && small));
+  // flat y/z lanes also for RAGGED ensembles below 128 members (70 members in member lanes are two wavefronts per line, the second
+  // one with 6 lanes: measured 1.53 -> 1.71 G at 70, 1.99 -> 2.09 G at 96 on 32x32x60); from 128 on the two independent member
+  // ranges, which need member lanes, are worth more
+  const bool ragged = P.nens % 64 != 0 && P.nens < 128;
+  h->flat = h->flat_supported && (h->lane_mode == 2 || (h->lane_mode == 0 && (small || ragged)));
   h->xg = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
   // (the groups of x lines are the y dimension of the tile kernels' launch grid: at most 65535)
   const bool grid_ok = ((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb <= 65535;

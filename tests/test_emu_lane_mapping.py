@@ -118,8 +118,10 @@ def test_tile_geometry_rules():
     assert (g["W"], g["halo"]) == (2, 0) and used(g, 32)[0] == 1.0
     g = geom(32, 32)                      # 1024 lanes: one whole line
     assert (g["W"], g["halo"], g["tc"], g["lpb"]) == (32, 0, 32, 1)
-    g = geom(63, 32)                      # 2016 lanes: tiles of cells with halo rows; every tile fits 1024 lanes
-    assert g["halo"] == 1 and (g["tc"] + 2) * g["W"] <= 1024 and g["ntl"] * g["tc"] >= 32
+    g = geom(63, 32)                      # 2016 lanes: rows of half the members (32), whole lines of 1024 lanes
+    assert (g["W"], g["nmb"], g["halo"], g["tc"]) == (32, 2, 0, 32)
+    g = geom(8, 250)                      # 2000 lanes, but rows of 4 members would be 32-byte runs: all 8 members per row, tiles with halo rows
+    assert g["W"] == 8 and g["halo"] == 1 and (g["tc"] + 2) * 8 <= 1024 and g["ntl"] * g["tc"] >= 250
     g = geom(128, 32)                     # member blocks of 64
     assert (g["W"], g["nmb"], g["halo"]) == (64, 2, 1) and (g["tc"] + 2) * 64 <= 1024
     g = geom(128, 32, (32, 0, 0))         # rows of 32 members: a whole line of 32 cells fits

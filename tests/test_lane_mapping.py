@@ -108,11 +108,13 @@ def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(c
 
 
 def test_small_ensemble_defaults_are_flat_and_tile_and_large_ones_member_and_sweep():
-    for case, small in (("nens1_c2grid_slab", True), ("nens2_c1_like", True), ("nens40_vapour_limited_B", True),
-                        ("nens128_nt4_rows", False), ("nens70_ragged_vapour_limited", False)):
+    # (flat y/z lanes, x tile kernels): below 64 members both; ragged ensembles below 128 flat y/z lanes with x sweeps; else neither
+    for case, want in (("nens1_c2grid_slab", (True, True)), ("nens2_c1_like", (True, True)), ("nens40_vapour_limited_B", (True, True)),
+                       ("nens128_nt4_rows", (False, False)), ("nens70_ragged_vapour_limited", (True, False)),
+                       ("nens192_nt10_2d", (False, False))):
         f, xlen, ylen = _fields(case)
         _, _, m, _ = _run(case, f, xlen, ylen, "auto", "auto")
-        assert m["yz_flat"] == small and m["x_tiles"] == small, (case, m)
+        assert (m["yz_flat"], m["x_tiles"]) == want, (case, m)
 
 
 def test_nens2_flat_lanes_equal_the_same_members_tiled_to_64_member_lanes():
