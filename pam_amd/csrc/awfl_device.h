@@ -1117,7 +1117,13 @@ struct FctRows {
   int *lines;          // (nt, nz, ny, ceil(nens/64)); nullptr where the stage structure has no use for them
   int seq;
   int sparse_store;
+  const int *seq_base; // nullptr, or (a timeStep replayed from a captured HIP graph) a device word that `seq` is relative to: the
+                       // launch parameters of a graph are frozen at capture, the stage number advances with every replay
 };
+// first thing in every kernel that takes FctRows: the stage's flag value as this launch must see it
+PAMA_D void fct_rows_resolve(FctRows &r) {
+  if (r.seq_base) r.seq += *r.seq_base;
+}
 PAMA_D long long fct_rows_per_tracer(const Params &P) { return (long long)P.nz * P.ny * P.nx * ((P.nens + 63) >> 6); }
 // layout (tracer, level, y, member block, x)
 PAMA_D long long fct_row(const Params &P, int k, int j, int i, int e) {

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, con
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
                                                        FctRows rows, double dt, int t0) {
+  fct_rows_resolve(rows);
   CellId c;
   if (grid_cell(P, R, c)) fct_mult_body(P, fx, fy, fz, seed, mult, rows, dt, c, t0);
 }
@@ -161,6 +162,7 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
                                                           const double *__restrict__ fx, const double *__restrict__ fy,
                                                           const double *__restrict__ fz, const double *__restrict__ mult,
                                                           FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  fct_rows_resolve(rows);
   CellId c;
   if (grid_cell(P, R, c)) update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, c);
 }
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
                                                                      const double *__restrict__ fz, double *__restrict__ seed,
                                                                      double *__restrict__ mult, FctRows rows, double dt_dyn,
                                                                      double dt_stage, int tracers_inline, int span, int nspan) {
+  fct_rows_resolve(rows);
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int grp = uni_int(u / nspan), sp = u - grp * nspan;
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
                                                                const double *__restrict__ fz, double *__restrict__ seed,
                                                                double *__restrict__ mult, FctRows rows, double dt_dyn,
                                                                double dt_stage, int npairs, int span, int nspan) {
+  fct_rows_resolve(rows);
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int g2 = uni_int(u / npairs), pair = u - g2 * npairs;
@@ -243,6 +247,7 @@ __global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, c
                                                          const double *__restrict__ fx, const double *__restrict__ fy,
                                                          const double *__restrict__ fz, const double *__restrict__ mult,
                                                          FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  fct_rows_resolve(rows);
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int line = uni_int(u / nblk), el = (u - line * nblk) * 64 + (int)(threadIdx.x & 63);
@@ -258,6 +263,7 @@ __global__ void __launch_bounds__(256) awfl_trfix_flat_kernel(Params P, const do
                                                               const double *__restrict__ fx, const double *__restrict__ fy,
                                                               const double *__restrict__ fz, const double *__restrict__ mult,
                                                               FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  fct_rows_resolve(rows);
   CellId c;
   if (!flat_cell(P, P.nz, c)) return;
   if (rows.any[c.e >> 6] != rows.seq) return;     // no row of this member block was flagged in this stage
@@ -310,6 +316,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
                                                               const double *__restrict__ fz, double *__restrict__ seed,
                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
                                                               double dt_stage, int with_pressure, int tracers_inline) {
+  fct_rows_resolve(rows);
   extern __shared__ double xt_lds[];
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
@@ -361,6 +368,7 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
                                                              const double *__restrict__ fz, double *__restrict__ seed,
                                                              double *__restrict__ mult, FctRows rows, double dt_dyn,
                                                              double dt_stage) {
+  fct_rows_resolve(rows);
   extern __shared__ double xt_lds[];
   const int pair = (int)blockIdx.z;
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
@@ -607,6 +615,20 @@ struct pam_amd_awfl {
   int chunks_requested = 0;    // 0: automatic
   bool use_priorities = true;  // flux streams get the device's highest stream priority (see Chunk)
   bool interleave_xy = true;
+  // timeStep replayed from a captured HIP graph (launch-bound small ensembles; pam_amd_awfl_set_graph_replay)
+  struct GraphEntry {
+    std::vector<const void *> ptrs;   // the coupler arrays the step reads and writes
+    int ncycles; double dt_dyn; const double *prim0_before; long gen;
+    hipGraphExec_t exec; double *prim0_after, *prim1_after; int nstages;
+  };
+  std::vector<GraphEntry> graphs;
+  int graph_mode = 0;          // 0 automatic, 1 off, 2 on
+  long graph_gen = 0;          // bumped by every setter that changes what a step launches: older graphs are dropped
+  bool capturing = false;
+  int capture_seq0 = 0;
+  int *seq_dev = nullptr;      // device word: fct_seq at the start of the replayed step
+  hipStream_t gstream = nullptr;
+  hipEvent_t g_fork = nullptr, g_join = nullptr;
   int lane_mode = 0;           // 0 automatic, 1 member lanes, 2 flat (x, member) lanes (pam_amd_awfl_set_lane_mapping)
   bool flat = false;           // resolved lane mapping of the fused stage: flat lanes over (x, member) (small ensembles)
   bool flat_supported = false; // every lane offset fits the 28 bits of the scalar-base + lane-offset addressing
@@ -826,6 +848,11 @@ FctRows fct_rows(const pam_amd_awfl *h, EnsRange r, bool sparse_store) {
   rows.any = h->fct_flags + h->n_fct_flags;                  // one int per member block behind the rows
   rows.lines = h->fct_flags + h->n_fct_flags + h->n_fct_any;   // ... and the line flags behind those
   rows.seq = h->fct_seq;
+  rows.seq_base = nullptr;
+  if (h->capturing) {        // the launch goes into a graph: the stage number relative to the word the replay sets first
+    rows.seq = h->fct_seq - h->capture_seq0;
+    rows.seq_base = h->seq_dev;
+  }
   rows.sparse_store = (sparse_store && r.e0 % 64 == 0 && r.ne % 64 == 0) ? 1 : 0;
   return rows;
 }
@@ -990,6 +1017,13 @@ void destroy_chunks(pam_amd_awfl *h) {
   h->chunks.clear();
 }
 
+// every captured step is dropped when something changes what a step launches (a setter, a re-bound array)
+void drop_graphs(pam_amd_awfl *h) {
+  for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+  h->graphs.clear();
+  h->graph_gen++;
+}
+
 // Lane mapping of the fused stage (decided from the WHOLE ensemble; results never depend on it):
 //   flat   the y/z sweeps take 64 consecutive (x, member) items per wavefront (flat_lane) instead of 64 members of one line
 //   xtile  the x direction runs as tile kernels (a lane per cell) instead of sweeps (a wavefront per line span)
@@ -997,6 +1031,7 @@ void destroy_chunks(pam_amd_awfl *h) {
 // Automatic: all three for ensembles of fewer than 64 members (a member-lane wavefront would be mostly idle lanes).
 void resolve_lane_mapping(pam_amd_awfl *h) {
   Params &P = h->P;
+  drop_graphs(h);
   const bool small = P.nens < 64;
   h->flat_supported = P.prim_fs < (1ll << 28) && P.fz_fs < (1ll << 28);
   // flat y/z lanes also for RAGGED ensembles below 128 members (70 members in member lanes are two wavefronts per line, the second
@@ -1021,6 +1056,8 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
 // (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
 int build_chunks(pam_amd_awfl *h) {
   (void)hipStreamSynchronize(h->stream);
+  if (h->gstream) (void)hipStreamSynchronize(h->gstream);
+  drop_graphs(h);
   for (auto &c : h->chunks) {
     if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
     if (c.fstream && c.fstream != h->stream) (void)hipStreamSynchronize(c.fstream);
@@ -1081,6 +1118,13 @@ int build_chunks(pam_amd_awfl *h) {
 }
 
 void free_all(pam_amd_awfl *h) {
+  drop_graphs(h);
+  if (h->gstream) { (void)hipStreamSynchronize(h->gstream); (void)hipStreamDestroy(h->gstream); h->gstream = nullptr; }
+  if (h->g_fork) (void)hipEventDestroy(h->g_fork);
+  if (h->g_join) (void)hipEventDestroy(h->g_join);
+  h->g_fork = h->g_join = nullptr;
+  if (h->seq_dev) (void)hipFree(h->seq_dev);
+  h->seq_dev = nullptr;
   destroy_chunks(h);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   h->ev_fork = nullptr;
@@ -1230,6 +1274,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->act_vert_s2c = h->vert_s2c; h->act_vert_wrl = h->vert_wrl;
   h->n_vert_s2c = vt.s2c.size(); h->n_vert_wrl = vt.wrl.size();
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  INIT_TRY(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+  INIT_TRY(hipEventCreateWithFlags(&h->g_fork, hipEventDisableTiming));
+  INIT_TRY(hipEventCreateWithFlags(&h->g_join, hipEventDisableTiming));
+  INIT_TRY(hipMalloc(&h->seq_dev, sizeof(int)));
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1262,6 +1310,7 @@ int pam_amd_awfl_finalize(pam_amd_awfl_t *h) {
   if (!h) return PAM_AMD_OK;
   USE_DEVICE(h);
   (void)hipStreamSynchronize(h->stream);
+  if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   for (auto &c : h->chunks) {
     if (c.stream && c.stream != h->stream) (void)hipStreamSynchronize(c.stream);
     if (c.fstream && c.fstream != h->stream) (void)hipStreamSynchronize(c.fstream);
@@ -1296,6 +1345,7 @@ int pam_amd_awfl_get_option(const pam_amd_awfl_t *h, const char *key, double *va
 
 int pam_amd_awfl_set_balance_hydrostasis_with_gravity(pam_amd_awfl_t *h, int value) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  drop_graphs(h);
   h->P.grav_balance = value ? 1 : 0;
   h->hydro_declared = false;
   return PAM_AMD_OK;
@@ -1335,6 +1385,7 @@ int pam_amd_awfl_bind_array(pam_amd_awfl_t *h, const char *name, double *device_
     HIP_TRY(hipMemcpyAsync(device_ptr, *act, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     *act = device_ptr;
   }
+  drop_graphs(h);
   h->P.grav_var = h->act_grav_var; h->P.hy_dens = h->act_hy_dens; h->P.hy_pres = h->act_hy_pres;
   return PAM_AMD_OK;
 }
@@ -1527,6 +1578,62 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       if ((rc = launch_finalize(h, fields, c.r, c.stream))) return rc;
     return PAM_AMD_OK;
   };
+  // Launch-bound ensembles: the whole step (coupler -> dycore, 3 x ncycles stages, dycore -> coupler) is captured ONCE into a HIP
+  // graph on an internal stream and replayed; the only thing that changes from one step to the next -- the stage number the FCT
+  // flags are compared with -- is a device word set in front of every replay (FctRows::seq_base).
+  const bool graph_on = h->graph_mode == 2 || (h->graph_mode == 0 && h->P.ncell <= 1048576);
+  if (graph_on && h->fused && !forked && !h->timing && h->gstream) {
+    const int nstages = 3 * ncycles;
+    if (h->fct_seq > 0x7fffffff - nstages - 4) {      // the wrap of the stage number cannot happen inside a graph
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemset(h->fct_flags, 0, (h->n_fct_flags + h->n_fct_any + h->n_fct_lines) * sizeof(int)));
+      h->fct_seq = 0;
+    }
+    std::vector<const void *> ptrs = {fields->density_dry, fields->uvel, fields->vvel, fields->wvel, fields->temp};
+    for (int t = 0; t < h->P.nt; t++) ptrs.push_back(fields->tracers[t]);
+    pam_amd_awfl::GraphEntry *entry = nullptr;
+    for (auto &g : h->graphs)
+      if (g.gen == h->graph_gen && g.ncycles == ncycles && g.dt_dyn == dt_dyn && g.prim0_before == h->prim0 && g.ptrs == ptrs) entry = &g;
+    HIP_TRY(hipEventRecord(h->g_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->gstream, h->g_fork, 0));
+    int seq0 = h->fct_seq;
+    if (!entry) {
+      if (h->graphs.size() >= 8) {                      // (a few shapes of a step recur: both buffer parities x the cycle counts met)
+        for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+      }
+      pam_amd_awfl::GraphEntry e;
+      e.ptrs = ptrs; e.ncycles = ncycles; e.dt_dyn = dt_dyn; e.prim0_before = h->prim0; e.gen = h->graph_gen; e.nstages = nstages;
+      Chunk &c0 = h->chunks[0];
+      const hipStream_t s_keep = c0.stream, f_keep = c0.fstream;
+      c0.stream = c0.fstream = h->gstream;
+      h->capturing = true;
+      h->capture_seq0 = h->fct_seq;
+      hipError_t cerr = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
+      if (cerr == hipSuccess) rc = enqueue();
+      hipGraph_t graph = nullptr;
+      const hipError_t eerr = (cerr == hipSuccess) ? hipStreamEndCapture(h->gstream, &graph) : cerr;
+      h->capturing = false;
+      c0.stream = s_keep; c0.fstream = f_keep;
+      if (rc == PAM_AMD_OK && eerr != hipSuccess) rc = fail(PAM_AMD_ENOGPU, std::string("time_step: graph capture: ") + hipGetErrorString(eerr));
+      if (rc == PAM_AMD_OK && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) != hipSuccess)
+        rc = fail(PAM_AMD_ENOGPU, "time_step: hipGraphInstantiate failed");
+      if (graph) (void)hipGraphDestroy(graph);
+      if (rc) return rc;
+      e.prim0_after = h->prim0; e.prim1_after = h->prim1;       // (the capture has walked the buffer rotation on the host side)
+      h->graphs.push_back(e);
+      entry = &h->graphs.back();
+    } else {
+      h->fct_seq += nstages;
+      h->prim0 = entry->prim0_after;
+      h->prim1 = entry->prim1_after;
+    }
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)h->seq_dev, seq0, 1, h->gstream));
+    HIP_TRY(hipGraphLaunch(entry->exec, h->gstream));
+    HIP_TRY(hipEventRecord(h->g_join, h->gstream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->g_join, 0));
+    return PAM_AMD_OK;
+  }
   rc = enqueue();
   // join: the caller's stream continues after every chunk (and the shared compute stream, which every chunk stream follows
   // or is followed by through the events above) has finished -- also on the error path
@@ -1593,6 +1700,7 @@ int pam_amd_awfl_init_idealized(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *
 
 int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  drop_graphs(h);
   h->timing = enable != 0;
   return PAM_AMD_OK;
 }
@@ -1617,6 +1725,7 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h) {
 int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (faces < 1 || faces > FLUX_MAX_SPAN) return fail(PAM_AMD_EINVAL, "set_flux_segment: faces must be in [1,64]");
+  drop_graphs(h);
   h->P.seg = faces;
   return PAM_AMD_OK;
 }
@@ -1624,6 +1733,7 @@ int pam_amd_awfl_set_flux_segment(pam_amd_awfl_t *h, int faces) {
 int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (faces < 0) return fail(PAM_AMD_EINVAL, "set_flux_span: faces must be >= 0 (0 = automatic)");
+  drop_graphs(h);
   h->span_override = faces;
   return PAM_AMD_OK;
 }
@@ -1685,6 +1795,16 @@ int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode) {
   return PAM_AMD_OK;
 }
 
+int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_graph_replay: 0 = automatic, 1 = off, 2 = on");
+  USE_DEVICE(h);
+  if (h->gstream) (void)hipStreamSynchronize(h->gstream);
+  drop_graphs(h);
+  h->graph_mode = mode;
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (yz_flat) *yz_flat = h->flat ? (h->ftile ? 2 : 1) : 0;
@@ -1696,6 +1816,7 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
 
 int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  drop_graphs(h);
   h->independent_ranges = independent != 0;
   return PAM_AMD_OK;
 }

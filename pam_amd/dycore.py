@@ -265,6 +265,10 @@ class Dycore:
         """x tile kernels: the pressure pass "inside" the tile kernel | "separate" | "auto" """
         check(self._lib.pam_amd_awfl_set_tile_fusion(self._h, {"auto": 0, "separate": 1, "inside": 2}[mode]))
 
+    def set_graph_replay(self, mode="auto"):
+        """a whole timeStep replayed from a captured HIP graph: "on" | "off" | "auto" (launch-bound ensembles)"""
+        check(self._lib.pam_amd_awfl_set_graph_replay(self._h, {"auto": 0, "off": 1, "on": 2}[mode]))
+
     def get_lane_mapping(self):
         flat, tile, cells = C.c_int(), C.c_int(), C.c_int()
         g = (C.c_int * 6)()
