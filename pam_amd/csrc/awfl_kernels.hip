@@ -1581,7 +1581,11 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   // Launch-bound ensembles: the whole step (coupler -> dycore, 3 x ncycles stages, dycore -> coupler) is captured ONCE into a HIP
   // graph on an internal stream and replayed; the only thing that changes from one step to the next -- the stage number the FCT
   // flags are compared with -- is a device word set in front of every replay (FctRows::seq_base).
-  const bool graph_on = h->graph_mode == 2 || (h->graph_mode == 0 && h->P.ncell <= 1048576);
+  // OFF unless asked for: measured on MI355X / ROCm 7.2 (round 4, 20 steps each) a replayed step is SLOWER than the same launches
+  // issued eagerly -- 32x32x60 with one member 0.907 -> 1.011 ms, two 1.134 -> 1.249, eight 3.41 -> 3.58, the 250x1x50 shape 0.364 ->
+  // 0.425 ms: the gaps between DEPENDENT kernels (~2.3 us each) are the same inside a graph, and the fork / join events cost more
+  // than the host-side launch calls they replace (the host is not the bottleneck: launches are issued well ahead of the device).
+  const bool graph_on = h->graph_mode == 2;
   if (graph_on && h->fused && !forked && !h->timing && h->gstream) {
     const int nstages = 3 * ncycles;
     if (h->fct_seq > 0x7fffffff - nstages - 4) {      // the wrap of the stage number cannot happen inside a graph
