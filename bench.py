@@ -342,6 +342,9 @@ class Job:
             dycore.set_range_schedule(True)
         if args.graph != "auto":
             dycore.set_graph_replay(args.graph)
+        if args.tuning:
+            from pam_amd import capi
+            capi.check(capi.load().pam_amd_awfl_set_launch_tuning(*[int(v) for v in args.tuning.split(",")]))
         nens_gen = min(16, nens_pg)
         f = idz.supercell_fields(nens_gen, nx, ny, self.nz, self.zint, consts=self.consts, tracers=self.tracers,
                                  magnitude=0.1, id0=rank * 1000)
@@ -823,6 +826,7 @@ def main():
     ap.add_argument("--launcher", default="python", choices=("python", "cpp"),
                     help="python: one process per GPU, dt exchange through torch.distributed (RCCL); cpp: examples/driver --gpus N, one "
                          "host thread per GPU in ONE process, dt exchange over N host doubles")
+    ap.add_argument("--tuning", default="", help="want_units,two_phase_below,split_below (wavefront thresholds of the sweep launches)")
     ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"), help="timeStep replayed from a captured HIP graph")
     ap.add_argument("--indep", type=int, default=0, help="1: with --chunks > 1, every member range runs its stage on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -191,9 +191,15 @@ int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_ti
 int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode);
 /* Launch-bound ensembles: a whole time_step (coupler -> dycore, every stage, dycore -> coupler: ~10 launches per sub-step of a few
  * microseconds each) is captured once into a HIP graph on an internal stream and replayed -- one graph per (coupler arrays, number
- * of sub-cycles, buffer parity); the caller's stream is ordered before and after it with events.  mode 0 = automatic (fused stage,
- * one member range, below ~1e6 cells), 1 = off, 2 = on.  Same launches, same results. */
+ * of sub-cycles, buffer parity); the caller's stream is ordered before and after it with events.  mode 2 = on (fused stage, one
+ * member range), 0 / 1 = off: the DEFAULT, because on MI355X / ROCm 7.2 the replay is 5-15 % slower than the eager launches (the gaps
+ * between dependent kernels are the same).  Same launches, same results. */
 int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode);
+/* Process-wide launch-shape thresholds of the sweep kernels, in wavefronts (experiments; results do not depend on them): a sweep is
+ * cut into spans until it has `want_units` wavefronts (> 0; default 3072); the y/z sweeps run pass 1 and the field pairs in launches
+ * of their own below `two_phase_below` (line, span) units (>= 0; 8192); phase 1 of the further tracers' x sweeps is a launch of its
+ * own below `split_below` units (>= 0; 8192).  Negative / zero arguments leave a threshold as it is. */
+int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_below, long long split_below);
 /* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels, pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */

@@ -2655,6 +2655,30 @@ PAMA_D double pint_body(const Params &P, const double *__restrict__ prim, int kf
   return 0.5 * (Rl + Lr);
 }
 
+// The same mean of mode A from interface pressures computed beforehand -- ONE thread per (face, column) instead of one per (level,
+// member) walking ny*nx columns with four polynomials each (hydro_pint_face: `pint` is (nz+1, ny, nx, nens), the layout of a z flux
+// field); the sum runs over the same values in the same order: same bits as hydro_mean_body.
+template <bool VZ_PER_ENS>
+PAMA_D void hydro_pint_face(const Params &P, const double *__restrict__ prim, double *__restrict__ pint, int kf, int j, int i, int e) {
+  const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+  pint[(long long)kf * P.sz + c2] = pint_body<VZ_PER_ENS>(P, prim, kf, c2, e);
+}
+PAMA_D void hydro_mean_from_pint(const Params &P, const double *__restrict__ prim, const double *__restrict__ pint,
+                                 double *__restrict__ grav_var, int k, int e) {
+  const double r_nx_ny = 1. / (P.nx * P.ny);
+  const long long ke = (long long)k * P.nens + e;
+  const double dzk = P.dz[ke];
+  double g = 0.0;
+  for (int j = 0; j < P.ny; j++)
+    for (int i = 0; i < P.nx; i++) {
+      const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+      const double dens = prim[P_RHO * P.prim_fs + (long long)(k + HS) * P.sz + c2];
+      const double pu = pint[(long long)(k + 1) * P.sz + c2], pl = pint[(long long)k * P.sz + c2];
+      g += -(pu - pl) / (dens * dzk) * r_nx_ny;
+    }
+  grav_var[ke] = g;
+}
+
 // horizontal means for level k, member e, accumulated in the reference's serial order (j outer, i inner), which
 // makes the result deterministic (the reference uses atomicAdd, Dycore.h:1487,1499-1500).
 template <bool VZ_PER_ENS>

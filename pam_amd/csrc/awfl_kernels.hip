@@ -555,6 +555,23 @@ __global__ void __launch_bounds__(64) awfl_hydro_kernel(Params P, const double *
     hydro_mean_body<VZ_PER_ENS>(P, prim, grav_var, hy_dens, hy_pres, (int)(idx / P.nens), (int)(idx % P.nens));
 }
 
+// mode A of declare_current_profile_as_hydrostatic in two steps: the interface pressure of every (face, column) in parallel, then
+// the horizontal means in the reference's order (hydro_pint_face, hydro_mean_from_pint)
+template <bool VZ_PER_ENS>
+__global__ void __launch_bounds__(256) awfl_hydro_pint_kernel(Params P, const double *__restrict__ prim, double *__restrict__ pint) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned sz = (unsigned)P.sz, sy = (unsigned)P.sy, ne = (unsigned)P.nens;
+  const unsigned kf = t / sz, r = t - kf * sz;
+  if (kf > (unsigned)P.nz) return;
+  const unsigned j = r / sy, r2 = r - j * sy, i = r2 / ne;
+  hydro_pint_face<VZ_PER_ENS>(P, prim, pint, (int)kf, (int)j, (int)i, (int)(r2 - i * ne));
+}
+__global__ void __launch_bounds__(64) awfl_hydro_sum_kernel(Params P, const double *__restrict__ prim, const double *__restrict__ pint,
+                                                            double *grav_var) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long long)P.nz * P.nens) hydro_mean_from_pint(P, prim, pint, grav_var, (int)(idx / P.nens), (int)(idx % P.nens));
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) {
@@ -736,11 +753,15 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
 // wavefronts to fill the chip (256 CUs x 4 SIMDs x ~4 resident waves, with slack for the tail); otherwise the line is cut,
 // down to `min_span` faces (each span re-reads a 5-cell overlap and rebuilds one polynomial).  nlines x ceil(nens/64)
 // wavefronts sweep one span each.  `span_override` > 0 forces a value (tests / tuning).
+// launch-shape thresholds (wavefronts); settable for experiments through pam_amd_awfl_set_launch_tuning
+static long long g_want_units = 3072;      // a sweep is cut into spans until it has this many wavefronts (or spans reach the shortest)
+static long long g_two_phase_below = 8192; // y/z sweeps: pass 1 and the pairs in launches of their own below this many (line, span) units
+static long long g_split_below = 8192;     // x: phase 1 of the further tracers in a launch of its own below this many units
 static void choose_span(int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
   const long long nib = nlines * ((nens + 63) / 64);
   // (3072 since round 4, 6144 before: whole x lines and 2 z spans at C2's 128-member shard and at C3 instead of half lines --
   // fewer redundant start-up / closing polynomials; C2@128 +1 ... +3 %, C3 +1.4 %, C4 unchanged: it stops at the shortest span)
-  const long long want_units = 3072;
+  const long long want_units = g_want_units;
   if (span_override > 0) {
     span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
   } else {
@@ -796,7 +817,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
   const int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
-  const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < 8192;
+  const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < g_two_phase_below;
   const int nphase = two_phase ? 2 : 1;
   if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
     return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
@@ -928,7 +949,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   // a wavefront sweeps its cells once for the state and once per pair of further tracers, one after the other: when there
   // are fewer wavefronts than the chip has slots, the tracer sweeps go to their own launch, one wavefront per pair
   const int npairs = (P.nt - 1 + 1) / 2;
-  const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < 8192;
+  const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < g_split_below;
   if (nunits * (npairs > 0 ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
   if (r.e0 % 64) return fail(PAM_AMD_EINVAL, "x-sweep launch: member ranges of the fused stage start at multiples of 64 (a wavefront is one row of FCT flags)");
   {
@@ -1399,7 +1420,15 @@ int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const
   {
     ScopedTimer st(h, "hydro", h->stream);
     const long long n = (long long)h->P.nz * h->P.nens;
-    if (h->P.vz_per_ens)
+    if (h->P.grav_balance && h->P.fz_fs < (1ll << 32)) {
+      // mode A: the interface pressures in parallel into the (idle) z flux array, then the means in the reference's order
+      const long long nf = h->P.fz_fs;       // (nz + 1) faces x columns
+      if (h->P.vz_per_ens)
+        hipLaunchKernelGGL(awfl_hydro_pint_kernel<true>, dim3(nblocks(nf, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->flux_z);
+      else
+        hipLaunchKernelGGL(awfl_hydro_pint_kernel<false>, dim3(nblocks(nf, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->flux_z);
+      hipLaunchKernelGGL(awfl_hydro_sum_kernel, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->flux_z, h->act_grav_var);
+    } else if (h->P.vz_per_ens)
       hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0,
                          h->act_grav_var, h->act_hy_dens, h->act_hy_pres);
     else
@@ -1581,7 +1610,11 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   // Launch-bound ensembles: the whole step (coupler -> dycore, 3 x ncycles stages, dycore -> coupler) is captured ONCE into a HIP
   // graph on an internal stream and replayed; the only thing that changes from one step to the next -- the stage number the FCT
   // flags are compared with -- is a device word set in front of every replay (FctRows::seq_base).
-  const bool graph_on = h->graph_mode == 2 || (h->graph_mode == 0 && h->P.ncell <= 1048576);
+  // OFF unless asked for: measured on MI355X / ROCm 7.2 (round 4, 20 steps each) a replayed step is SLOWER than the same launches
+  // issued eagerly -- 32x32x60 with one member 0.907 -> 1.011 ms, two 1.134 -> 1.249, eight 3.41 -> 3.58, the 250x1x50 shape 0.364 ->
+  // 0.425 ms: the gaps between DEPENDENT kernels (~2.3 us each) are the same inside a graph, and the fork / join events cost more
+  // than the host-side launch calls they replace (the host is not the bottleneck: launches are issued well ahead of the device).
+  const bool graph_on = h->graph_mode == 2;
   if (graph_on && h->fused && !forked && !h->timing && h->gstream) {
     const int nstages = 3 * ncycles;
     if (h->fct_seq > 0x7fffffff - nstages - 4) {      // the wrap of the stage number cannot happen inside a graph
@@ -1802,6 +1835,13 @@ int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode) {
   if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   drop_graphs(h);
   h->graph_mode = mode;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_below, long long split_below) {
+  if (want_units > 0) g_want_units = want_units;
+  if (two_phase_below >= 0) g_two_phase_below = two_phase_below;
+  if (split_below >= 0) g_split_below = split_below;
   return PAM_AMD_OK;
 }
 

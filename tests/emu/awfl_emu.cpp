@@ -452,6 +452,22 @@ void emu_declare_hydrostatic(Emu *h, double *rho_d, double *u, double *v, double
       if (h->P.vz_per_ens) hydro_mean_body<true>(h->P, h->prim0.data(), h->grav_var.data(), h->hy_dens.data(), h->hy_pres.data(), k, e);
       else hydro_mean_body<false>(h->P, h->prim0.data(), h->grav_var.data(), h->hy_dens.data(), h->hy_pres.data(), k, e);
     }
+  if (h->P.grav_balance) {
+    // what the device does in mode A (awfl_hydro_pint_kernel + awfl_hydro_sum_kernel): the interface pressure of every face first,
+    // then the means -- must reproduce hydro_mean_body's variable_gravity bit for bit
+    const Params &P = h->P;
+    std::vector<double> pint((size_t)P.fz_fs), g2((size_t)P.nz * P.nens);
+    for (int kf = 0; kf <= P.nz; kf++)
+      for (int j = 0; j < P.ny; j++)
+        for (int i = 0; i < P.nx; i++)
+          for (int e = 0; e < P.nens; e++) {
+            if (P.vz_per_ens) hydro_pint_face<true>(P, h->prim0.data(), pint.data(), kf, j, i, e);
+            else hydro_pint_face<false>(P, h->prim0.data(), pint.data(), kf, j, i, e);
+          }
+    for (int k = 0; k < P.nz; k++)
+      for (int e = 0; e < P.nens; e++) hydro_mean_from_pint(P, h->prim0.data(), pint.data(), g2.data(), k, e);
+    if (std::memcmp(g2.data(), h->grav_var.data(), g2.size() * sizeof(double)) != 0) abort();
+  }
 }
 
 double emu_compute_time_step(Emu *h, double *rho_d, double *u, double *v, double *w, double *T, double *tracers, double cfl) {
