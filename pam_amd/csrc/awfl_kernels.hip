@@ -1032,7 +1032,7 @@ void destroy_chunks(pam_amd_awfl *h) {
     if (c.done) (void)hipEventDestroy(c.done);
     if (c.flux_done) (void)hipEventDestroy(c.flux_done);
     if (c.upd_done) (void)hipEventDestroy(c.upd_done);
-    if (c.fstream && c.fstream != h->stream) (void)hipStreamDestroy(c.fstream);
+    if (c.fstream && c.fstream != h->stream && c.fstream != c.stream) (void)hipStreamDestroy(c.fstream);
     if (c.stream && c.stream != h->stream) (void)hipStreamDestroy(c.stream);
   }
   h->chunks.clear();
@@ -1127,9 +1127,14 @@ int build_chunks(pam_amd_awfl *h) {
   } else {
     int prio_low = 0, prio_high = 0;   // numerically lower = higher priority
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    // (streams are a scarce resource: the runtime maps them onto a handful of hardware queues, and two "independent" ranges whose
+    // streams land on one queue run one after the other -- seen in round 4: one more internal stream per handle cost C4 0.80 -> 0.54 G.
+    // Independent ranges of the fused stage need ONE stream each; only the shared-compute-stream schedules use a second one.)
+    const bool one_stream_per_range = h->fused && h->independent_ranges;
     for (auto &c : h->chunks) {
       HIP_TRY(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_low));
-      HIP_TRY(hipStreamCreateWithPriority(&c.fstream, hipStreamNonBlocking, h->use_priorities ? prio_high : prio_low));
+      if (one_stream_per_range) c.fstream = c.stream;
+      else HIP_TRY(hipStreamCreateWithPriority(&c.fstream, hipStreamNonBlocking, h->use_priorities ? prio_high : prio_low));
       HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c.flux_done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c.upd_done, hipEventDisableTiming));
@@ -1295,10 +1300,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   h->act_vert_s2c = h->vert_s2c; h->act_vert_wrl = h->vert_wrl;
   h->n_vert_s2c = vt.s2c.size(); h->n_vert_wrl = vt.wrl.size();
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  INIT_TRY(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
-  INIT_TRY(hipEventCreateWithFlags(&h->g_fork, hipEventDisableTiming));
-  INIT_TRY(hipEventCreateWithFlags(&h->g_join, hipEventDisableTiming));
-  INIT_TRY(hipMalloc(&h->seq_dev, sizeof(int)));
+  // (the graph-replay stream, its events and the stage-number word are created when the replay is switched on)
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1835,6 +1837,12 @@ int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode) {
   if (h->gstream) (void)hipStreamSynchronize(h->gstream);
   drop_graphs(h);
   h->graph_mode = mode;
+  if (mode == 2 && !h->gstream) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->g_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->g_join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&h->seq_dev, sizeof(int)));
+  }
   return PAM_AMD_OK;
 }
 
@@ -1856,9 +1864,9 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
 
 int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  drop_graphs(h);
   h->independent_ranges = independent != 0;
-  return PAM_AMD_OK;
+  USE_DEVICE(h);
+  return build_chunks(h);
 }
 
 int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {
@@ -1866,7 +1874,7 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable) {
   if (enable && !h->fused_supported) return fail(PAM_AMD_EINVAL, "set_fused_stage: not available on this handle");
   const bool changed = h->fused != (enable != 0);
   h->fused = enable != 0;
-  if (changed && h->chunks_requested <= 0) {   // the automatic range count depends on the stage structure
+  if (changed) {   // the automatic range count and the streams a range needs depend on the stage structure
     USE_DEVICE(h);
     return build_chunks(h);
   }
