@@ -1904,8 +1904,11 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 // tile of `rows` rows of that run -- a row = (one cell) x (W consecutive members), W = nens when the whole ensemble fits a row
 // (small ensembles: rows follow each other without a gap, the lanes of a wavefront are 64 consecutive (x, member) pairs whatever
 // nens is), else a block of members -- and every lane
-//   A  builds the ONE polynomial set of its own cell (the same weno5_const on the same five values as the sweeps: same bits) and
-//      puts the right-edge values into LDS;
+//   0  stages the tile: it loads the stage-input values of ITS cell (in a tile with halo rows the lanes of the first rows also the
+//      two cells beyond the halo row on each side) into an LDS image of the tile: every value leaves global memory once;
+//   A  reads the 5-point stencils from that image (the lanes W and 2W slots to either side; inside a whole-line tile they wrap around
+//      the tile's rows), builds the ONE polynomial set of its own cell (the same weno5_const on the same five values as the sweeps:
+//      same bits) and puts the right-edge values into a second LDS region;
 //   B  takes the right-edge values of the cell to its left from LDS, forms the fluxes through its own left face (acoustic pair +
 //      upwinding, as flux_x_update_body) and puts them into LDS;
 //   C  takes the fluxes of its right face from the lane to its right and finishes its cell exactly as the sweep does (divergence,
@@ -1914,9 +1917,9 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 // workgroup) or `tc` cells of it with one halo row on each side (the left one only builds polynomials, the right one also the face
 // that closes the tile; both recompute what the neighbouring tile computes, with the same bits).
 // What this buys over the sweep: no serial chain along the line (a wavefront per 64 cells instead of per 64 lines), lanes that are
-// full whenever nx*nens reaches 64, and half the registers (4 waves per SIMD).  What it costs: the stage input is read through
-// five shifted loads per field instead of one (L1 / L2 hits), and the halo rows.  Launches that fill the chip with one wavefront
-// per line span keep the sweep (HBM-bound there, and it reads every input once).
+// full whenever nx*nens reaches 64, and half the registers (4 waves per SIMD).  What it costs: the LDS round trips, four workgroup
+// barriers and the halo rows.  Launches that fill the chip with one wavefront per line span keep the sweep (measured: DESIGN.md
+// section 6).
 // Reference: Dycore.h:334-386 (x fluxes), :553-571, :162-221, next stage's :310-321 (divide), :662-710 (ghosts), :525-550 + :572-584
 // (water vapour); x_tile_tracer_*: :367-385, :525-548, :572-584 for the further tracers.
 struct XTileGeom {
