@@ -367,12 +367,22 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
                                                              const double *__restrict__ fx, const double *__restrict__ fy,
                                                              const double *__restrict__ fz, double *__restrict__ seed,
                                                              double *__restrict__ mult, FctRows rows, double dt_dyn,
-                                                             double dt_stage) {
+                                                             double dt_stage, int fixup_slice) {
   fct_rows_resolve(rows);
   extern __shared__ double xt_lds[];
   const int pair = (int)blockIdx.z;
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
+  if (PHASE == 2 && fixup_slice && pair == (int)gridDim.z - 1) {
+    // the last z slice of a phase-2 launch of a small ensemble: water vapour's fix-up (tracer_fixup_cell_body), a lane per cell of
+    // the tile -- everything it reads was written by earlier launches; one launch less per stage than awfl_trfix_flat_kernel
+    if (X.upd && rows.any[X.e >> 6] == rows.seq) {
+      CellId c;
+      c.k = X.k; c.j = X.j; c.i = X.i; c.e = X.e; c.idx = (long long)X.io;
+      tracer_fixup_cell_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, c);
+    }
+    return;
+  }
   const int TS = xtile_stage_elems(G);
   const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
   if (2 * pair + 1 < P.nt - 1)
@@ -927,13 +937,16 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       if (!h->tile_pressure) {       // (small ensembles: phase 1 ran inline in the state kernel, like the pressure pass)
         ScopedTimer st(h, "xtr1", s);
         hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
-                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage, 0);
         HIP_TRY(hipGetLastError());
       }
       {
+        // (small ensembles: one more z slice does water vapour's fix-up -- launch_tail then has nothing left to launch)
         ScopedTimer st(h, "xtr2", s);
-        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
-                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage);
+        const dim3 tgrid2(grid.x, grid.y, (unsigned)(npairs + (h->tile_pressure ? 1 : 0)));
+        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid2, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                           h->tile_pressure ? 1 : 0);
         HIP_TRY(hipGetLastError());
       }
     }
@@ -990,7 +1003,7 @@ int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     hipLaunchKernelGGL(awfl_ptail_kernel, g, dim3(256), 0, s, h->P, r, prim_out);
     HIP_TRY(hipGetLastError());
   }
-  {
+  if (!(h->xtile && h->tile_pressure && h->P.nt > 1)) {    // (else: the last slice of the phase-2 tile launch has done it)
     ScopedTimer st(h, "trfix", s);
     if (h->P.flat_cells) {      // small ensembles: a lane per cell
       hipLaunchKernelGGL(awfl_trfix_flat_kernel<STAGE>, cell_grid(h->P, r), dim3(256), 0, s, h->P, prim_in, prim0, prim_out,

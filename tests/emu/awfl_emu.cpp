@@ -295,6 +295,13 @@ static void xupd_tile_launch(Emu *h, const double *in, const double *p0, double 
   if (npairs > 0) tracer_phase(std::integral_constant<int, 1>{});
   poison_unflagged_mult(h);
   if (npairs > 0) tracer_phase(std::integral_constant<int, 2>{});
+  if (npairs > 0 && h->tile_pressure) {      // the fix-up slice of the phase-2 tile launch (small ensembles)
+    bool any = false;
+    for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || fr.any[b] == fr.seq;
+    if (any)
+      for (long long idx = 0; idx < P.ncell; idx++)
+        tracer_fixup_cell_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->mult.data(), fr, h->seed.data(), dt, P.idWV, cell_of(P, idx));
+  }
 }
 
 // launch geometry of awfl_xupd_kernel: one wavefront per (x line, block of 64 members); lanes = members
@@ -338,6 +345,7 @@ static void tail_launch(Emu *h, const double *in, const double *p0, double *out,
   const Params &P = h->P;
   if (!(h->xtile && h->tile_pressure))
     for (long long idx = 0; idx < P.ncell; idx++) pressure_tail_body(P, out, cell_of(P, idx));
+  if (h->xtile && h->tile_pressure && P.nt > 1) return;      // (done by the last slice of the phase-2 tile launch)
   const FctRows rows = fct_rows(h);
   bool any = false;
   for (int b = 0; b < ((P.nens + 63) >> 6); b++) any = any || rows.any[b] == rows.seq;
