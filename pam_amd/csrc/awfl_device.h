@@ -1939,9 +1939,16 @@ PAMA_HD XTileGeom xtile_geometry(const Params &P, int w_req, int tc_req, int lpb
   // fewer than 64 members whose whole line does not fit a workgroup: rows of an even share of the members (at least 16: 128-byte
   // runs) so that a tile is still a whole periodic line -- no halo rows (measured, 48 members on 32x32x60: rows of all 48 members in
   // 16-cell tiles with halo rows 0.31 ms per stage, whole lines 0.24)
-  if (P.nens < 64 && (long long)P.nx * P.nens > 1024) {
-    const int nmb = (int)(((long long)P.nx * P.nens + 1023) / 1024), w = (P.nens + nmb - 1) / nmb;
+  // ... and a whole line of 512 lanes rather than 1024: at 97-105 VGPRs a CU holds 16 wavefronts of this kernel -- ONE workgroup of
+  // 1024 lanes, whose four barriers then stall the whole CU, or two of 512 that fill each other's waits (measured, 32x32x60: 32
+  // members 1.77 -> 1.91 G, 48 members 1.82 -> 2.01 G with rows of 16; 256-lane tiles lose again: 16 members 1.69 -> 1.64)
+  if (P.nens < 64 && (long long)P.nx * P.nens > 512) {
+    const int nmb = (int)(((long long)P.nx * P.nens + 511) / 512), w = (P.nens + nmb - 1) / nmb;
     if (w >= 16 && P.nx * w <= 1024) G.W = w;
+    else if ((long long)P.nx * P.nens > 1024) {
+      const int nmb2 = (int)(((long long)P.nx * P.nens + 1023) / 1024), w2 = (P.nens + nmb2 - 1) / nmb2;
+      if (w2 >= 16 && P.nx * w2 <= 1024) G.W = w2;
+    }
   }
   if (w_req > 0) G.W = w_req < P.nens ? w_req : P.nens;
   if (G.W > 1024 / 3) G.W = 64;

@@ -116,10 +116,12 @@ def test_tile_geometry_rules():
     assert g["halo"] == 0 and used(g, 65)[0] >= 0.9
     g = geom(2, 32)                       # C1: 64 lanes per line
     assert (g["W"], g["halo"]) == (2, 0) and used(g, 32)[0] == 1.0
-    g = geom(32, 32)                      # 1024 lanes: one whole line
-    assert (g["W"], g["halo"], g["tc"], g["lpb"]) == (32, 0, 32, 1)
-    g = geom(63, 32)                      # 2016 lanes: rows of half the members (32), whole lines of 1024 lanes
-    assert (g["W"], g["nmb"], g["halo"], g["tc"]) == (32, 2, 0, 32)
+    g = geom(32, 32)                      # 1024 lanes: rows of 16 members, whole lines of 512 lanes (two workgroups per CU)
+    assert (g["W"], g["nmb"], g["halo"], g["tc"], g["lpb"]) == (16, 2, 0, 32, 1)
+    g = geom(24, 32)                      # 768 lanes: rows of 12 members would be 96-byte runs -- all 24 members per row
+    assert (g["W"], g["halo"], g["tc"]) == (24, 0, 32)
+    g = geom(63, 32)                      # 2016 lanes: rows of a quarter of the members (16), whole lines of 512 lanes
+    assert (g["W"], g["nmb"], g["halo"], g["tc"]) == (16, 4, 0, 32)
     g = geom(8, 250)                      # 2000 lanes, but rows of 4 members would be 32-byte runs: all 8 members per row, tiles with halo rows
     assert g["W"] == 8 and g["halo"] == 1 and (g["tc"] + 2) * 8 <= 1024 and g["ntl"] * g["tc"] >= 250
     g = geom(128, 32)                     # member blocks of 64
