@@ -128,3 +128,45 @@ def test_tile_geometry_rules():
     assert (g["W"], g["nmb"], g["halo"]) == (64, 2, 1) and (g["tc"] + 2) * 64 <= 1024
     g = geom(128, 32, (32, 0, 0))         # rows of 32 members: a whole line of 32 cells fits
     assert (g["W"], g["nmb"], g["halo"], g["tc"]) == (32, 4, 0, 32)
+
+
+def _random_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    shapes = []
+    while len(shapes) < n:
+        nens = int(rng.choice([1, 2, 3, 5, 7, 17, 33, 40]))
+        ny = int(rng.choice([1, 1, 3, 4]))
+        nx = int(rng.choice([3, 4, 5, 9, 16, 33]))
+        nz = int(rng.choice([3, 5, 8]))
+        nt = int(rng.choice([1, 2, 4]))
+        if nens * nx * ny * nz * (6 + nt) > 60000:
+            continue
+        shapes.append((nens, nx, ny, nz, nt, bool(rng.randint(2)), bool(rng.randint(2))))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _random_shapes(8, 4), ids=lambda s: "nens%d_%dx%dx%d_nt%d_%s%s" % (s[0], s[1], s[2], s[3], s[4], "A" if s[5] else "B", "_limited" if s[6] else ""))
+def test_random_shapes_every_mapping_equals_member_lane_sweeps_bit_for_bit(shape):
+    """the index logic of the flat lanes and of every tile kernel (x, y/z, fused small-ensemble form) on shapes nobody picked; the same
+    test on the device build: tests/test_lane_mapping.py"""
+    nens, nx, ny, nz, nt, mode_a, limited = shape
+    tr = [("water_vapor", True, True)] + [("t%d" % i, i % 3 != 1, i % 2 == 0) for i in range(nt - 1)]
+    if nt >= 3:
+        tr = tr[1:3] + tr[:1] + tr[3:]
+    names, pos, mass, idwv = idz.tracer_flags(tr)
+    zint = idz.stretched_interfaces(nz, 9000.0)
+    xlen, ylen = nx * 500.0, (ny if ny > 1 else nx) * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if limited:
+        f["uvel"] -= 25.0
+        idz.carve_dry_air(f, tr)
+    dz = np.diff(zint)[:, None] * np.ones((1, nens))
+    args = (nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, idz.CONSTS_DEFAULT, mode_a)
+    n0, ref, _ = _run_emu(args, f, False, False)
+    for flat, xtile, ftile in ((True, True, None), (True, True, (0, 0)), (True, True, (2, 3))):
+        n1, got, g = _run_emu(args, f, flat, xtile, ftile=ftile)
+        assert n0 == n1
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+            assert np.isfinite(got[k]).all(), (ftile, k)
+            assert np.array_equal(ref[k], got[k]), (ftile, k, g.x_tile_geometry(), np.abs(ref[k] - got[k]).max())

@@ -188,3 +188,72 @@ def test_time_step_replayed_from_a_hip_graph_equals_eager_launches_bit_for_bit(c
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.isfinite(got[k]).all(), k
         assert np.array_equal(ref[k], got[k]), (k, np.abs(ref[k] - got[k]).max())
+
+
+def _random_shapes(n, seed):
+    rng = np.random.RandomState(seed)
+    shapes = []
+    while len(shapes) < n:
+        nens = int(rng.choice([1, 2, 3, 5, 7, 12, 17, 24, 31, 33, 40, 63, 65, 70, 100]))
+        ny = int(rng.choice([1, 1, 3, 4, 5, 7]))
+        nx = int(rng.choice([3, 4, 5, 9, 16, 33, 50, 67, 130])) if nens <= 12 else int(rng.choice([3, 5, 9, 16, 21, 33]))
+        nz = int(rng.choice([3, 5, 8, 13, 17]))
+        nt = int(rng.choice([1, 1, 2, 3, 4, 10]))
+        if nens * nx * ny * nz * (6 + nt) > 1.2e6:
+            continue
+        shapes.append((nens, nx, ny, nz, nt, bool(rng.randint(2)), bool(rng.randint(2))))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _random_shapes(18, 20261004), ids=lambda s: "nens%d_%dx%dx%d_nt%d_%s%s" % (s[0], s[1], s[2], s[3], s[4], "A" if s[5] else "B", "_limited" if s[6] else ""))
+def test_random_shapes_automatic_mapping_equals_member_lanes_and_sweeps_bit_for_bit(shape):
+    """index logic of every mapping on shapes nobody picked: partial last tiles, ragged member blocks, several short lines per
+    workgroup with a partial last group, lines longer than a workgroup, 2-D and 3-D, 1 ... 10 tracers, both hydrostasis modes, vapour
+    limited or not -- the automatic mapping of the shape (flat lanes / tile kernels / fused small-ensemble kernel where it applies)
+    and the forced flat + tile mapping against member lanes + sweeps"""
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz, nt, mode_a, limited = shape
+    tr = [("water_vapor", True, True)] + [("t%d" % i, i % 3 != 1, i % 2 == 0) for i in range(nt - 1)]
+    if nt >= 3:
+        tr = tr[1:3] + tr[:1] + tr[3:]          # water vapour not registered first (P3 registers it last)
+    zint = idz.stretched_interfaces(nz, 9000.0)
+    xlen, ylen = nx * 500.0, (ny if ny > 1 else nx) * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    if limited:
+        f["uvel"] -= 25.0
+        idz.carve_dry_air(f, tr)
+
+    def run(yz, xk):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 1.5)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        coupler.set_grid(xlen, ylen, zint)
+        for n, p, m in tr:
+            coupler.add_tracer(n, "", p, m)
+        d = Dycore()
+        d.init(coupler)
+        try:
+            d.set_lane_mapping(yz, xk)
+        except Exception:
+            d.finalize(coupler)
+            return None
+        coupler.load_fields(f)
+        if not mode_a:
+            coupler.set_option("balance_hydrostasis_with_gravity", False)
+        d.declare_current_profile_as_hydrostatic(coupler)
+        n = [d.timeStep(coupler) for _ in range(2)]
+        torch.cuda.synchronize()
+        out = coupler.dump_fields()
+        d.finalize(coupler)
+        return n, out
+    ref = run("member", "sweep")
+    for yz, xk in (("auto", "auto"), ("flat", "tile")):
+        got = run(yz, xk)
+        if got is None:
+            continue
+        assert got[0] == ref[0]
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+            assert np.isfinite(got[1][k]).all(), (yz, xk, k)
+            assert np.array_equal(ref[1][k], got[1][k]), (yz, xk, k, np.abs(ref[1][k] - got[1][k]).max())
