@@ -22,6 +22,8 @@ CASES = {
     "nens2_c1_like": (2, 32, 8, 12, idz.TRACERS_NONE, idz.uniform_interfaces(12, 12000.0), False, True, idz.CONSTS_DEFAULT, False, [(1, 0, 0)]),
     "nens8_nt4_B": (8, 12, 6, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, False, idz.CONSTS_DEFAULT, False, [(0, 4, 0), (4, 0, 0)]),
     "nens32_nt10_2d_p3_perens": (32, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), True, True, idz.CONSTS_P3, False, [(0, 7, 0)]),
+    # a line longer than a workgroup (1500 lanes): tiles of cells with halo rows, partial last tile
+    "nens1_long_line_halo_tiles": (1, 1500, 1, 6, idz.TRACERS_KESSLER_SHOC, idz.uniform_interfaces(6, 6000.0), False, True, idz.CONSTS_DEFAULT, False, [(0, 700, 0)]),
     "nens5_vapour_limited": (5, 16, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT, True, [(0, 3, 0)]),
     "nens40_vapour_limited_B": (40, 32, 3, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, False, idz.CONSTS_DEFAULT, True, [(0, 6, 0)]),
     # large ensembles with the small-ensemble mappings forced: 64-aligned (a wavefront of a 64-lane row IS a row of FCT flags: sparse
@@ -257,3 +259,37 @@ def test_random_shapes_automatic_mapping_equals_member_lanes_and_sweeps_bit_for_
         for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
             assert np.isfinite(got[1][k]).all(), (yz, xk, k)
             assert np.array_equal(ref[1][k], got[1][k]), (yz, xk, k, np.abs(ref[1][k] - got[1][k]).max())
+
+
+def test_more_lines_than_the_tile_launch_grid_falls_back_to_sweeps():
+    """the groups of x lines are the y dimension of the tile kernels' launch grid (<= 65535): beyond that the automatic mapping keeps
+    the x sweeps (flat y/z lanes stay), and the step still equals the member-lane one"""
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    nens, nx, ny, nz = 1, 4, 22000, 3
+    tr = idz.TRACERS_NONE
+    zint = idz.uniform_interfaces(nz, 3000.0)
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    res = []
+    for yz, xk in (("auto", "auto"), ("member", "sweep")):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 1.0)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        coupler.set_grid(nx * 500.0, ny * 500.0, zint)
+        coupler.add_tracer("water_vapor", "", True, True)
+        d = Dycore()
+        d.init(coupler)
+        d.set_lane_mapping(yz, xk)
+        m = d.get_lane_mapping()
+        if yz == "auto":
+            assert m["yz_flat"] and not m["x_tiles"], m
+            with pytest.raises(Exception):
+                d.set_lane_mapping("flat", "tile")          # asked for explicitly: refused, nothing changes
+        coupler.load_fields(f)
+        d.declare_current_profile_as_hydrostatic(coupler)
+        d.timeStep(coupler)
+        torch.cuda.synchronize()
+        res.append(coupler.dump_fields())
+        d.finalize(coupler)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
