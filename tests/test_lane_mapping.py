@@ -280,6 +280,9 @@ def test_more_lines_than_the_tile_launch_grid_falls_back_to_sweeps():
         d = Dycore()
         d.init(coupler)
         d.set_lane_mapping(yz, xk)
+        if yz == "auto":
+            assert d.get_lane_mapping()["x_tiles"]              # 48 lines of 4 lanes per workgroup: 1375 groups
+            d.set_x_tile(lines_per_group=1)                     # one line per workgroup: 66000 groups > 65535
         m = d.get_lane_mapping()
         if yz == "auto":
             assert m["yz_flat"] and not m["x_tiles"], m
