@@ -158,7 +158,8 @@ def launch_cpp(args):
     out = {"metric": "cell-updates/sec (AWFL dycore step)", "value": updates / d["seconds"], "unit": "cell-updates/s",
            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": d["seconds"] / args.steps * 1e3,
            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": desc % (nens_total // args.gpus), "nens_per_gpu": nens_total // args.gpus, "nens_total": nens_total,
+           "config": {"scaling": args.scaling, "nens_total": nens_total, "nens_per_gpu": nens_total // args.gpus,
+                      "workload": desc % (nens_total // args.gpus),
                       "nx": nx, "ny": ny, "nz": nz, "num_tracers": len(tracers), "crm_dt": crm_dt,
                       "substeps_per_step": d["substeps"] / float(args.steps), "parallelism": "nens-shard x%d" % args.gpus,
                       "launcher": "cpp: examples/driver --gpus %d (one host thread + one dycore handle per device; dt = min over %d host "
@@ -166,8 +167,7 @@ def launch_cpp(args):
                       "collective": None, "ranks_seen": d["ranks"], "devices_seen": d["devices"], "limiter_input": args.limiter},
            "roofline": None, "cpu_baseline": None,
            "note": "roofline / cpu_baseline are measured by the default (Python) launcher of the same library"}
-    print(json.dumps(out))
-    sys.stdout.flush()
+    emit(out, args)
 
 
 def _host_cores():
@@ -277,6 +277,8 @@ def cpu_baseline(cfg_name):
             "processes_x_1_core": {"value": agg, "processes": cores, "cores": cores, "seconds_max": max(m["seconds"] for m in many),
                                    "nens_per_process": n1},
             "openmp": {"value": omp["value"], "threads": cores, "seconds": omp["seconds"], "nens": nomp},
+            "sample_short": "oracle/awfl_oracle.c (C port of the reference algorithm; the reference needs YAKL, absent), %s grid, one timeStep = "
+                            "%d sub-steps; value = best %d-core figure" % (one["grid"], one["substeps"], cores),
             "sample": "oracle/awfl_oracle.c (%s; a port of the reference algorithm: the reference needs YAKL, an absent submodule) on %s, "
                       "%s grid, one timeStep = %d sub-steps: 1 core x %d members %.1f s; %d processes x 1 core x %d members %.1f s; "
                       "OpenMP %d threads x %d members %.1f s; `value` = the better of the two %d-core figures"
@@ -338,13 +340,12 @@ class Job:
         self.lds_floor = args.lds_floor
         if args.chunks >= 0:
             dycore.set_ensemble_chunks(args.chunks, args.lds_floor)
-        if args.indep:
-            dycore.set_range_schedule(True)
+        if args.indep >= 0:
+            dycore.set_range_schedule(bool(args.indep))
         if args.graph != "auto":
             dycore.set_graph_replay(args.graph)
         if args.tuning:
-            from pam_amd import capi
-            capi.check(capi.load().pam_amd_awfl_set_launch_tuning(*[int(v) for v in args.tuning.split(",")]))
+            dycore.set_launch_tuning(*[int(v) for v in args.tuning.split(",")])
         nens_gen = min(16, nens_pg)
         f = idz.supercell_fields(nens_gen, nx, ny, self.nz, self.zint, consts=self.consts, tracers=self.tracers,
                                  magnitude=0.1, id0=rank * 1000)
@@ -642,6 +643,99 @@ def modules_timing(torch, dev):
     return out
 
 
+LINE_LIMIT = 4096              # the driver parses the LAST stdout line; round 4's 32 KB object was not parsed
+
+
+def _sig(x, n=6):
+    """numbers of the compact line carry six significant digits (value and ms_per_step are kept exact)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (n, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The line the driver parses: the contract's fields, `roofline` and `cpu_baseline` as flat objects of numbers, the other
+    configurations as one number each.  Everything else (per-kernel tables, per-config rooflines, module timings, the prose that
+    defines each figure) is in bench_detail.json beside this file and on stderr."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    c = full["config"]
+    keep = ("scaling", "nens_total", "nens_per_gpu", "workload", "nx", "ny", "nz", "num_tracers", "crm_dt", "substeps_per_step",
+            "parallelism", "collective", "ranks_seen", "launcher", "devices_seen", "limiter_input", "fct_rows_flagged_last_stage",
+            "fct_rows", "rank_ms_per_step")
+    out["config"] = _sig({k: c[k] for k in keep if k in c})
+    m = c.get("lane_mapping")
+    if m:
+        out["config"]["lanes"] = ("flat" if m.get("yz_flat") else "member") + "+" + ("xtile" if m.get("x_tiles") else "xsweep")
+    r = full.get("roofline")
+    if r:
+        rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "ms_per_stage", "alg_bytes_per_launch",
+                                    "stage_ms_back_to_back", "stage_frac", "stage_traffic", "stage_traffic_ratio")}
+        v = r.get("valu")
+        if v:
+            rr["valu"] = {k: v[k] for k in ("frac", "issue_frac_at_sustained_clock", "sustained_clock_GHz_approx") if k in v}
+            rr["valu"]["source"] = "pmc" if "issue_frac_at_sustained_clock" in v else "model"
+        out["roofline"] = _sig(rr)
+    else:
+        out["roofline"] = None
+    b = full.get("cpu_baseline")
+    if b:
+        bb = {k: b.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model")}
+        for k in ("one_core", "processes_x_1_core", "openmp"):
+            if isinstance(b.get(k), dict):
+                bb[k] = {"value": b[k]["value"], "s": b[k].get("seconds", b[k].get("seconds_max")),
+                         "nens": b[k].get("nens", b[k].get("nens_per_process"))}
+        bb["sample"] = (b.get("sample_short") or b.get("sample") or "")[:200]
+        out["cpu_baseline"] = _sig(bb)
+    else:
+        out["cpu_baseline"] = None
+    o = full.get("other_configs")
+    if o:
+        oo = {}
+        for k, v in o.items():
+            if k == "modules":
+                oo["modules_ms"] = {kk: vv["ms"] for kk, vv in v.items() if isinstance(vv, dict) and "ms" in vv}
+            elif isinstance(v, dict):
+                oo[k] = v.get("value")
+                rf = v.get("roofline") or {}
+                if k in ("c3", "c4") and rf:
+                    oo[k + "_stage_frac"] = rf.get("stage_frac")
+                    oo[k + "_stage_traffic_ratio"] = rf.get("stage_traffic_ratio")
+        oo["unit"] = "cell-updates/s"
+        out["other"] = _sig(oo, 4)
+    out["detail"] = "bench_detail.json"
+    return out
+
+
+def emit(full, args):
+    """full object -> bench_detail.json + stderr; compact object (< LINE_LIMIT bytes, strict JSON) -> the last stdout line"""
+    detail = json.dumps(_sig(full, 17), allow_nan=False)      # strict JSON: a NaN / inf becomes null
+    try:
+        with open(os.path.join(ROOT, args.detail), "w") as fh:
+            fh.write(detail + "\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: cannot write %s: %r\n" % (args.detail, e))
+    sys.stderr.write("bench.py detail: " + detail + "\n")
+    sys.stderr.flush()
+    line = json.dumps(compact_line(full), allow_nan=False, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:            # never print a line the driver cannot parse: drop the optional blocks, largest first
+        c = compact_line(full)
+        for k in ("other", "detail"):
+            c.pop(k, None)
+            line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT, "bench line of %d bytes" % len(line)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+
+
 def worker(args):
     import torch
     import torch.distributed as dist
@@ -784,7 +878,7 @@ def worker(args):
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": desc, "nens_per_gpu": nens_pg, "nens_total": nens_total, "nx": nx, "ny": ny,
+               "config": {"scaling": args.scaling, "nens_total": nens_total, "nens_per_gpu": nens_pg, "workload": desc, "nx": nx, "ny": ny,
                           "nz": nz, "num_tracers": nt, "crm_dt": crm_dt, "substeps_per_step": substeps / args.steps,
                           "parallelism": "nens-shard x%d" % world,
                           "limiter_input": args.limiter, "fct_rows_flagged_last_stage": fct_rows[0], "fct_rows": fct_rows[1],
@@ -794,8 +888,7 @@ def worker(args):
                           "rank_ms_per_step": {"min": rank_ms[0], "max": rank_ms[1]}},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_rooflines": kernel_rooflines,
                "other_configs": others}
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out, args)
     if dd is not None:
         dist.destroy_process_group()
 
@@ -828,7 +921,10 @@ def main():
                          "host thread per GPU in ONE process, dt exchange over N host doubles")
     ap.add_argument("--tuning", default="", help="want_units,two_phase_below,split_below (wavefront thresholds of the sweep launches)")
     ap.add_argument("--graph", default="auto", choices=("auto", "on", "off"), help="timeStep replayed from a captured HIP graph")
-    ap.add_argument("--indep", type=int, default=0, help="1: with --chunks > 1, every member range runs its stage on its own stream")
+    ap.add_argument("--indep", type=int, default=-1, choices=(-1, 0, 1),
+                    help="member ranges of the fused stage: 1 every range runs its whole stage on its own stream, 0 the polynomial kernels of "
+                         "all ranges share one compute stream (round 2's schedule); -1 (default): the library's default (1)")
+    ap.add_argument("--detail", default="bench_detail.json", help="file (beside bench.py) that receives the full measurement object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -8,9 +8,10 @@
 //   driver [--gpus N] [--tile R] [--bench K W] <input.bin> <output.bin>
 //
 // --gpus N: the ensemble is sharded by member index over N devices of this node -- ONE host thread, ONE coupler and ONE dycore
-// handle per device (hipSetDevice before init), no inter-device halo and no collective library: the only exchange the reference
-// semantics need is the dynamics time step, a minimum over ALL members (awfl/Dycore.h:86-101,141-145), taken here over N host
-// doubles behind a barrier (HostMin) and handed to Dycore::timeStep(coupler, dt_dyn).  With fewer devices than ranks the ranks share
+// handle per device (hipSetDevice before init), no inter-device halo and no collective library: the exchanges the reference
+// semantics need are the two sub-cycling steps, each a minimum over ALL members -- the dynamics time step (awfl/Dycore.h:86-101,
+// 141-145) and, with the Kessler microphysics, its sedimentation step (kessler/Microphysics.h:385-390) -- taken here over N host
+// doubles behind a barrier (HostMin) and handed to Dycore::timeStep(coupler, dt_dyn) / Microphysics::timeStep(coupler, rainsplit).  With fewer devices than ranks the ranks share
 // devices (rehearsal on a 1-GPU box; bit-identical results, tests/test_cpp_driver.py).
 // --tile R: the input's members are repeated R times along nens (tile t gets +t mK on temp so that no two CRMs are equal).
 // --bench K W: W untimed + K timed steps between barriers; rank 0 prints one JSON line with the wall time (bench.py --launcher cpp).
@@ -24,6 +25,7 @@
 //   then idWV int64), then density_dry,uvel,vvel,wvel,temp,(tracers...) each nz*ny*nx*nens f64.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -179,7 +181,20 @@ static void run_rank(Job &J, int rank, int world, int ndev, HostMin &hmin, Bench
     bench.substeps += dycore.last_ncycles();
 #endif
     if (J.with_sponge) coupler.run_module("sponge_layer", modules::sponge_layer);       // driver.cpp:250
-    if (J.with_micro) coupler.run_module("micro", [&](pam::PamCoupler &c) { micro.timeStep(c); });   // driver.cpp:253
+    if (J.with_micro) {                                                                  // driver.cpp:253
+      if (world == 1) {
+        coupler.run_module("micro", [&](pam::PamCoupler &c) { micro.timeStep(c); });
+      } else {
+        // Kessler's sedimentation sub-cycle count is a reduction over ALL members as well (rainsplit = ceil(dt / minval(dt2d)),
+        // physics/micro/kessler/Microphysics.h:385-390): this shard's stable step, the minimum over the ranks, one count for all
+        coupler.run_module("micro", [&](pam::PamCoupler &c) {
+          const real dt_max_all = hmin(rank, micro.max_stable_dt(c));
+          const real crm_dt = c.get_option<real>("crm_dt");
+          const int rainsplit = std::max(1, (int)std::ceil(crm_dt / dt_max_all));
+          micro.timeStep(c, rainsplit);
+        });
+      }
+    }
   };
   if (J.bench_steps > 0) {
     for (int s = 0; s < J.bench_warmup; s++) one_step();

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PAM_AMD_AWFL_ABI_VERSION 3
+#define PAM_AMD_AWFL_ABI_VERSION 4
 
 #define PAM_AMD_OK 0
 #define PAM_AMD_EINVAL (-1)   /* bad argument / inconsistent dimensions (reference: endrun) */
@@ -195,11 +195,15 @@ int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode);
  * member range), 0 / 1 = off: the DEFAULT, because on MI355X / ROCm 7.2 the replay is 5-15 % slower than the eager launches (the gaps
  * between dependent kernels are the same).  Same launches, same results. */
 int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode);
-/* Process-wide launch-shape thresholds of the sweep kernels, in wavefronts (experiments; results do not depend on them): a sweep is
+/* Process-wide DEFAULTS of the launch-shape thresholds of the sweep kernels, in wavefronts (experiments; results do not depend on them): a sweep is
  * cut into spans until it has `want_units` wavefronts (> 0; default 3072); the y/z sweeps run pass 1 and the field pairs in launches
  * of their own below `two_phase_below` (line, span) units (>= 0; 8192); phase 1 of the further tracers' x sweeps is a launch of its
  * own below `split_below` units (>= 0; 8192).  Negative / zero arguments leave a threshold as it is. */
 int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_below, long long split_below);
+/* The same three thresholds for ONE handle (ABI 4).  Every handle owns its thresholds: the process-wide call above only sets the
+ * defaults a handle created AFTERWARDS starts from, so that in the one-process / N-handle host path (examples/driver.cpp --gpus N)
+ * tuning one handle never re-shapes the launches of another.  Drains the handle's streams and rebuilds its member ranges. */
+int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_units, long long two_phase_below, long long split_below);
 /* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels, pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */

@@ -69,6 +69,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_tile_fusion": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_launch_tuning": (C.c_int, [C.c_longlong, C.c_longlong, C.c_longlong]),
+    "pam_amd_awfl_set_handle_launch_tuning": (C.c_int, [C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong]),
     "pam_amd_awfl_get_lane_mapping": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pam_amd_awfl_debug_get_buffer": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pam_amd_awfl_debug_fct_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -672,6 +673,7 @@ struct pam_amd_awfl {
   bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
   bool fused_supported = false;
   size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
+  long long want_units = 3072, two_phase_below = 8192, split_below = 8192;   // launch-shape thresholds (pam_amd_awfl_set_handle_launch_tuning)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
@@ -764,14 +766,16 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
 // down to `min_span` faces (each span re-reads a 5-cell overlap and rebuilds one polynomial).  nlines x ceil(nens/64)
 // wavefronts sweep one span each.  `span_override` > 0 forces a value (tests / tuning).
 // launch-shape thresholds (wavefronts); settable for experiments through pam_amd_awfl_set_launch_tuning
-static long long g_want_units = 3072;      // a sweep is cut into spans until it has this many wavefronts (or spans reach the shortest)
-static long long g_two_phase_below = 8192; // y/z sweeps: pass 1 and the pairs in launches of their own below this many (line, span) units
-static long long g_split_below = 8192;     // x: phase 1 of the further tracers in a launch of its own below this many units
-static void choose_span(int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
+// The process-wide values below are only the DEFAULTS a new handle starts from (atomics: handles may be created on several host
+// threads); every handle carries its own copy (pam_amd_awfl::want_units ...), so tuning one handle never re-shapes another's launches.
+static std::atomic<long long> g_want_units{3072};      // a sweep is cut into spans until it has this many wavefronts (or spans reach the shortest)
+static std::atomic<long long> g_two_phase_below{8192}; // y/z sweeps: pass 1 and the pairs in launches of their own below this many (line, span) units
+static std::atomic<long long> g_split_below{8192};     // x: phase 1 of the further tracers in a launch of its own below this many units
+static void choose_span(const pam_amd_awfl *h, int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
   const long long nib = nlines * ((nens + 63) / 64);
   // (3072 since round 4, 6144 before: whole x lines and 2 z spans at C2's 128-member shard and at C3 instead of half lines --
   // fewer redundant start-up / closing polynomials; C2@128 +1 ... +3 %, C3 +1.4 %, C4 unchanged: it stops at the shortest span)
-  const long long want_units = g_want_units;
+  const long long want_units = h->want_units;
   if (span_override > 0) {
     span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
   } else {
@@ -814,9 +818,9 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   const long long gz = flat ? (flat_items(P, 2) + 63) / 64 : (long long)P.ny * P.nx;
   const int ens_for_span = flat ? 1 : P.nens;
   // the span is chosen from the WHOLE ensemble so that results/scheduling do not depend on the chunking
-  choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, G.spx, G.nsx);
-  choose_span(P.ny, gy, ens_for_span, P.seg, h->span_override, G.spy, G.nsy);
-  choose_span(P.nz + 1, gz, ens_for_span, P.seg, h->span_override, G.spz, G.nsz);
+  choose_span(h, P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, G.spx, G.nsx);
+  choose_span(h, P.ny, gy, ens_for_span, P.seg, h->span_override, G.spy, G.nsy);
+  choose_span(h, P.nz + 1, gz, ens_for_span, P.seg, h->span_override, G.spz, G.nsz);
   if (diff) { G.spy = P.ny; G.nsy = 1; }   // difference form: a periodic line is swept whole (its last cell needs face n == face 0)
   const long long nblk = flat ? 1 : (r.ne + 63) / 64;     // member lanes: a wavefront = 64 consecutive members of ONE line
   const long long nblk_all = flat ? 1 : (P.nens + 63) / 64;
@@ -827,7 +831,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
   const int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
-  const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < g_two_phase_below;
+  const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < h->two_phase_below;
   const int nphase = two_phase ? 2 : 1;
   if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
     return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
@@ -956,13 +960,13 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   // does not fill the chip the lines are cut into spans (each recomputes its closing face) as choose_span decides from the
   // WHOLE ensemble, so that results and schedule do not depend on the chunking
   int span, nspan;
-  choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, span, nspan);
+  choose_span(h, P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, span, nspan);
   const long long nlb = (long long)P.nz * P.ny * ((r.ne + 63) / 64);
   const long long nunits = nlb * nspan;
   // a wavefront sweeps its cells once for the state and once per pair of further tracers, one after the other: when there
   // are fewer wavefronts than the chip has slots, the tracer sweeps go to their own launch, one wavefront per pair
   const int npairs = (P.nt - 1 + 1) / 2;
-  const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < g_split_below;
+  const bool split = npairs > 0 && (long long)P.nz * P.ny * ((P.nens + 63) / 64) * nspan < h->split_below;
   if (nunits * (npairs > 0 ? npairs : 1) > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "x-sweep launch: more than 2^30 wavefronts");
   if (r.e0 % 64) return fail(PAM_AMD_EINVAL, "x-sweep launch: member ranges of the fused stage start at multiples of 64 (a wavefront is one row of FCT flags)");
   {
@@ -974,7 +978,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   }
   // the tracer launches have npairs wavefronts per (line, member block, span): their lines are cut less (or not at all)
   int tspan = span, tnspan = nspan;
-  if (npairs > 0) choose_span(P.nx, (long long)P.nz * P.ny * npairs, P.nens, P.seg, h->span_override, tspan, tnspan);
+  if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * npairs, P.nens, P.seg, h->span_override, tspan, tnspan);
   const long long tunits = nlb * tnspan * npairs;
   if (split) {     // phase 1 of the further tracers (their FCT multipliers) in a launch of its own
     ScopedTimer st(h, "xtr1", s);
@@ -1053,6 +1057,13 @@ void destroy_chunks(pam_amd_awfl *h) {
 
 // every captured step is dropped when something changes what a step launches (a setter, a re-bound array)
 void drop_graphs(pam_amd_awfl *h) {
+  // (a replay may still be queued on gstream: an exec is destroyed only once nothing can be running it -- ADVICE r4)
+  if (!h->graphs.empty() && h->gstream) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != h->device) (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->gstream);
+    if (cur >= 0 && cur != h->device) (void)hipSetDevice(cur);
+  }
   for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   h->graphs.clear();
   h->graph_gen++;
@@ -1107,9 +1118,9 @@ int build_chunks(pam_amd_awfl *h) {
     // launch still fills the chip (W = wavefronts of one whole-ensemble flux launch).
     const Params &P = h->P;
     int sp, nsx, nsy, nsz;
-    choose_span(P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, sp, nsx);
-    choose_span(P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, sp, nsy);
-    choose_span(P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, sp, nsz);
+    choose_span(h, P.nx, (long long)P.nz * P.ny, P.nens, P.seg, h->span_override, sp, nsx);
+    choose_span(h, P.ny, (long long)P.nz * P.nx, P.nens, P.seg, h->span_override, sp, nsy);
+    choose_span(h, P.nz + 1, (long long)P.ny * P.nx, P.nens, P.seg, h->span_override, sp, nsz);
     const long long nblk = (P.nens + 63) / 64;
     const long long ux = (long long)P.nz * P.ny * nblk * nsx, uy = (long long)P.nz * P.nx * nblk * nsy;
     const long long uz = (long long)P.ny * P.nx * nblk * nsz;
@@ -1336,6 +1347,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 0;   // no residency cap by default
+  h->want_units = g_want_units.load(); h->two_phase_below = g_two_phase_below.load(); h->split_below = g_split_below.load();
   resolve_lane_mapping(h);
   if (int rc = build_chunks(h)) { free_all(h); delete h; return rc; }
   *out = h;
@@ -1647,6 +1659,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     int seq0 = h->fct_seq;
     if (!entry) {
       if (h->graphs.size() >= 8) {                      // (a few shapes of a step recur: both buffer parities x the cycle counts met)
+        HIP_TRY(hipStreamSynchronize(h->gstream));      // an earlier replay may still be running one of them
         for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
         h->graphs.clear();
       }
@@ -1657,6 +1670,10 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       c0.stream = c0.fstream = h->gstream;
       h->capturing = true;
       h->capture_seq0 = h->fct_seq;
+      // what the capture advances on the host side (stage number, buffer rotation) is put back when no graph comes out of it: no
+      // kernel has run then, and the next step must start from the same buffers
+      const int seq_keep = h->fct_seq;
+      double *const p0_keep = h->prim0, *const p1_keep = h->prim1;
       hipError_t cerr = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
       if (cerr == hipSuccess) rc = enqueue();
       hipGraph_t graph = nullptr;
@@ -1667,7 +1684,14 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       if (rc == PAM_AMD_OK && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) != hipSuccess)
         rc = fail(PAM_AMD_ENOGPU, "time_step: hipGraphInstantiate failed");
       if (graph) (void)hipGraphDestroy(graph);
-      if (rc) return rc;
+      if (rc) {
+        h->fct_seq = seq_keep; h->prim0 = p0_keep; h->prim1 = p1_keep;
+        // the caller's stream was forked into gstream above: join it again, then run the step eagerly instead of failing it
+        (void)hipEventRecord(h->g_join, h->gstream);
+        (void)hipStreamWaitEvent(h->stream, h->g_join, 0);
+        h->graph_mode = 1;                              // (no further capture attempts on this handle)
+        return enqueue();
+      }
       e.prim0_after = h->prim0; e.prim1_after = h->prim1;       // (the capture has walked the buffer rotation on the host side)
       h->graphs.push_back(e);
       entry = &h->graphs.back();
@@ -1819,9 +1843,12 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
   const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group);
   if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
+  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) > 160 * 1024)
+    return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");
+  USE_DEVICE(h);
   h->xt_w = row_lanes; h->xt_tc = cells_per_tile; h->xt_lpb = lines_per_group;
-  resolve_lane_mapping(h);
-  return PAM_AMD_OK;
+  resolve_lane_mapping(h);       // (may switch the x kernels: the ranges are rebuilt like set_lane_mapping does)
+  return build_chunks(h);
 }
 
 int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile) {
@@ -1864,6 +1891,15 @@ int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_bel
   if (two_phase_below >= 0) g_two_phase_below = two_phase_below;
   if (split_below >= 0) g_split_below = split_below;
   return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_units, long long two_phase_below, long long split_below) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
+  if (want_units > 0) h->want_units = want_units;
+  if (two_phase_below >= 0) h->two_phase_below = two_phase_below;
+  if (split_below >= 0) h->split_below = split_below;
+  return build_chunks(h);      // (the automatic range count looks at the spans; drains the handle's streams and drops captured graphs)
 }
 
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]) {

@@ -242,6 +242,10 @@ class Dycore:
     def set_range_schedule(self, independent):
         check(self._lib.pam_amd_awfl_set_range_schedule(self._h, int(bool(independent))))
 
+    def set_launch_tuning(self, want_units=0, two_phase_below=-1, split_below=-1):
+        """launch-shape thresholds of THIS handle's sweep kernels, in wavefronts (0 / -1 = leave as it is); same results"""
+        check(self._lib.pam_amd_awfl_set_handle_launch_tuning(self._h, int(want_units), int(two_phase_below), int(split_below)))
+
     def set_fused_stage(self, enable):
         check(self._lib.pam_amd_awfl_set_fused_stage(self._h, int(bool(enable))))
 

@@ -2,7 +2,7 @@
 reference's generated matrices that the hot path uses (dynamics/awfl/TransformMatrices.h: sten_to_coefs<5,5> :970,
 coefs_to_gll_lower<5,2> :1132, weno_lower_sten_to_coefs<3,3,3> :1218, coefs_to_tv<3> :188, coefs_to_tv<5> :871,
 get_gll_points<9> :4113, get_gll_weights<9> :4126) against the constants this repository derives independently from
-exact rationals (oracle/gen_constants.py -> awfl_constants.h).  The reference file is only READ as text here; nothing of
+exact rationals (tools/gen_constants.py -> awfl_constants.h).  The reference file is only READ as text here; nothing of
 it is stored in the repository.  This pins the constants of the oracle and of the HIP kernels to the reference itself."""
 import os
 import re

@@ -8,7 +8,8 @@ oracle's own response to 1-ulp input noise over the same steps is ~2e-15 (rho, T
 ~2e-11 (v, which is ~1e-1 m/s noise in these cases) -- see DESIGN.md "Parity budget".  So:
    density_dry, temp, water_vapor:  max|a-b| <= 1e-12 * max|b|          (the north_star gate); density_dry and temp also
                                     ELEMENT-WISE: |a-b| <= 1e-12 |b| in every cell
-   uvel, wvel, vvel, other tracers: max|a-b| <= 1e-9  * max|b|          (small, noise-dominated fields)
+   uvel, wvel, vvel, other tracers: max|a-b| <= 1e-11 (1 + nsub/3) * max|b|   (small, noise-dominated fields: the measured error
+                                    curve, tests/parity_gate.py -- shared by every HIP-vs-oracle comparison of the repository)
 """
 import copy
 import json
@@ -21,22 +22,8 @@ from pam_amd import idealized as idz
 
 pytestmark = pytest.mark.gpu
 
-TOL_TIGHT = 1e-12
+from parity_gate import TOL_TIGHT, tol_noise_fields, compare as _compare_gate   # noqa: E402  (tests/parity_gate.py: the gate, documented there)
 
-
-def tol_noise_fields(nsub, factor=1.0):
-    """Gate of the small, noise-dominated fields (u, v, w, tracers other than water vapour) after `nsub` SSPRK3 sub-steps, relative to
-    max|field|.  It follows the MEASURED curve, not a flat bound: profiles/r03_error_growth_c1.txt (BASELINE config C1, HIP vs oracle
-    beside the oracle's own response to ONE ulp of T) has u, v, w at 4.5e-13 ... 6.8e-12 over 3 ... 30 sub-steps, i.e. within
-    1e-12 (1 + nsub/3) throughout.  The gate is 1e-11 (1 + nsub/3): the worst of the 18 oracle cases recorded on MI355X
-    (profiles/r04_parity_worst.json, written under PAM_AMD_PARITY_RECORD) sits at 0.30 of it (v of the per-member-grid case; C1: 0.04),
-    so a 4x regression of the worst case -- 25x of C1 -- fails, where round 3's flat 1e-9 let 100x through; and a relative perturbation of
-    1e-10 injected into one field turns the case red (below).  `factor`: the one exception, the degenerate 3 x 3 x 3 grid (the
-    periodic stencil wraps every line twice; w is 1e-3 m/s of noise there), recorded at 1.43 and gated at 4."""
-    return factor * 1.0e-11 * (1.0 + nsub / 3.0)
-
-
-_RECORD = {}
 
 def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True, per_ens=False, mag=0.5, crm_dt=2.0,
            dxy=500.0, dry_air=False):
@@ -74,33 +61,8 @@ def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True
     return coupler, dycore, oracle, copy.deepcopy(f), names
 
 
-def _worst(got, exp, names):
-    worst = {}
-    for k in ("density_dry", "temp", "uvel", "vvel", "wvel"):
-        scale = max(np.abs(exp[k]).max(), 1e-300)
-        worst[k] = np.abs(got[k] - exp[k]).max() / scale
-    for t, n in enumerate(names):
-        scale = max(np.abs(exp["tracers"][t]).max(), 1e-300)
-        worst[n] = np.abs(got["tracers"][t] - exp["tracers"][t]).max() / scale
-    for k in ("density_dry", "temp"):   # bounded away from zero: also ELEMENT-WISE
-        worst[k + "_elementwise"] = np.abs((got[k] - exp[k]) / exp[k]).max()
-    return worst
-
-
 def _compare(got, exp, names, nsub, case=None, factor=1.0):
-    """north_star gate: rho_d, T (max-norm and element-wise) and water vapour within 1e-12; the noise-dominated fields within
-    tol_noise_fields(nsub)."""
-    worst = _worst(got, exp, names)
-    if case is not None:
-        _RECORD[case] = dict(worst, nsub=nsub)
-        path = os.environ.get("PAM_AMD_PARITY_RECORD")
-        if path:
-            json.dump(_RECORD, open(path, "w"), indent=1, sort_keys=True)
-    loose = tol_noise_fields(nsub, factor)
-    for k, e in worst.items():
-        tol = TOL_TIGHT if k.split("_elementwise")[0] in ("density_dry", "temp", "water_vapor") else loose
-        assert e <= tol, (k, e, tol, worst)
-    return worst
+    return _compare_gate(got, exp, names, nsub, case, factor)
 
 
 CASES = {
@@ -537,9 +499,11 @@ def test_long_run_parity_120_substeps():
     torch.cuda.synchronize()
     assert sub >= 100
     got = coupler.dump_fields()
-    for k, tol in (("density_dry", 1e-12), ("temp", 1e-12), ("uvel", 1e-12), ("wvel", 1e-10), ("vvel", 1e-9)):
+    # the measured-curve gate (tol_noise_fields(120) = 4.1e-10 for v, w and the non-vapour tracers; rho_d, T, vapour 1e-12), recorded
+    # into profiles/r05_parity_worst.json like the other oracle cases; u and w additionally keep round 3's tighter flat bounds
+    _compare(got, fo, names, sub, "long_run_120_substeps")
+    for k, tol in (("uvel", 1e-12), ("wvel", 1e-10)):
         assert np.abs(got[k] - fo[k]).max() <= tol * np.abs(fo[k]).max(), k
-    assert np.abs(got["tracers"][0] - fo["tracers"][0]).max() <= 1e-12 * np.abs(fo["tracers"][0]).max()
     dycore.finalize(coupler)
 
 

@@ -84,3 +84,76 @@ def test_sharded_time_step_helper_without_process_group_is_the_local_step():
         assert np.array_equal(x[k], y[k]), k
     a_d.finalize(a_c)
     b_d.finalize(b_c)
+
+
+def _mk_large(nens, nt_set, seed_id=0):
+    """an ensemble large enough for member lanes and two independent member ranges (>= 128 members)"""
+    nx, ny, nz = 16, 1, 12
+    tr = nt_set
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    f = idz.supercell_fields(16, nx, ny, nz, zint, tracers=tr, magnitude=0.5, id0=seed_id)
+    if len(tr) > 1:
+        idz.add_tracer_blobs(f, tr, nx * 500.0, nx * 500.0, zint)
+    f = {k: np.ascontiguousarray(np.tile(v, (1,) * (v.ndim - 1) + (nens // 16,))) for k, v in f.items()}
+    f["temp"] = f["temp"] + 1e-3 * (np.arange(nens) // 16)
+    return _mk(f, 0, nens, nx, ny, nz, zint, tr)
+
+
+def test_two_handles_in_one_process_tuned_differently_do_not_reshape_each_other():
+    """the launch-shape thresholds are per handle.  Two handles of one process (what examples/driver --gpus N holds:
+    one per device) get DIFFERENT thresholds -- and the process-wide default is changed after both exist -- and both must still
+    produce the bits of an untuned handle (results never depend on launch shapes; before round 5 the thresholds were three
+    process-global statics, so tuning one handle silently re-shaped the launches of every other, unsynchronised)."""
+    import torch
+    from pam_amd import capi
+    tr = idz.TRACERS_KESSLER_SHOC
+    ref_c, ref_d = _mk_large(128, tr)
+    a_c, a_d = _mk_large(128, tr)
+    b_c, b_d = _mk_large(128, tr)
+    a_d.set_launch_tuning(64, 0, 0)                  # whole lines, one-phase y/z sweeps, tracer phase 1 inline
+    b_d.set_launch_tuning(1 << 20, 1 << 30, 1 << 30)   # shortest spans, two-phase sweeps, phase 1 in its own launch
+    lib = capi.load()
+    capi.check(lib.pam_amd_awfl_set_launch_tuning(777, 5, 5))     # the defaults of handles created from now on: a, b, ref keep theirs
+    try:
+        for _ in range(2):
+            n = [d.timeStep(c) for c, d in ((ref_c, ref_d), (a_c, a_d), (b_c, b_d))]
+            assert n[0] == n[1] == n[2]
+        torch.cuda.synchronize()
+        r, a, b = ref_c.dump_fields(), a_c.dump_fields(), b_c.dump_fields()
+        for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+            assert np.array_equal(a[k], r[k]) and np.array_equal(b[k], r[k]), k
+        # the two tunings really are different launch shapes: kernel launch counts per step differ
+        for d in (a_d, b_d):
+            d.set_kernel_timing(True)
+            d.reset_kernel_timing()
+        a_d.timeStep(a_c)
+        b_d.timeStep(b_c)
+        torch.cuda.synchronize()
+        assert a_d.get_kernel_timing("xtr1")[1] == 0 and b_d.get_kernel_timing("xtr1")[1] > 0
+    finally:
+        capi.check(lib.pam_amd_awfl_set_launch_tuning(3072, 8192, 8192))
+    for c, d in ((ref_c, ref_d), (a_c, a_d), (b_c, b_d)):
+        d.finalize(c)
+
+
+def test_a_handle_created_beside_eight_idle_streams_gives_the_two_range_result_bit_for_bit():
+    """streams map onto a handful of hardware queues, and a host model with streams of its own may push the
+    handle's two member ranges onto one queue (slower, never different): a handle created while 8 unrelated idle streams exist, and
+    one restricted to a single range (the robust setting of INTEGRATION.md section 4), equal the plain two-range run bit for bit."""
+    import torch
+    tr = idz.TRACERS_NONE
+    ref_c, ref_d = _mk_large(256, tr)
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    busy_c, busy_d = _mk_large(256, tr)
+    one_c, one_d = _mk_large(256, tr)
+    one_d.set_ensemble_chunks(1, 0)
+    for _ in range(2):
+        n = [d.timeStep(c) for c, d in ((ref_c, ref_d), (busy_c, busy_d), (one_c, one_d))]
+        assert n[0] == n[1] == n[2]
+    torch.cuda.synchronize()
+    r, b, o = ref_c.dump_fields(), busy_c.dump_fields(), one_c.dump_fields()
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.array_equal(b[k], r[k]) and np.array_equal(o[k], r[k]), k
+    del streams
+    for c, d in ((ref_c, ref_d), (busy_c, busy_d), (one_c, one_d)):
+        d.finalize(c)

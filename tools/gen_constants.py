@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Derive the order-5 WENO transform constants from first principles (exact rationals).
 
-TEST INFRASTRUCTURE / build helper.  Emits `awfl_constants.h`, shared by the CPU oracle
-(`oracle/awfl_oracle.c`) and by the HIP product (`pam_amd/csrc/`): the numbers are mathematical
-constants, not code.  They restate the VALUES of the generated literals in the reference's
+Build helper (tools/: it is neither the oracle nor built from the reference).  Emits `awfl_constants.h`,
+once for the HIP product (`pam_amd/csrc/`) and once for the CPU oracle (`oracle/awfl_oracle.c`): the
+numbers are mathematical constants, not code.  They restate the VALUES of the generated literals in the reference's
 `dynamics/awfl/TransformMatrices.h`:
 
   sten_to_coefs<5,5>            TransformMatrices.h:970-997
@@ -19,8 +19,9 @@ Derivation (unit cells centred on the stencil's middle cell):
   * total variation  TV(a) = sum_{l>=1} integral_{-1/2}^{1/2} (d^l p/dx^l)^2 dx.
   * 9-point Gauss-Lobatto-Legendre nodes/weights on [-1/2, 1/2] (Newton on P8', 60 digits).
 
-`python oracle/gen_constants.py` rewrites `oracle/awfl_constants.h` and the copy under
-`pam_amd/csrc/`; `tests/test_constants.py` re-derives and checks them.
+`python tools/gen_constants.py` rewrites `pam_amd/csrc/awfl_constants.h` and the copy under `oracle/`
+(the oracle's Makefile calls it from here); `tests/test_oracle_kat.py` re-derives and checks them,
+`tests/test_constants_vs_reference.py` compares them with the reference's literals.
 """
 from fractions import Fraction as F
 from decimal import Decimal, getcontext
@@ -142,7 +143,7 @@ def build():
 
 def emit(c):
     o = []
-    o.append("/* GENERATED by oracle/gen_constants.py -- do not edit.  Mathematical constants of the order-5")
+    o.append("/* GENERATED by tools/gen_constants.py -- do not edit.  Mathematical constants of the order-5")
     o.append(" * WENO transform (values restate dynamics/awfl/TransformMatrices.h:188,871,970,1132,1218,4113,4126). */")
     o.append("#ifndef AWFL_CONSTANTS_H\n#define AWFL_CONSTANTS_H\n")
     o.append("/* stencil -> polynomial coefficients, [s][ii] (TransformMatrices.h:970) */")
@@ -185,8 +186,8 @@ def emit(c):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     text = emit(build())
-    targets = [os.path.join(here, "awfl_constants.h"),
-               os.path.join(here, "..", "pam_amd", "csrc", "awfl_constants.h")]
+    targets = [os.path.join(here, "..", "pam_amd", "csrc", "awfl_constants.h"),
+               os.path.join(here, "..", "oracle", "awfl_constants.h")]
     for t in targets:
         os.makedirs(os.path.dirname(t), exist_ok=True)
         with open(t, "w") as f:
