@@ -335,6 +335,8 @@ class Job:
             dycore.set_lane_mapping(args.lanes, args.xkernels)
         if args.xtile:
             dycore.set_x_tile(*[int(v) for v in args.xtile.split(",")])
+        if args.xexchange != "auto":
+            dycore.set_x_exchange(args.xexchange)
         self.lane_mapping = dycore.get_lane_mapping()
         self.chunks = args.chunks
         self.lds_floor = args.lds_floor
@@ -484,7 +486,7 @@ def stage_rooflines(job, alone):
     return out
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def load_profile(cfg_name):
@@ -499,7 +501,7 @@ def load_profile(cfg_name):
     return prof, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE, separate passes, this build (%s)" % prof["csrc_hash"]
 
 
-def measure_roofline(job, args, default_workload=True):
+def measure_roofline(job, args, profile_key=None):
     """HIP-event pass over the stage kernels of `job` + the roofline object of its dominant kernel (see the module docstring)."""
     d = job.dycore
     cells = job.nens * job.nz * job.ny * job.nx
@@ -523,17 +525,22 @@ def measure_roofline(job, args, default_workload=True):
     if dom.startswith("xtr"):
         kname = "awfl_xtr_kernel<%s>" % dom[3:]
     mine = [k for k in kernel_rooflines if k["kernel"] == kname]
-    prof, tnote = (load_profile(job.cfg_name) if default_workload else (None, "not the profiled workload"))
+    prof, tnote = (load_profile(profile_key) if profile_key else (None, "not a profiled workload"))
     traffic, stage_traffic, valu = None, None, None
     if prof is not None:
         pk = prof["kernels"]
 
-        def pkey(name):      # "awfl_xtr_kernel<2>" is one template family in the profile
-            return name if name in pk else name.split("<")[0]
+        def pkey(name):      # "awfl_xtr_kernel<2>" is one template family in the profile; small ensembles run the _tile_ forms
+            for cand in (name, name.replace("_kernel", "_tile_kernel"), name.split("<")[0], name.split("<")[0].replace("_kernel", "_tile_kernel")):
+                if cand in pk:
+                    return cand
+            if name.startswith("awfl_trfix") and "awfl_trfix_flat_kernel" in pk:
+                return "awfl_trfix_flat_kernel"
+            return name
         if pkey(kname) in pk:
             traffic = pk[pkey(kname)]["hbm_bytes_per_stage"]
         for kr in kernel_rooflines:
-            k = kr["kernel"]
+            k = pkey(kr["kernel"])
             if k in pk:
                 kr["traffic"] = pk[k]["hbm_bytes_per_stage"]
         names = set(pkey(kr["kernel"]) for kr in kernel_rooflines)
@@ -672,7 +679,7 @@ def compact_line(full):
     out["config"] = _sig({k: c[k] for k in keep if k in c})
     m = c.get("lane_mapping")
     if m:
-        out["config"]["lanes"] = ("flat" if m.get("yz_flat") else "member") + "+" + ("xtile" if m.get("x_tiles") else "xsweep")
+        out["config"]["lanes"] = ("flat" if m.get("yz_flat") else "member") + "+" + (("xtile-shfl" if m.get("x_shuffles") else "xtile") if m.get("x_tiles") else "xsweep")
     r = full.get("roofline")
     if r:
         rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "ms_per_stage", "alg_bytes_per_launch",
@@ -704,7 +711,7 @@ def compact_line(full):
             elif isinstance(v, dict):
                 oo[k] = v.get("value")
                 rf = v.get("roofline") or {}
-                if k in ("c3", "c4") and rf:
+                if k in ("c3", "c4", "ref_nens1", "c2grid_nens1") and rf:
                     oo[k + "_stage_frac"] = rf.get("stage_frac")
                     oo[k + "_stage_traffic_ratio"] = rf.get("stage_traffic_ratio")
         oo["unit"] = "cell-updates/s"
@@ -809,8 +816,11 @@ def worker(args):
     # ---- per-kernel durations (HIP events on the stream each kernel is launched on), separate un-timed passes
     roofline, kernels, kernel_rooflines = None, {}, []
     if not args.no_kernel_timing:
-        roofline, kernels, kernel_rooflines = measure_roofline(job, args, default_workload=(args.nens == 0 and args.scaling == "weak"
-                                                                                           and not args.limiter))
+        plain = args.scaling == "weak" and not args.limiter
+        pkey = args.config if (plain and args.nens == 0) else ("c2grid_nens%d" % args.nens if (plain and args.config == "c2") else None)
+        if plain and args.config == "ref" and args.nens in (0, 1):
+            pkey = "ref_nens1"
+        roofline, kernels, kernel_rooflines = measure_roofline(job, args, pkey)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -831,7 +841,7 @@ def worker(args):
     if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs and not args.limiter:
         others = {}
 
-        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, roofline_profile=True):
+        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, profile=None):
             try:
                 a2 = copy.copy(args)
                 a2.limiter = limiter
@@ -845,29 +855,29 @@ def worker(args):
                 if note:
                     others[key]["note"] = note
                 if not args.no_kernel_timing:
-                    rf, _, krf = measure_roofline(j, a2, default_workload=roofline_profile)
+                    rf, _, krf = measure_roofline(j, a2, profile)
                     others[key]["roofline"] = rf
                     others[key]["kernel_rooflines"] = krf
                 j.close()
                 del j
             except Exception as e:
                 others[key] = {"value": None, "error": repr(e)}
-        run_other("c3", "c3")
-        run_other("c4", "c4")
+        run_other("c3", "c3", profile="c3")
+        run_other("c4", "c4", profile="c4")
         # the N = 1 denominators of the two strong-scaling rows and the per-GPU workload of C2 over 8 GPUs
-        run_other("c4_full", "c4", nens=4096, steps=2, roofline_profile=False,
+        run_other("c4_full", "c4", nens=4096, steps=2,
                   note="BASELINE config C4 whole (nens = 4096, NT = 10) on ONE GPU: what c4 (one GPU's 512-member shard) is 1/8 of")
-        run_other("c2_shard128", "c2", nens=128, roofline_profile=False,
+        run_other("c2_shard128", "c2", nens=128,
                   note="what one GPU runs of C2 strong-scaled over 8 GPUs (1024 / 8 members)")
         # the limiter acting on water vapour itself (NT = 1): the flagged paths of the state pass and the fix-up pass
-        run_other("c2_limiter1", "c2", limiter=1, steps=2, roofline_profile=False,
+        run_other("c2_limiter1", "c2", limiter=1, steps=2,
                   note="C2 with dry slabs in the vapour at the same place in every member (--limiter 1)")
-        run_other("c2_limiter2", "c2", limiter=2, steps=2, roofline_profile=False,
+        run_other("c2_limiter2", "c2", limiter=2, steps=2,
                   note="C2 with dry slabs at member-dependent places: nearly every row of 64 members flagged (--limiter 2)")
         # small ensembles (flat lanes + tile kernels): the reference's own input shape and the C2 grid with one member
-        run_other("ref_nens1", "ref", roofline_profile=False, steps=5,
+        run_other("ref_nens1", "ref", steps=5, profile="ref_nens1",
                   note="the shape of the reference's input file (input_pama.yaml: 250x1, nens = 1, 50 levels), Kessler + SHOC tracers")
-        run_other("c2grid_nens1", "c2", nens=1, roofline_profile=False, steps=5, note="C2's 32x32x60 grid with ONE member")
+        run_other("c2grid_nens1", "c2", nens=1, steps=5, profile="c2grid_nens1", note="C2's 32x32x60 grid with ONE member")
         try:
             others["modules"] = modules_timing(torch, dev)
         except Exception as e:
@@ -916,6 +926,8 @@ def main():
     ap.add_argument("--xkernels", default="auto", choices=("auto", "sweep", "tile"),
                     help="x direction: a wavefront per line span / a lane per cell with LDS exchange (auto: tile when nens < 64)")
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
+    ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),
+                    help="x tile kernels: neighbouring cells exchange through LDS + barriers / by wavefront shuffles (a line inside one wavefront)")
     ap.add_argument("--launcher", default="python", choices=("python", "cpp"),
                     help="python: one process per GPU, dt exchange through torch.distributed (RCCL); cpp: examples/driver --gpus N, one "
                          "host thread per GPU in ONE process, dt exchange over N host doubles")

@@ -179,6 +179,12 @@ int pam_amd_awfl_set_fused_stage(pam_amd_awfl_t *h, int enable);
  * completes (a tile shorter than the line gets one halo row on each side), lines per workgroup (whole-line tiles only). */
 int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels);
 int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group);
+/* How the lanes of an x tile kernel exchange values with the lanes of the neighbouring cells (the four outer values of each 5-point
+ * stencil, the right-edge values of the cell to the left, the fluxes of the right face): mode 1 through an LDS image of the tile and
+ * four workgroup barriers; mode 2 by WAVEFRONT SHUFFLES (ds_bpermute_b32 pairs; no LDS, no barrier) -- possible when a whole periodic
+ * line of a tile lies inside one wavefront, i.e. nx x (lanes per row) divides 64: the 32-cell lines of the C1 / C2 grid with one or two
+ * members, 16-cell lines with up to four; 0 = automatic (shuffles wherever possible).  Same bits either way (ABI 4). */
+int pam_amd_awfl_set_x_exchange(pam_amd_awfl_t *h, int mode);
 /* With flat y/z lanes the y and z fluxes of a stage can run as ONE tile kernel as well (a lane per cell; rows of a tile follow the
  * sweep direction, the lanes of a row are contiguous (x, member) / (y, x, member) items) instead of flat-lane SWEEPS (a lane per item
  * walks its line serially): enable = 0 automatic (tile kernel while the whole ensemble is below ~2.6e5 cells), 1 sweeps, 2 tile
@@ -204,7 +210,8 @@ int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_bel
  * defaults a handle created AFTERWARDS starts from, so that in the one-process / N-handle host path (examples/driver.cpp --gpus N)
  * tuning one handle never re-shapes the launches of another.  Drains the handle's streams and rebuilds its member ranges. */
 int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_units, long long two_phase_below, long long split_below);
-/* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels, pointwise kernels on a
+/* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels (0 sweeps, 1 tiles with
+ * LDS exchange, 2 tiles with wavefront shuffles), pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile
  * geometry {lanes per row, member blocks per line, cells per tile, halo rows per side, tiles per line, lines per workgroup} */
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]);

@@ -2125,18 +2125,55 @@ PAMA_D void xtile_stage(const Params &P, const double *__restrict__ prim_in, con
     if (has2) st[f * TS + X.stage_el[2]] = v2[f];
   }
 }
+// WAVEFRONT-SHUFFLE form of the tile exchange.  When a whole periodic line of a tile (nx rows of W lanes) lies inside ONE wavefront
+// -- nx * W divides 64: the C2 / C1 grid with 1 or 2 members, 16-cell lines with up to 4 -- every value a lane exchanges with its
+// neighbours (the four outer stencil values of each quantity, the right-edge values of the cell to its left, the fluxes of its right
+// face) is held by another lane of the same wavefront, and the tile kernels fetch it with wavefront shuffles (ds_bpermute_b32 pairs:
+// the LDS crossbar, no LDS memory): no LDS image, no workgroup barrier.  Same values into the same helpers: same bits as the LDS form.
+struct XShuf { int ln[5]; int l, r; };     // wavefront lanes of the cells i-2 .. i+2 (periodic inside the line), of the left / right cell
+PAMA_HD bool xtile_line_in_wavefront(const Params &P, const XTileGeom &G) {
+  return G.halo == 0 && P.nx * G.W <= 64 && 64 % (P.nx * G.W) == 0;
+}
+// lane: the lane's index inside its wavefront (the workgroup's linear thread index & 63); (tx, ty): member of the row, row
+PAMA_D XShuf xtile_shuffle_lanes(const Params &P, const XTileGeom &G, int lane, int tx, int ty) {
+  XShuf S;
+  const int base = lane - (ty * G.W + tx);             // first lane of the line
+#pragma unroll
+  for (int s = 0; s < 5; s++) {
+    int r = ty + s - 2;
+    r = r < 0 ? r + P.nx : (r >= P.nx ? r - P.nx : r);
+    S.ln[s] = base + r * G.W + tx;
+  }
+  S.l = S.ln[1];
+  S.r = S.ln[3];
+  return S;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+PAMA_D double xtile_shfl(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+#else
+PAMA_D double xtile_shfl(double v, int) { return v; }     // (host emulation: the tile kernels are emulated in their LDS form)
+#endif
+// the stage-input values of the lane's own cell (whole-line tiles: every lane stages exactly its own cell)
+template <int NSF>
+PAMA_D void xtile_load_own(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double (&own)[NSF]) {
+#pragma unroll
+  for (int f = 0; f < NSF; f++) own[f] = (X.nstage > 0) ? uni(prim_in + (long long)fields[f] * P.prim_fs)[X.stage_po[0]] : 0.0;
+}
 PAMA_D void xtile_state_fields(const Params &P, int (&fields)[XT_NS]) {
   fields[0] = P_RHO; fields[1] = P_PRES; fields[2] = P_U; fields[3] = P_V; fields[4] = P_W; fields[5] = P_THETA; fields[6] = P_TR0 + P.idWV;
 }
 // A: one polynomial per field of the lane's own cell, stencils from the staged tile (staged fields: rho, p, u, v, w, theta, vapour).
 // cen: the stage-input values the update needs again: rho*u, v, w, theta, vapour (window element of the cell in the sweep) and the
 // density
-PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[XT_NS],
-                              double (&L)[XT_NS], double (&R)[XT_NS], double (&cen)[6]) {
+//   nb(f, s): the value of staged field f in the cell s - 2 cells away (s = 0, 1, 3, 4) -- from the LDS image of the tile, or (a line
+//   that lies inside ONE wavefront) from the lane that holds it, by a wavefront shuffle (XShuf below)
+template <class Neighbour>
+PAMA_D void xtile_state_polys_from(const Params &P, Neighbour &&nb, const double (&own)[XT_NS], double (&L)[XT_NS], double (&R)[XT_NS],
+                                   double (&cen)[6]) {
   const WenoConsts wc = weno_consts();
   auto stencil = [&](int f, double (&u)[5]) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) u[s] = (s == 2) ? own[f] : st[f * TS + X.s5[s]];
+    for (int s = 0; s < 5; s++) u[s] = (s == 2) ? own[f] : nb(f, s);
   };
   double r[5], u[5], w[5];
   stencil(0, r);
@@ -2165,6 +2202,10 @@ PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st,
   stencil(6, w);
   cen[4] = w[2];
   weno5_const(w, wc, L[6], R[6]);
+}
+PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[XT_NS],
+                              double (&L)[XT_NS], double (&R)[XT_NS], double (&cen)[6]) {
+  xtile_state_polys_from(P, [&](int f, int s) { return st[f * TS + X.s5[s]]; }, own, L, R, cen);
 }
 // B: the fluxes through the lane's LEFT face from the right-edge values of the cell to its left (Rl) and its own left-edge values
 // (Dycore.h:341-386).  own_face: the face belongs to this tile (its cell is one the tile completes): the mass flux (when further
@@ -2251,18 +2292,23 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
 }
 
 // ---- tracer tiles (the arithmetic of x_tracer_sweep, cell by cell): NF further tracers per lane ------------------------------
-template <int NF>
-PAMA_D void xtile_tracer_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[NF], double (&L)[NF],
-                               double (&R)[NF], double (&cen)[NF]) {
+template <int NF, class Neighbour>
+PAMA_D void xtile_tracer_polys_from(const Params &P, Neighbour &&nb, const double (&own)[NF], double (&L)[NF], double (&R)[NF],
+                                    double (&cen)[NF]) {
   const WenoConsts wc = weno_consts();
 #pragma unroll
   for (int n = 0; n < NF; n++) {
     double w[5];
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[s] = (s == 2) ? own[n] : st[n * TS + X.s5[s]];
+    for (int s = 0; s < 5; s++) w[s] = (s == 2) ? own[n] : nb(n, s);
     cen[n] = w[2];
     weno5_const(w, wc, L[n], R[n]);
   }
+}
+template <int NF>
+PAMA_D void xtile_tracer_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[NF], double (&L)[NF],
+                               double (&R)[NF], double (&cen)[NF]) {
+  xtile_tracer_polys_from<NF>(P, [&](int n, int s) { return st[n * TS + X.s5[s]]; }, own, L, R, cen);
 }
 // the fluxes through the lane's left face, upwinded by the face mass flux the state kernel left in flux_x field 0 (Dycore.h:367-385)
 //   have_ruf / ruf_reg: the mass flux through the lane's left face handed over in a register (phase 1 inline in the state kernel: the

@@ -271,20 +271,36 @@ __global__ void __launch_bounds__(256) awfl_trfix_flat_kernel(Params P, const do
   tracer_fixup_cell_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, c);
 }
 
-// TILE form of the further tracers' x sweeps (one pair of tracers); have_ruf: inline in the state kernel (phase 1 only)
-template <int STAGE, int PHASE, int NF>
-__device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, int T, int TS, const double *__restrict__ prim_in,
+// TILE form of the further tracers' x sweeps (one pair of tracers); have_ruf: inline in the state kernel (phase 1 only).
+// SHUF: a whole line of the tile lies inside one wavefront (xtile_line_in_wavefront): the stencil values, the right-edge values and the
+// face fluxes come from the neighbouring lanes by wavefront shuffles -- no LDS image, no workgroup barrier (XShuf, awfl_device.h)
+template <int STAGE, int PHASE, int NF, bool SHUF>
+__device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, const XShuf &S, int T, int TS, const double *__restrict__ prim_in,
                                              const double *__restrict__ prim0, double *__restrict__ prim_out,
                                              const double *__restrict__ fx, const double *__restrict__ fy,
                                              const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
                                              const FctRows &rows, double dt_dyn, double dt_stage, const int *fa, double *lds,
                                              bool have_ruf, double ruf_reg) {
-  // lds: NF staged fields of TS elements (later: the face fluxes), then NF x T right-edge values
-  double *st = lds, *ex = lds + NF * TS;
   double L[NF], R[NF], cen[NF], F[NF], own[NF];
   int fields[NF];
 #pragma unroll
   for (int n = 0; n < NF; n++) fields[n] = P_U + fa[n];
+  if (SHUF) {
+    xtile_load_own<NF>(P, prim_in, X, fields, own);
+    if (X.poly) {      // (whole-line tiles: poly == face == upd; the lanes a lane shuffles with are lanes of its own line)
+      xtile_tracer_polys_from<NF>(P, [&](int n, int s) { return xtile_shfl(own[n], S.ln[s]); }, own, L, R, cen);
+#pragma unroll
+      for (int f = 0; f < NF; f++) R[f] = xtile_shfl(R[f], S.l);
+      xtile_tracer_face<NF>(P, fx, X, L, R, F, have_ruf, ruf_reg);
+      double Fhi[NF];
+#pragma unroll
+      for (int f = 0; f < NF; f++) Fhi[f] = xtile_shfl(F[f], S.r);
+      xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
+    }
+    return;
+  }
+  // lds: NF staged fields of TS elements (later: the face fluxes), then NF x T right-edge values
+  double *st = lds, *ex = lds + NF * TS;
   xtile_stage<NF>(P, prim_in, X, fields, st, TS, own);
   __syncthreads();
   if (X.poly) {
@@ -309,8 +325,9 @@ __device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, in
   }
 }
 // TILE form of the fused x-sweep (xtile_* in awfl_device.h): a lane per cell, right-edge values and face fluxes exchanged through
-// LDS (XT_NS doubles per lane, used twice).  grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
-template <int STAGE>
+// LDS (XT_NS doubles per lane, used twice) -- or, SHUF, by wavefront shuffles when a line lies inside one wavefront.
+// grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
+template <int STAGE, bool SHUF>
 __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
                                                               const double *__restrict__ prim0, double *__restrict__ prim_out,
                                                               double *__restrict__ fx, const double *__restrict__ fy,
@@ -322,47 +339,63 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
   const int TS = xtile_stage_elems(G);
-  // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
-  double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
+  XShuf S = {};
+  if (SHUF) S = xtile_shuffle_lanes(P, G, (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) & 63, (int)threadIdx.x, (int)threadIdx.y);
   double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
   int fields[XT_NS];
   xtile_state_fields(P, fields);
-  xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
-  __syncthreads();
-  if (X.poly) {
-    xtile_state_polys(P, X, st, TS, own, L, R, cen);
+  if (SHUF) {
+    xtile_load_own<XT_NS>(P, prim_in, X, fields, own);
+    if (X.poly) {
+      xtile_state_polys_from(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
 #pragma unroll
-    for (int f = 0; f < XT_NS; f++) ex[f * T + X.slot] = R[f];
-  }
-  __syncthreads();
-  if (X.face) {
+      for (int f = 0; f < XT_NS; f++) R[f] = xtile_shfl(R[f], S.l);       // now: the right-edge values of the cell to the left
+      xtile_state_face(P, fx, X, L, R, X.upd, F);
+      double Fhi[XT_NF];
 #pragma unroll
-    for (int f = 0; f < XT_NS; f++) R[f] = ex[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
-    xtile_state_face(P, fx, X, L, R, X.upd, F);
+      for (int f = 0; f < XT_NF; f++) Fhi[f] = xtile_shfl(F[f], S.r);
+      xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
+    }
+  } else {
+    // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
+    double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
+    xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
+    __syncthreads();
+    if (X.poly) {
+      xtile_state_polys(P, X, st, TS, own, L, R, cen);
 #pragma unroll
-    for (int f = 0; f < XT_NF; f++) st[f * T + X.slot] = F[f];          // (every stencil read of the staged tile is behind the barrier)
-  }
-  __syncthreads();
-  if (X.upd) {
-    double Fhi[XT_NF];
+      for (int f = 0; f < XT_NS; f++) ex[f * T + X.slot] = R[f];
+    }
+    __syncthreads();
+    if (X.face) {
 #pragma unroll
-    for (int f = 0; f < XT_NF; f++) Fhi[f] = st[f * T + X.slot_r];
-    xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
+      for (int f = 0; f < XT_NS; f++) R[f] = ex[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
+      xtile_state_face(P, fx, X, L, R, X.upd, F);
+#pragma unroll
+      for (int f = 0; f < XT_NF; f++) st[f * T + X.slot] = F[f];          // (every stencil read of the staged tile is behind the barrier)
+    }
+    __syncthreads();
+    if (X.upd) {
+      double Fhi[XT_NF];
+#pragma unroll
+      for (int f = 0; f < XT_NF; f++) Fhi[f] = st[f * T + X.slot_r];
+      xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
+    }
   }
   // phase 1 of the further tracers (their FCT multipliers) inline -- small ensembles, where a launch costs more than the work: the
   // mass flux through the lane's left face is still in its register
   if (tracers_inline) {
     for (int i = 0; i < P.nt - 1; i += 2) {
       const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
-      __syncthreads();
+      if (!SHUF) __syncthreads();
       if (i + 1 < P.nt - 1)
-        xtr_tile_run<STAGE, 1, 2>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+        xtr_tile_run<STAGE, 1, 2, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
       else
-        xtr_tile_run<STAGE, 1, 1>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
+        xtr_tile_run<STAGE, 1, 1, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, true, F[0]);
     }
   }
 }
-template <int STAGE, int PHASE>
+template <int STAGE, int PHASE, bool SHUF>
 __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
                                                              const double *__restrict__ prim0, double *__restrict__ prim_out,
                                                              const double *__restrict__ fx, const double *__restrict__ fy,
@@ -385,11 +418,13 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
     return;
   }
   const int TS = xtile_stage_elems(G);
+  XShuf S = {};
+  if (SHUF) S = xtile_shuffle_lanes(P, G, (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) & 63, (int)threadIdx.x, (int)threadIdx.y);
   const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
   if (2 * pair + 1 < P.nt - 1)
-    xtr_tile_run<STAGE, PHASE, 2>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
+    xtr_tile_run<STAGE, PHASE, 2, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
   else
-    xtr_tile_run<STAGE, PHASE, 1>(P, X, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
+    xtr_tile_run<STAGE, PHASE, 1, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds, false, 0.0);
 }
 
 // TILE form of the fused stage's y and z sweeps (ftile_* in awfl_device.h): a lane per cell, one launch for both directions --
@@ -663,6 +698,8 @@ struct pam_amd_awfl {
   int xtile_mode = 0;          // 0 automatic, 1 sweep kernels (a wavefront per line span), 2 tile kernels (a lane per cell)
   bool xtile = false;          // resolved: the x direction of the fused stage runs as tile kernels
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
+  int xshuf_mode = 0;          // x tile kernels, exchange between neighbouring cells: 0 automatic, 1 through LDS, 2 wavefront shuffles
+  bool xshuf = false;          // resolved: wavefront shuffles (a whole periodic line of a tile lies inside one wavefront)
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
   int tile_pressure_mode = 0;  // 0 automatic, 1 separate pressure pass, 2 inside the x tile kernel
   bool tile_pressure = true;   // x tile kernels: the next stage's pressure inside awfl_xupd_tile_kernel (no awfl_ptail_kernel launch)
@@ -923,15 +960,24 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     const dim3 block((unsigned)G.W, (unsigned)xtile_rows(G), (unsigned)G.lpb);
     const dim3 grid((unsigned)(G.ntl * G.nmb), (unsigned)((nlines + G.lpb - 1) / G.lpb), 1);
     if (grid.y > 65535u) return fail(PAM_AMD_EINVAL, "x-tile launch: more than 65535 groups of x lines");
-    if ((size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) > 160 * 1024)
+    if (!h->xshuf && (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) > 160 * 1024)
       return fail(PAM_AMD_EINVAL, "x-tile launch: the staged tile does not fit the 160 KB of LDS");
     // a wavefront is one row of FCT flags only when a row of the tile is exactly one 64-member block
     const bool wave_is_row = (G.W == 64 && P.nens % 64 == 0);
+    // a whole line inside one wavefront: neighbours by wavefront shuffles (no LDS image, no barrier); else through LDS
+    const bool shuf = h->xshuf;
+    const size_t lds_state = shuf ? 0 : (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double);
+    const size_t lds_pair = shuf ? 0 : (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double);
     {
       ScopedTimer st(h, "xupd", s);
-      hipLaunchKernelGGL(awfl_xupd_tile_kernel<STAGE>, grid, block, (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
-                         prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                         h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+      if (shuf)
+        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), grid, block, lds_state, s, P, G, prim_in, prim0,
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+      else
+        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), grid, block, lds_state, s, P, G, prim_in, prim0,
+                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
@@ -940,17 +986,26 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       const dim3 tgrid(grid.x, grid.y, (unsigned)npairs);
       if (!h->tile_pressure) {       // (small ensembles: phase 1 ran inline in the state kernel, like the pressure pass)
         ScopedTimer st(h, "xtr1", s);
-        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1>), tgrid, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
-                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage, 0);
+        if (shuf)
+          hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1, true>), tgrid, block, lds_pair, s, P, G, prim_in, prim0,
+                             prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage, 0);
+        else
+          hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 1, false>), tgrid, block, lds_pair, s, P, G, prim_in, prim0,
+                             prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage, 0);
         HIP_TRY(hipGetLastError());
       }
       {
         // (small ensembles: one more z slice does water vapour's fix-up -- launch_tail then has nothing left to launch)
         ScopedTimer st(h, "xtr2", s);
         const dim3 tgrid2(grid.x, grid.y, (unsigned)(npairs + (h->tile_pressure ? 1 : 0)));
-        hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2>), tgrid2, block, (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double), s, P, G, prim_in, prim0,
-                           prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0);
+        if (shuf)
+          hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2, true>), tgrid2, block, lds_pair, s, P, G, prim_in, prim0,
+                             prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                             h->tile_pressure ? 1 : 0);
+        else
+          hipLaunchKernelGGL((awfl_xtr_tile_kernel<STAGE, 2, false>), tgrid2, block, lds_pair, s, P, G, prim_in, prim0,
+                             prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
+                             h->tile_pressure ? 1 : 0);
         HIP_TRY(hipGetLastError());
       }
     }
@@ -1088,6 +1143,8 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // (the groups of x lines are the y dimension of the tile kernels' launch grid: at most 65535)
   const bool grid_ok = ((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb <= 65535;
   h->xtile = xtile_supported(P) && grid_ok && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
+  // neighbours by wavefront shuffles instead of an LDS image + barriers wherever a line lies inside one wavefront
+  h->xshuf = h->xtile && h->xshuf_mode != 1 && xtile_line_in_wavefront(P, h->xg);
   P.flat_cells = (h->lane_mode != 1 && (long long)P.nx * P.nens < 256 && P.ncell < (1ll << 31)) ? 1 : 0;
   // the y/z fluxes of a flat-lane stage: ONE tile kernel (a lane per cell) while the whole ensemble is below ~2.6e5 cells -- a flat-lane
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
@@ -1334,15 +1391,15 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // the tile kernels stage their tiles in LDS: up to 14 doubles per lane of a 1024-lane workgroup
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
@@ -1851,6 +1908,20 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   return build_chunks(h);
 }
 
+int pam_amd_awfl_set_x_exchange(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_x_exchange: 0 = automatic, 1 = through LDS, 2 = wavefront shuffles");
+  const int old = h->xshuf_mode;
+  h->xshuf_mode = mode;
+  resolve_lane_mapping(h);
+  if (mode == 2 && !h->xshuf) {
+    h->xshuf_mode = old;
+    resolve_lane_mapping(h);
+    return fail(PAM_AMD_EINVAL, "set_x_exchange: wavefront shuffles need x tile kernels whose whole periodic line lies inside one wavefront (nx * row lanes divides 64)");
+  }
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (cells_per_y_tile < 0 || levels_per_z_tile < 0) return fail(PAM_AMD_EINVAL, "set_flux_tile: tile sizes must be >= 0 (0 = automatic)");
@@ -1907,6 +1978,7 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
   if (yz_flat) *yz_flat = h->flat ? (h->ftile ? 2 : 1) : 0;
   if (x_tiles) *x_tiles = h->xtile ? 1 : 0;
   if (flat_cells) *flat_cells = h->P.flat_cells;
+  if (x_tiles && h->xtile && h->xshuf) *x_tiles = 2;
   if (geom) { geom[0] = h->xg.W; geom[1] = h->xg.nmb; geom[2] = h->xg.tc; geom[3] = h->xg.halo; geom[4] = h->xg.ntl; geom[5] = h->xg.lpb; }
   return PAM_AMD_OK;
 }

@@ -260,6 +260,11 @@ class Dycore:
     def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
         check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
 
+    def set_x_exchange(self, mode="auto"):
+        """x tile kernels: neighbouring cells exchange values through "lds" (+ workgroup barriers) or by wavefront "shuffle"s (a whole
+        line inside one wavefront) | "auto" (shuffles wherever possible); same bits"""
+        check(self._lib.pam_amd_awfl_set_x_exchange(self._h, {"auto": 0, "lds": 1, "shuffle": 2}[mode]))
+
     def set_flux_tile(self, mode="auto", cells_per_y_tile=0, levels_per_z_tile=0):
         """y/z fluxes of a flat-lane stage: "sweep" (flat-lane sweeps) | "tile" (one tile kernel) | "auto" """
         check(self._lib.pam_amd_awfl_set_flux_tile(self._h, {"auto": 0, "sweep": 1, "tile": 2}[mode], int(cells_per_y_tile),
@@ -277,7 +282,8 @@ class Dycore:
         flat, tile, cells = C.c_int(), C.c_int(), C.c_int()
         g = (C.c_int * 6)()
         check(self._lib.pam_amd_awfl_get_lane_mapping(self._h, C.byref(flat), C.byref(tile), C.byref(cells), g))
-        return {"yz_flat": bool(flat.value), "yz_tile_kernel": flat.value == 2, "x_tiles": bool(tile.value), "flat_cells": bool(cells.value),
+        return {"yz_flat": bool(flat.value), "yz_tile_kernel": flat.value == 2, "x_tiles": bool(tile.value), "x_shuffles": tile.value == 2,
+                "flat_cells": bool(cells.value),
                 "tile": dict(zip(("W", "nmb", "tc", "halo", "ntl", "lpb"), list(g)))}
 
     def debug_buffer(self, name):

@@ -58,6 +58,19 @@ def main():
             wc = m["SQ_WAVE_CYCLES"]
             print("%-34s wave-cycle split: waiting (s_waitcnt/barrier) %.1f %%, issue-stalled %.1f %%, issuing %.1f %%"
                   % (k, 100 * m["SQ_WAIT_ANY"] / wc, 100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * m.get("SQ_ACTIVE_INST_ANY", 0) / wc))
+    for k in sorted(acc):
+        a = acc[k]
+        if "SQ_WAVES" in a and "SQ_WAVE_CYCLES" in a:
+            # per wavefront: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants)
+            m = {c: sum(v) / len(v) for c, v in a.items()}
+            w = max(m["SQ_WAVES"], 1.0)
+            extra = ""
+            for c, label in (("SQ_INSTS_LDS", "LDS"), ("SQ_INSTS_SALU", "SALU"), ("SQ_INSTS_SMEM", "SMEM"), ("SQ_INSTS_VMEM_RD", "vmem-rd"),
+                             ("SQ_INSTS_VMEM_WR", "vmem-wr"), ("SQ_IFETCH", "ifetch")):
+                if c in m:
+                    extra += ", %s %.0f" % (label, m[c] / w)
+            print("%-34s per wavefront: %.0f wavefronts per launch, %.0f cycles resident, VALU instructions %.0f%s"
+                  % (k, w, 4.0 * m["SQ_WAVE_CYCLES"] / w, m.get("SQ_INSTS_VALU", 0.0) / w, extra))
     if "--traffic-json" in sys.argv:
         # HBM bytes per launch of every stage kernel: FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B; calibrated on
         # kernels of known byte counts) + WRITE_SIZE; template instances of one kernel are averaged
@@ -66,7 +79,7 @@ def main():
         def family(k):
             """template instances of one kernel are one family -- except the two PHASES of the tracer sweeps, which are different
             kernels in all but name: awfl_xtr_kernel<STAGE, PHASE> -> awfl_xtr_kernel<PHASE> (bench.py's name for them)"""
-            m = re.match(r"(awfl_xtr_kernel)<\s*\d+\s*,\s*(\d+)\s*>", k)
+            m = re.match(r"(awfl_xtr(?:_tile)?_kernel)<\s*\d+\s*,\s*(\d+)\s*>", k)
             return "%s<%s>" % (m.group(1), m.group(2)) if m else re.sub(r"<.*", "", k)
         out = {}
         for k in acc:
@@ -77,7 +90,7 @@ def main():
         res = {}
         nlaunch = {base: sum(r[2] for r in rows) for base, rows in out.items()}
         # tendency stages in the profiled run: every stage has exactly one update-type launch
-        nstage = nlaunch.get("awfl_xupd_kernel") or nlaunch.get("awfl_update_kernel") or 1
+        nstage = nlaunch.get("awfl_xupd_kernel") or nlaunch.get("awfl_xupd_tile_kernel") or nlaunch.get("awfl_update_kernel") or 1
         for base, rows in out.items():
             n = nlaunch[base]
             fetch, write = sum(r[0] for r in rows), sum(r[1] for r in rows)
