@@ -119,7 +119,7 @@ def test_bench_py_small_ensemble_line_uses_flat_lanes_and_tiles():
     d, full = _run_bench("--nens", "2")
     _check_contract(d, nens_per_gpu=2)
     m = full["config"]["lane_mapping"]
-    assert m["yz_flat"] and m["x_tiles"] and m["flat_cells"] and d["config"]["lanes"] == "flat+xtile"
+    assert m["yz_flat"] and m["x_tiles"] and m["flat_cells"] and d["config"]["lanes"] == "flat+xtile-shfl"      # (2 x 32 lanes: a line is one wavefront)
 
 
 @pytest.mark.gpu

@@ -31,7 +31,12 @@ CASES = {
     "nens128_nt4_rows": (128, 32, 4, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, True, idz.CONSTS_DEFAULT, False, [(32, 0, 0), (64, 6, 0)]),
     "nens70_ragged_vapour_limited": (70, 12, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT, True, [(35, 0, 0)]),
     "nens192_nt10_2d": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), False, False, idz.CONSTS_P3, False, [(64, 14, 0)]),
+    # whole lines inside ONE wavefront (nx x row lanes divides 64): the x tile kernels exchange by wavefront shuffles (SHUFFLE_CASES below)
+    "nens1_nx16_nt4": (1, 16, 4, 10, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(10, 12000.0), False, True, idz.CONSTS_DEFAULT, False, [(0, 0, 1), (0, 0, 3)]),
+    "nens4_nx16_nt10_2d_p3_B": (4, 16, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), True, False, idz.CONSTS_P3, False, [(2, 0, 0)]),
+    "nens2_nx32_vapour_limited": (2, 32, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT, True, [(1, 0, 0)]),
 }
+SHUFFLE_CASES = ("nens1_c2grid_slab", "nens2_c1_like", "nens1_nx16_nt4", "nens4_nx16_nt10_2d_p3_B", "nens2_nx32_vapour_limited")
 
 
 def _fields(case):
@@ -47,7 +52,7 @@ def _fields(case):
     return f, xlen, ylen
 
 
-def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=("auto", 0, 0), graph="auto", dts=(2.0, 0.7)):
+def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=("auto", 0, 0), graph="auto", dts=(2.0, 0.7), xex="auto"):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
@@ -68,6 +73,8 @@ def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=
     dycore.init(coupler)
     dycore.set_lane_mapping(yz, xk)
     dycore.set_x_tile(*tile)
+    if xex != "auto":
+        dycore.set_x_exchange(xex)
     dycore.set_flux_tile(*ftile)
     dycore.set_tile_fusion("inside" if ftile[0] == "tile" else ("separate" if ftile[0] == "sweep" else "auto"))
     dycore.set_graph_replay(graph)
@@ -108,6 +115,53 @@ def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(c
         for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
             assert np.isfinite(got[k]).all(), (yz, xk, tile, ftile, k)
             assert np.array_equal(ref[k], got[k]), (yz, xk, tile, ftile, m1, k, np.abs(ref[k] - got[k]).max())
+
+
+@pytest.mark.parametrize("case", SHUFFLE_CASES)
+def test_wavefront_shuffle_exchange_equals_the_lds_exchange_and_the_sweeps_bit_for_bit(case):
+    """north_star: "wavefront shuffles for the 5-point reconstruction".  Where a whole periodic line of an x tile lies inside one
+    wavefront the tile kernels fetch the stencil values, the right-edge values of the cell to the left and the fluxes of the right
+    face from the neighbouring LANES (ds_bpermute pairs) -- no LDS image, no workgroup barrier -- and that is the default there.  Same
+    values into the same helpers: the same bits as the LDS form and as the member-lane sweeps; state kernel, inline and separately
+    launched tracer phases, vapour limited, 2-D and 3-D, mode B, per-member grids, one and several lines per wavefront."""
+    f, xlen, ylen = _fields(case)
+    tiles = CASES[case][-1]
+    n0, ref, m0, rows = _run(case, f, xlen, ylen, "member", "sweep")
+    if CASES[case][-2]:
+        assert 0 < rows[0] <= rows[1] and rows[2], rows
+    for tile in [(0, 0, 0)] + list(tiles):
+        for ftile in (("auto", 0, 0), ("sweep", 0, 0)):         # ("sweep": the pressure pass and tracer phase 1 as launches of their own)
+            outs = {}
+            for xex in ("lds", "shuffle", "auto"):
+                n1, got, m1, _ = _run(case, f, xlen, ylen, "flat", "tile", tile, ftile=ftile, xex=xex)
+                assert m1["x_tiles"] and m1["x_shuffles"] == (xex != "lds"), (xex, m1)
+                assert n1 == n0
+                outs[xex] = got
+            for xex, got in outs.items():
+                for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+                    assert np.isfinite(got[k]).all(), (xex, tile, k)
+                    assert np.array_equal(ref[k], got[k]), (xex, tile, ftile, k, np.abs(ref[k] - got[k]).max())
+
+
+def test_wavefront_shuffles_are_refused_where_a_line_does_not_fit_a_wavefront():
+    from pam_amd import PamAmdError
+    import torch
+    from pam_amd import Dycore, PamCoupler
+    case = "nens8_nt4_B"                      # 12-cell lines of 8 members: 96 lanes
+    nens, nx, ny, nz, tr, zint = CASES[case][:6]
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 2.0)
+    coupler.allocate_coupler_state(nz, ny, nx, nens)
+    coupler.set_grid(nx * 500.0, ny * 500.0, zint)
+    for n, p, m in tr:
+        coupler.add_tracer(n, "", p, m)
+    d = Dycore()
+    d.init(coupler)
+    assert d.get_lane_mapping()["x_tiles"] and not d.get_lane_mapping()["x_shuffles"]
+    with pytest.raises(PamAmdError):
+        d.set_x_exchange("shuffle")
+    d.set_x_exchange("lds")
+    d.finalize(coupler)
 
 
 def test_small_ensemble_defaults_are_flat_and_tile_and_large_ones_member_and_sweep():

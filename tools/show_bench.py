@@ -3,7 +3,7 @@
 import json, sys
 for f in sys.argv[1:]:
     try:
-        b = json.loads([l for l in open(f) if l.startswith('{"metric"')][-1])
+        b = json.loads([l for l in open(f) if l.startswith('{"metric"')][-1])     # a bench.py --detail file (or an old full line)
     except Exception as e:
         print(f, "unreadable:", e); continue
     c = b["config"]
