@@ -2542,19 +2542,31 @@ PAMA_D void ftile_acoustic_face(const Params &P, double *__restrict__ flux, cons
   if (X.own) uniw(flux)[X.fo] = ruf;
 }
 // the advected quantities fa[0..nf) (advected-field indices: 0 u, 1 v, 2 w, 3 theta, 4.. tracers)
+//   ftile_adv_load: the 5-point stencils of a group (requested one group AHEAD by the device kernel: the next group's values travel
+//   while this group's polynomials are built -- a group is otherwise a full memory round trip behind a barrier)
+PAMA_D void ftile_adv_load(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf, double (&w)[FT_NG][5]) {
+#pragma unroll
+  for (int n = 0; n < FT_NG; n++) {
+    gc_ptr f = uni(prim + (long long)(P_U + ((n < nf) ? fa[n] : 0)) * P.prim_fs);
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[n][s] = (n < nf && X.poly) ? f[X.o5[s]] : 0.0;
+  }
+}
 template <int DIR, bool VZ_PER_ENS>
-PAMA_D void ftile_adv_polys(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf,
-                            double (&L)[FT_NG], double (&R)[FT_NG]) {
+PAMA_D void ftile_adv_polys_from(const Params &P, const FLane &X, int nf, const double (&w)[FT_NG][5], double (&L)[FT_NG], double (&R)[FT_NG]) {
   const WenoConsts wc = weno_consts();
 #pragma unroll
   for (int n = 0; n < FT_NG; n++) {
     if (n >= nf) { L[n] = R[n] = 0.0; continue; }
-    gc_ptr f = uni(prim + (long long)(P_U + fa[n]) * P.prim_fs);
-    double w[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) w[s] = f[X.o5[s]];
-    ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, w, L[n], R[n]);
+    ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, w[n], L[n], R[n]);
   }
+}
+template <int DIR, bool VZ_PER_ENS>
+PAMA_D void ftile_adv_polys(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf,
+                            double (&L)[FT_NG], double (&R)[FT_NG]) {
+  double w[FT_NG][5];
+  ftile_adv_load(P, prim, X, fa, nf, w);
+  ftile_adv_polys_from<DIR, VZ_PER_ENS>(P, X, nf, w, L, R);
 }
 // their fluxes through the lane's lower face; tracers leave as faces at once, state variables wait for the difference
 template <int DIR>

@@ -337,15 +337,29 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   fct_rows_resolve(rows);
   extern __shared__ double xt_lds[];
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
+  const int tid = (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
   const int TS = xtile_stage_elems(G);
+  // the pressure pass inside this kernel (small ensembles): the tables of pow_pos_fast (3.5 KB) go to LDS, as in awfl_ptail_kernel --
+  // a pow is two dependent per-lane table look-ups, and the lanes of a boundary level chain nine of them (the density / pressure
+  // ghosts, Dycore.h:682-709): those wavefronts are the last to finish
+  __shared__ PowTab sh_tab;
+  if (with_pressure) {
+    const double *src = reinterpret_cast<const double *>(P.pw);
+    double *dst = reinterpret_cast<double *>(&sh_tab);
+    for (int i = tid; i < (int)(sizeof(PowTab) / sizeof(double)); i += T) dst[i] = src[i];
+  }
   XShuf S = {};
-  if (SHUF) S = xtile_shuffle_lanes(P, G, (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x) & 63, (int)threadIdx.x, (int)threadIdx.y);
+  if (SHUF) S = xtile_shuffle_lanes(P, G, tid & 63, (int)threadIdx.x, (int)threadIdx.y);
   double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
   int fields[XT_NS];
   xtile_state_fields(P, fields);
   if (SHUF) {
     xtile_load_own<XT_NS>(P, prim_in, X, fields, own);
+    if (with_pressure) {        // (the one barrier of the shuffle form: the table is complete; reached long before it is needed)
+      __syncthreads();
+      P.pw = &sh_tab;
+    }
     if (X.poly) {
       xtile_state_polys_from(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
 #pragma unroll
@@ -361,6 +375,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
     double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
     xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
     __syncthreads();
+    if (with_pressure) P.pw = &sh_tab;
     if (X.poly) {
       xtile_state_polys(P, X, st, TS, own, L, R, cen);
 #pragma unroll
@@ -432,7 +447,7 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
 // two ping-pong sets of FT_NG right-edge values + 4 face fluxes (the state variables' differences).
 constexpr int FT_MAXG = (4 + MAXT + FT_NG - 1) / FT_NG + 1;
 struct FTileGroups { int ny_groups, nz_groups; int gy[FT_MAXG][FT_NG], gz[FT_MAXG][FT_NG]; };
-template <int DIR, bool VZ_PER_ENS>
+template <int DIR, bool VZ_PER_ENS, bool AHEAD>
 __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &G, int bx, int by, int T, const int (*grp)[FT_NG],
                                               int ngroups, const double *__restrict__ prim, double *__restrict__ flux, double *lds) {
   const int rows = ftile_rows(G), per = rows * G.W;
@@ -443,6 +458,19 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
   double *ldsR[2] = {lds, lds + FT_NG * T}, *ldsF = lds + 2 * FT_NG * T;
   const int ncomp_a = (DIR == 1) ? 1 : 2;
   double L[FT_NG], R[FT_NG], F[FT_NG], ruf = 0.0, fn = 0.0;
+  // the stencils of the advected groups are requested one group ahead (wn): group 0's before the acoustic polynomials are built
+  double wn[FT_NG][5];
+  auto group_fields = [&](int g, int (&fa)[FT_NG]) -> int {
+    int nf = 0;
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; }
+    return nf;
+  };
+  if (AHEAD) {
+    int fa0[FT_NG];
+    const int nf0 = (ngroups > 0) ? group_fields(0, fa0) : 0;
+    ftile_adv_load(P, prim, X, fa0, nf0, wn);
+  }
   if (X.poly) {
     ftile_acoustic_polys<DIR, VZ_PER_ENS>(P, prim, X, L, R);
 #pragma unroll
@@ -457,11 +485,21 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
   }
   for (int g = 0; g < ngroups; g++) {
     double *buf = ldsR[(g + 1) & 1];
-    int fa[FT_NG], nf = 0;
+    int fa[FT_NG];
+    const int nf = group_fields(g, fa);
+    double w[FT_NG][5];
+    if (!AHEAD) ftile_adv_load(P, prim, X, fa, nf, wn);
 #pragma unroll
-    for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; }
+    for (int n = 0; n < FT_NG; n++)
+#pragma unroll
+      for (int s5 = 0; s5 < 5; s5++) w[n][s5] = wn[n][s5];
+    if (AHEAD && g + 1 < ngroups) {
+      int fa1[FT_NG];
+      const int nf1 = group_fields(g + 1, fa1);
+      ftile_adv_load(P, prim, X, fa1, nf1, wn);
+    }
     if (X.poly) {
-      ftile_adv_polys<DIR, VZ_PER_ENS>(P, prim, X, fa, nf, L, R);
+      ftile_adv_polys_from<DIR, VZ_PER_ENS>(P, X, nf, w, L, R);
 #pragma unroll
       for (int n = 0; n < FT_NG; n++) buf[n * T + X.slot] = R[n];
     }
@@ -486,14 +524,16 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
     }
   }
 }
-template <bool VZ_PER_ENS>
-__global__ void __launch_bounds__(1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
+// MAXT: the largest workgroup the instance may be launched with (1024, or 512: twice the registers per lane -- the stencils requested one
+// group ahead do not fit the 128 registers a 1024-lane workgroup leaves a lane)
+template <bool VZ_PER_ENS, int MAXT>
+__global__ void __launch_bounds__(MAXT) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
                                                               const double *__restrict__ prim, double *__restrict__ fy,
                                                               double *__restrict__ fz) {
   extern __shared__ double ft_lds[];
   const int T = (int)blockDim.x, b = (int)blockIdx.x;
-  if (b < nby) flux_tile_run<1, VZ_PER_ENS>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
-  else flux_tile_run<2, VZ_PER_ENS>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
+  if (b < nby) flux_tile_run<1, VZ_PER_ENS, (MAXT <= 512)>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
+  else flux_tile_run<2, VZ_PER_ENS, (MAXT <= 512)>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
 }
 
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
@@ -846,8 +886,11 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     if (T > 1024) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes");
     const size_t lds = (size_t)(2 * FT_NG + 4) * T * sizeof(double);
     ScopedTimer st(h, "flux", s);
-    if (P.vz_per_ens) hipLaunchKernelGGL(awfl_flux_tile_kernel<true>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
-    else hipLaunchKernelGGL(awfl_flux_tile_kernel<false>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
+#define PAMA_LAUNCH_FTILE(VZ, MT) \
+  hipLaunchKernelGGL((awfl_flux_tile_kernel<VZ, MT>), dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z)
+    if (T <= 512) { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 512); else PAMA_LAUNCH_FTILE(false, 512); }
+    else { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 1024); else PAMA_LAUNCH_FTILE(false, 1024); }
+#undef PAMA_LAUNCH_FTILE
     HIP_TRY(hipGetLastError());
     return PAM_AMD_OK;
   }
@@ -960,7 +1003,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     const dim3 block((unsigned)G.W, (unsigned)xtile_rows(G), (unsigned)G.lpb);
     const dim3 grid((unsigned)(G.ntl * G.nmb), (unsigned)((nlines + G.lpb - 1) / G.lpb), 1);
     if (grid.y > 65535u) return fail(PAM_AMD_EINVAL, "x-tile launch: more than 65535 groups of x lines");
-    if (!h->xshuf && (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) > 160 * 1024)
+    if (!h->xshuf && (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) + sizeof(PowTab) > 160 * 1024)
       return fail(PAM_AMD_EINVAL, "x-tile launch: the staged tile does not fit the 160 KB of LDS");
     // a wavefront is one row of FCT flags only when a row of the tile is exactly one 64-member block
     const bool wave_is_row = (G.W == 64 && P.nens % 64 == 0);
@@ -1400,8 +1443,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 0;   // no residency cap by default
   h->want_units = g_want_units.load(); h->two_phase_below = g_two_phase_below.load(); h->split_below = g_split_below.load();
@@ -1900,7 +1945,7 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
   const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group);
   if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
-  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) > 160 * 1024)
+  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) + sizeof(PowTab) > 160 * 1024)
     return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");
   USE_DEVICE(h);
   h->xt_w = row_lanes; h->xt_tc = cells_per_tile; h->xt_lpb = lines_per_group;
