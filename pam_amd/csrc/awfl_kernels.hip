@@ -212,6 +212,35 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
       x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
+// The same sweeps with up to FOUR further tracers per wavefront (pam_amd_awfl_set_tracer_grouping; VERDICT r3 / r4 experiment (a)): half the
+// wavefronts, the per-wavefront loads shared by a pair (face mass flux, the three densities) shared by four tracers -- and twice the
+// windows in registers.  A kernel of its own so that the pair form keeps its register count.  Same arithmetic per tracer: same bits.
+template <int STAGE, int PHASE>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr4_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                                const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                                const double *__restrict__ fx, const double *__restrict__ fy,
+                                                                const double *__restrict__ fz, double *__restrict__ seed,
+                                                                double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                                double dt_stage, int ngroups, int span, int nspan) {
+  fct_rows_resolve(rows);
+  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
+  const int nblk = (R.ne + 63) >> 6;
+  const int g2 = uni_int(u / ngroups), grp4 = u - g2 * ngroups;
+  const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
+  const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + (int)(threadIdx.x & 63);
+  if (line < P.nz * P.ny && el < R.ne) {
+    const int first = 4 * grp4, left = P.nt - 1 - first;
+    const int fa[4] = {4 + further_tracer(P, first), 4 + further_tracer(P, first + 1), 4 + further_tracer(P, first + 2), 4 + further_tracer(P, first + 3)};
+    if (left >= 4)
+      x_tracer_sweep<4, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+    else if (left == 3)
+      x_tracer_sweep<3, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+    else if (left == 2)
+      x_tracer_sweep<2, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+    else
+      x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+  }
+}
 // Pointwise tail of the fused stage, (1): next stage's pressure + density/pressure ghosts: a pow per cell and nothing else, so few
 // registers and full occupancy; TAIL_LEVELS levels per thread (a sixth of the wavefronts, the (i, member) split once).
 constexpr int TAIL_LEVELS = 6;
@@ -751,6 +780,7 @@ struct pam_amd_awfl {
   bool fused_supported = false;
   size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
   long long want_units = 3072, two_phase_below = 8192, split_below = 8192;   // launch-shape thresholds (pam_amd_awfl_set_handle_launch_tuning)
+  int tracers_per_wave = 2;    // further tracers swept by one wavefront of the separately launched x tracer sweeps: 2 (default) or 4
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
@@ -1075,21 +1105,33 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     HIP_TRY(hipGetLastError());
   }
   // the tracer launches have npairs wavefronts per (line, member block, span): their lines are cut less (or not at all)
+  const bool quads = h->tracers_per_wave == 4;
+  const int ngroups = quads ? (P.nt - 1 + 3) / 4 : npairs;        // wavefronts per (line, member block, span): pairs or groups of four
   int tspan = span, tnspan = nspan;
-  if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * npairs, P.nens, P.seg, h->span_override, tspan, tnspan);
-  const long long tunits = nlb * tnspan * npairs;
+  if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * ngroups, P.nens, P.seg, h->span_override, tspan, tnspan);
+  const long long tunits = nlb * tnspan * ngroups;
   if (split) {     // phase 1 of the further tracers (their FCT multipliers) in a launch of its own
     ScopedTimer st(h, "xtr1", s);
-    hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
-                       prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
-                       npairs, tspan, tnspan);
+    if (quads)
+      hipLaunchKernelGGL((awfl_xtr4_kernel<STAGE, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         ngroups, tspan, tnspan);
+    else
+      hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         npairs, tspan, tnspan);
     HIP_TRY(hipGetLastError());
   }
   if (npairs > 0) {   // phase 2: their complete update, one wavefront per (line, member block, span, pair)
     ScopedTimer st(h, "xtr2", s);
-    hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
-                       prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
-                       npairs, tspan, tnspan);
+    if (quads)
+      hipLaunchKernelGGL((awfl_xtr4_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         ngroups, tspan, tnspan);
+    else
+      hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         npairs, tspan, tnspan);
     HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;
@@ -1434,9 +1476,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // the tile kernels stage their tiles in LDS: up to 14 doubles per lane of a 1024-lane workgroup
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2016,6 +2058,14 @@ int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_unit
   if (two_phase_below >= 0) h->two_phase_below = two_phase_below;
   if (split_below >= 0) h->split_below = split_below;
   return build_chunks(h);      // (the automatic range count looks at the spans; drains the handle's streams and drops captured graphs)
+}
+
+int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (tracers_per_wavefront != 2 && tracers_per_wavefront != 4) return fail(PAM_AMD_EINVAL, "set_tracer_grouping: 2 or 4 tracers per wavefront");
+  drop_graphs(h);
+  h->tracers_per_wave = tracers_per_wavefront;
+  return PAM_AMD_OK;
 }
 
 int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_tiles, int *flat_cells, int geom[6]) {

@@ -260,6 +260,10 @@ class Dycore:
     def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
         check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
 
+    def set_tracer_grouping(self, tracers_per_wavefront=2):
+        """separately launched x sweeps of the further tracers: 2 or 4 tracers per wavefront (experiment knob; same bits)"""
+        check(self._lib.pam_amd_awfl_set_tracer_grouping(self._h, int(tracers_per_wavefront)))
+
     def set_x_exchange(self, mode="auto"):
         """x tile kernels: neighbouring cells exchange values through "lds" (+ workgroup barriers) or by wavefront "shuffle"s (a whole
         line inside one wavefront) | "auto" (shuffles wherever possible); same bits"""

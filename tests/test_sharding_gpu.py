@@ -157,3 +157,27 @@ def test_a_handle_created_beside_eight_idle_streams_gives_the_two_range_result_b
     del streams
     for c, d in ((ref_c, ref_d), (busy_c, busy_d), (one_c, one_d)):
         d.finalize(c)
+
+
+@pytest.mark.parametrize("trname", ["p3_shoc", "kessler_shoc", "three", "six"])
+def test_four_tracers_per_wavefront_equal_pairs_bit_for_bit(trname):
+    """pam_amd_awfl_set_tracer_grouping (VERDICT r3 / r4 experiment (a)): the separately launched x sweeps of the further tracers with up to
+    FOUR tracers per wavefront (groups of 4 + a remainder of 1, 2 or 3) against pairs: same arithmetic per tracer, same bits.  9, 3, 2 and
+    5 further tracers: remainders 1, 3, 2 and 1."""
+    import torch
+    tr = {"p3_shoc": idz.TRACERS_P3_SHOC, "kessler_shoc": idz.TRACERS_KESSLER_SHOC,
+          "three": (("cloud", True, True), ("water_vapor", True, True), ("rain", True, False)),
+          "six": tuple([("t%d" % i, True, i % 2 == 0) for i in range(5)] + [("water_vapor", True, True)])}[trname]
+    a_c, a_d = _mk_large(128, tr)
+    b_c, b_d = _mk_large(128, tr)
+    for d in (a_d, b_d):
+        d.set_launch_tuning(0, -1, 1 << 30)          # phase 1 of the tracer sweeps as a launch of its own
+    b_d.set_tracer_grouping(4)
+    for _ in range(2):
+        assert a_d.timeStep(a_c) == b_d.timeStep(b_c)
+    torch.cuda.synchronize()
+    a, b = a_c.dump_fields(), b_c.dump_fields()
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
+    for c, d in ((a_c, a_d), (b_c, b_d)):
+        d.finalize(c)
