@@ -210,10 +210,16 @@ int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_bel
  * defaults a handle created AFTERWARDS starts from, so that in the one-process / N-handle host path (examples/driver.cpp --gpus N)
  * tuning one handle never re-shapes the launches of another.  Drains the handle's streams and rebuilds its member ranges. */
 int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_units, long long two_phase_below, long long split_below);
-/* Separately launched x sweeps of the further tracers (awfl_xtr_kernel): 2 (default) or 4 tracers per wavefront.  Four halve the
- * wavefronts and share the loads a pair shares (face mass flux, three densities) among four tracers, at twice the registers; measured
- * slower or equal on MI355X -- an experiment knob.  Same bits (ABI 4). */
-int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront);
+/* Separately launched x sweeps of the further tracers (awfl_xtr_kernel) -- two experiment knobs, measured in DESIGN.md section 6, same bits
+ * (ABI 4): tracers_per_wavefront 2 (default) or 4 -- four halve the wavefronts and share the loads a pair shares (face mass flux, three
+ * densities) among four tracers, at twice the registers; prefetch 1 -- phase 2 requests the loads of the next trip one trip ahead (pairs
+ * only; one more set of loaded values in registers). */
+int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront, int prefetch);
+/* Switches of measured experiments that stayed OFF (DESIGN.md section 6 gives each A/B); same bits either way (ABI 4):
+ *   "ftile_ahead"    the y/z flux TILE kernel (small ensembles) requests the 5-point stencils of the next group of quantities before it
+ *                    builds the polynomials of the current one (a 512-lane instance with 143 instead of 113 registers);
+ *   "tile_pow_lds"   the x tile kernel with the pressure pass inside stages the tables of its pow in LDS (as awfl_ptail_kernel does). */
+int pam_amd_awfl_set_experiment(pam_amd_awfl_t *h, const char *name, int value);
 /* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels (0 sweeps, 1 tiles with
  * LDS exchange, 2 tiles with wavefront shuffles), pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile

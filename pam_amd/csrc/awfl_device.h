@@ -1528,7 +1528,7 @@ PAMA_D void finish_tracer_cell(const Params &P, int t, double *prim_out, double 
 //                            is the periodic face nx == face 0), handed over in a register when this sweep runs inline after the state
 //                            pass of the same wavefront -- another wavefront of the SAME launch may still be writing it to flux_x.  In
 //                            a launch of its own (awfl_xtr_kernel) it is read from flux_x like the others.
-template <int NF, int STAGE, int PHASE>
+template <int NF, int STAGE, int PHASE, bool AHEAD = false>
 PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                            double *__restrict__ prim_out, const double *__restrict__ fx, const double *__restrict__ fy,
                            const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
@@ -1590,42 +1590,64 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
       w[n][4] = uni(q[n] + on)[eu];
     }
   }
-#pragma clang loop unroll(disable)
-  for (int c = c0; c <= c1; c++) {                       // window = cells c-2..c+2; face c1 closes the last cell
+  // everything one trip loads: the cell that enters the windows (c + 3), the face mass flux of face c, and what the cell this trip
+  // completes (cc = c - 1) needs besides its x fluxes -- loaded on EVERY trip, also the first one, which completes no cell (see
+  // flux_x_update_body: s_waitcnt counts are a static minimum over all paths)
+  struct Trip {
+    double nq[NF], ruf, rho_in, rho_0, rho_new;
+    double yl[NF], yh[NF], zl[NF], zh[NF], sd[NF], q_0[NF], m_new[NF], m_jm1[NF], m_jp1[NF], m_km1[NF], m_kp1[NF];
+  };
+  auto load_trip = [&](int c, Trip &T) {
     const long long on = cell_off(c + 3);
-    double nq[NF], L[NF], R[NF];
 #pragma unroll
-    for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
-    double ruf = uni(ruf_line + (long long)(c == nx ? 0 : c) * P.sx)[eu];
-    if (have_close && c == c1) ruf = ruf_close;
-    // everything the cell this trip completes needs besides its x fluxes; loaded on EVERY trip, also the first one, which
-    // completes no cell (see flux_x_update_body: s_waitcnt counts are a static minimum over all paths)
+    for (int n = 0; n < NF; n++) T.nq[n] = uni(q[n] + on)[eu];
+    T.ruf = uni(ruf_line + (long long)(c == nx ? 0 : c) * P.sx)[eu];
     const int cc = c > c0 ? c - 1 : c0;
     const long long o = pbase + (long long)cc * P.sx, ix = fbase + (long long)cc * P.sx;
-    double rho_in = 0.0, rho_0 = 0.0, rho_new = 1.0;
+    T.rho_in = 0.0; T.rho_0 = 0.0; T.rho_new = 1.0;
     if (PHASE == 2) {
-      rho_in = uni(pr + o)[eu];
-      rho_0 = (STAGE > 1) ? uni(r0 + o)[eu] : 0.0;
-      rho_new = uni(rn + o)[eu];
+      T.rho_in = uni(pr + o)[eu];
+      T.rho_0 = (STAGE > 1) ? uni(r0 + o)[eu] : 0.0;
+      T.rho_new = uni(rn + o)[eu];
     }
-    double yl[NF], yh[NF], zl[NF], zh[NF], sd[NF], q_0[NF];
-    double m_new[NF], m_jm1[NF], m_jp1[NF], m_km1[NF], m_kp1[NF];
 #pragma unroll
     for (int n = 0; n < NF; n++) {
-      yl[n] = have_y ? uni(fyt[n] + ix)[eu] : 0.0;
-      yh[n] = have_y ? uni(fyt[n] + ix + jp1)[eu] : 0.0;
-      zl[n] = uni(fzt[n] + ix)[eu];
-      zh[n] = uni(fzt[n] + ix + P.sz)[eu];
-      sd[n] = (PHASE == 1) ? uni(seed + (long long)tt[n] * P.ncell + ix)[eu] : 0.0;
-      q_0[n] = (PHASE == 2 && STAGE > 1) ? uni(q0p[n] + o)[eu] : 0.0;
-      m_jm1[n] = m_jp1[n] = m_km1[n] = m_kp1[n] = m_new[n] = 1.0;
+      T.yl[n] = have_y ? uni(fyt[n] + ix)[eu] : 0.0;
+      T.yh[n] = have_y ? uni(fyt[n] + ix + jp1)[eu] : 0.0;
+      T.zl[n] = uni(fzt[n] + ix)[eu];
+      T.zh[n] = uni(fzt[n] + ix + P.sz)[eu];
+      T.sd[n] = (PHASE == 1) ? uni(seed + (long long)tt[n] * P.ncell + ix)[eu] : 0.0;
+      T.q_0[n] = (PHASE == 2 && STAGE > 1) ? uni(q0p[n] + o)[eu] : 0.0;
+      T.m_jm1[n] = T.m_jp1[n] = T.m_km1[n] = T.m_kp1[n] = T.m_new[n] = 1.0;
       if (PHASE == 2) {
-        m_new[n] = uni(mline[n] + (long long)(c == nx ? 0 : c) * P.sx)[eu];                       // cell c: the x neighbour of cell cc
-        if (have_y) { m_jm1[n] = uni(mline[n] + (long long)cc * P.sx + jm1)[eu]; m_jp1[n] = uni(mline[n] + (long long)cc * P.sx + jp1)[eu]; }
-        if (zlo) m_km1[n] = uni(mline[n] + (long long)cc * P.sx - P.sz)[eu];
-        if (zhi) m_kp1[n] = uni(mline[n] + (long long)cc * P.sx + P.sz)[eu];
+        T.m_new[n] = uni(mline[n] + (long long)(c == nx ? 0 : c) * P.sx)[eu];                       // cell c: the x neighbour of cell cc
+        if (have_y) { T.m_jm1[n] = uni(mline[n] + (long long)cc * P.sx + jm1)[eu]; T.m_jp1[n] = uni(mline[n] + (long long)cc * P.sx + jp1)[eu]; }
+        if (zlo) T.m_km1[n] = uni(mline[n] + (long long)cc * P.sx - P.sz)[eu];
+        if (zhi) T.m_kp1[n] = uni(mline[n] + (long long)cc * P.sx + P.sz)[eu];
       }
     }
+  };
+  // AHEAD (experiment (b) of VERDICT r3 / r4): trip c + 1's loads are requested before trip c's polynomials are built -- one more
+  // trip of latency hidden per wavefront, one more set of loaded values (2 + 6 NF doubles in 2-D) in registers
+  Trip Tn;
+  if (AHEAD) load_trip(c0, Tn);
+#pragma clang loop unroll(disable)
+  for (int c = c0; c <= c1; c++) {                       // window = cells c-2..c+2; face c1 closes the last cell
+    Trip T;
+    if (AHEAD) {
+      T = Tn;
+      if (c < c1) load_trip(c + 1, Tn);
+    } else {
+      load_trip(c, T);
+    }
+    double L[NF], R[NF];
+    double ruf = T.ruf;
+    if (have_close && c == c1) ruf = ruf_close;
+    const int cc = c > c0 ? c - 1 : c0;
+    const long long ix = fbase + (long long)cc * P.sx;
+    const double rho_in = T.rho_in, rho_0 = T.rho_0, rho_new = T.rho_new;
+    const double (&nq)[NF] = T.nq, (&yl)[NF] = T.yl, (&yh)[NF] = T.yh, (&zl)[NF] = T.zl, (&zh)[NF] = T.zh, (&sd)[NF] = T.sd, (&q_0)[NF] = T.q_0;
+    const double (&m_new)[NF] = T.m_new, (&m_jm1)[NF] = T.m_jm1, (&m_jp1)[NF] = T.m_jp1, (&m_km1)[NF] = T.m_km1, (&m_kp1)[NF] = T.m_kp1;
 #pragma unroll
     for (int n = 0; n < NF; n++) weno5_const(w[n], wc, L[n], R[n]);
     const bool up = ruf > 0.0;                              // upwind (Dycore.h:368)

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
 // x sweeps of tracers 1.. (x_tracer_sweep): wave unit u -> (x line, member block, span, pair of tracers).  PHASE 1 (the cells' FCT
 // multipliers; only for small ensembles -- otherwise it runs inline in awfl_xupd_kernel) and PHASE 2 (the cells' complete update)
 // both follow awfl_xupd_kernel (they need the face mass flux; phase 2 also the new density and every line's multipliers).
-template <int STAGE, int PHASE>
+template <int STAGE, int PHASE, bool AHEAD = false>
 __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
                                                                const double *__restrict__ prim0, double *__restrict__ prim_out,
                                                                const double *__restrict__ fx, const double *__restrict__ fy,
@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
     // advected-field indices of the pair's tracers (water vapour rides with the state pass)
     const int fa[2] = {4 + further_tracer(P, 2 * pair), 4 + further_tracer(P, 2 * pair + 1)};
     if (2 * pair + 1 < P.nt - 1)
-      x_tracer_sweep<2, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+      x_tracer_sweep<2, STAGE, PHASE, AHEAD>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
     else
-      x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
+      x_tracer_sweep<1, STAGE, PHASE, AHEAD>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
 // The same sweeps with up to FOUR further tracers per wavefront (pam_amd_awfl_set_tracer_grouping; VERDICT r3 / r4 experiment (a)): half the
@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   // a pow is two dependent per-lane table look-ups, and the lanes of a boundary level chain nine of them (the density / pressure
   // ghosts, Dycore.h:682-709): those wavefronts are the last to finish
   __shared__ PowTab sh_tab;
-  if (with_pressure) {
+  const bool pow_lds = with_pressure == 2;
+  if (pow_lds) {
     const double *src = reinterpret_cast<const double *>(P.pw);
     double *dst = reinterpret_cast<double *>(&sh_tab);
     for (int i = tid; i < (int)(sizeof(PowTab) / sizeof(double)); i += T) dst[i] = src[i];
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   xtile_state_fields(P, fields);
   if (SHUF) {
     xtile_load_own<XT_NS>(P, prim_in, X, fields, own);
-    if (with_pressure) {        // (the one barrier of the shuffle form: the table is complete; reached long before it is needed)
+    if (pow_lds) {              // (the one barrier of the shuffle form: the table is complete; reached long before it is needed)
       __syncthreads();
       P.pw = &sh_tab;
     }
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
     double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
     xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
     __syncthreads();
-    if (with_pressure) P.pw = &sh_tab;
+    if (pow_lds) P.pw = &sh_tab;
     if (X.poly) {
       xtile_state_polys(P, X, st, TS, own, L, R, cen);
 #pragma unroll
@@ -781,6 +782,9 @@ struct pam_amd_awfl {
   size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
   long long want_units = 3072, two_phase_below = 8192, split_below = 8192;   // launch-shape thresholds (pam_amd_awfl_set_handle_launch_tuning)
   int tracers_per_wave = 2;    // further tracers swept by one wavefront of the separately launched x tracer sweeps: 2 (default) or 4
+  bool tracer_prefetch = false;   // phase 2 of those sweeps requests the next trip's loads one trip ahead (pairs only; experiment)
+  bool ftile_ahead = false;    // flux tile kernel: the 512-lane instance that requests the next group's stencils one group ahead (experiment)
+  bool tile_pow_lds = false;   // x tile kernel with the pressure inside: pow tables staged in LDS (experiment)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
@@ -918,7 +922,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     ScopedTimer st(h, "flux", s);
 #define PAMA_LAUNCH_FTILE(VZ, MT) \
   hipLaunchKernelGGL((awfl_flux_tile_kernel<VZ, MT>), dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z)
-    if (T <= 512) { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 512); else PAMA_LAUNCH_FTILE(false, 512); }
+    if (T <= 512 && h->ftile_ahead) { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 512); else PAMA_LAUNCH_FTILE(false, 512); }
     else { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 1024); else PAMA_LAUNCH_FTILE(false, 1024); }
 #undef PAMA_LAUNCH_FTILE
     HIP_TRY(hipGetLastError());
@@ -1046,11 +1050,11 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       if (shuf)
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), grid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? (h->tile_pow_lds ? 2 : 1) : 0, h->tile_pressure ? 1 : 0);
       else
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), grid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? (h->tile_pow_lds ? 2 : 1) : 0, h->tile_pressure ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
@@ -1128,6 +1132,10 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       hipLaunchKernelGGL((awfl_xtr4_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
                          prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
                          ngroups, tspan, tnspan);
+    else if (h->tracer_prefetch)      // (experiment (b): phase 2 with the next trip's loads requested one trip ahead)
+      hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 2, true>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         npairs, tspan, tnspan);
     else
       hipLaunchKernelGGL((awfl_xtr_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
                          prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
@@ -2060,11 +2068,23 @@ int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_unit
   return build_chunks(h);      // (the automatic range count looks at the spans; drains the handle's streams and drops captured graphs)
 }
 
-int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront) {
+int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront, int prefetch) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (tracers_per_wavefront != 2 && tracers_per_wavefront != 4) return fail(PAM_AMD_EINVAL, "set_tracer_grouping: 2 or 4 tracers per wavefront");
+  if (prefetch && tracers_per_wavefront != 2) return fail(PAM_AMD_EINVAL, "set_tracer_grouping: the one-trip-ahead form exists for pairs only");
   drop_graphs(h);
   h->tracers_per_wave = tracers_per_wavefront;
+  h->tracer_prefetch = prefetch != 0;
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_experiment(pam_amd_awfl_t *h, const char *name, int value) {
+  if (!h || !name) return fail(PAM_AMD_EINVAL, "set_experiment: null argument");
+  const std::string k(name);
+  drop_graphs(h);
+  if (k == "ftile_ahead") h->ftile_ahead = value != 0;
+  else if (k == "tile_pow_lds") h->tile_pow_lds = value != 0;
+  else return fail(PAM_AMD_EINVAL, "set_experiment: unknown switch " + k);
   return PAM_AMD_OK;
 }
 

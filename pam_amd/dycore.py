@@ -260,9 +260,14 @@ class Dycore:
     def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
         check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
 
-    def set_tracer_grouping(self, tracers_per_wavefront=2):
-        """separately launched x sweeps of the further tracers: 2 or 4 tracers per wavefront (experiment knob; same bits)"""
-        check(self._lib.pam_amd_awfl_set_tracer_grouping(self._h, int(tracers_per_wavefront)))
+    def set_experiment(self, name, value):
+        """switches of measured experiments that stayed off (include/pam_amd_awfl.h); same bits"""
+        check(self._lib.pam_amd_awfl_set_experiment(self._h, name.encode(), int(value)))
+
+    def set_tracer_grouping(self, tracers_per_wavefront=2, prefetch=False):
+        """separately launched x sweeps of the further tracers: 2 or 4 tracers per wavefront; phase 2 with the next trip's loads requested
+        one trip ahead (experiment knobs; same bits)"""
+        check(self._lib.pam_amd_awfl_set_tracer_grouping(self._h, int(tracers_per_wavefront), int(bool(prefetch))))
 
     def set_x_exchange(self, mode="auto"):
         """x tile kernels: neighbouring cells exchange values through "lds" (+ workgroup barriers) or by wavefront "shuffle"s (a whole

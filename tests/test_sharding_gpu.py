@@ -170,14 +170,16 @@ def test_four_tracers_per_wavefront_equal_pairs_bit_for_bit(trname):
           "six": tuple([("t%d" % i, True, i % 2 == 0) for i in range(5)] + [("water_vapor", True, True)])}[trname]
     a_c, a_d = _mk_large(128, tr)
     b_c, b_d = _mk_large(128, tr)
-    for d in (a_d, b_d):
+    p_c, p_d = _mk_large(128, tr)
+    for d in (a_d, b_d, p_d):
         d.set_launch_tuning(0, -1, 1 << 30)          # phase 1 of the tracer sweeps as a launch of its own
     b_d.set_tracer_grouping(4)
+    p_d.set_tracer_grouping(2, prefetch=True)        # experiment (b): phase 2 with the next trip's loads one trip ahead
     for _ in range(2):
-        assert a_d.timeStep(a_c) == b_d.timeStep(b_c)
+        assert a_d.timeStep(a_c) == b_d.timeStep(b_c) == p_d.timeStep(p_c)
     torch.cuda.synchronize()
-    a, b = a_c.dump_fields(), b_c.dump_fields()
+    a, b, pf = a_c.dump_fields(), b_c.dump_fields(), p_c.dump_fields()
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
-        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
-    for c, d in ((a_c, a_d), (b_c, b_d)):
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]) and np.array_equal(a[k], pf[k]), k
+    for c, d in ((a_c, a_d), (b_c, b_d), (p_c, p_d)):
         d.finalize(c)
