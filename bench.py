@@ -340,7 +340,7 @@ class Job:
         for e in args.exp:
             k, _, v = e.partition("=")
             dycore.set_experiment(k, int(v or 1))
-        if args.trgroup != 2 or args.trprefetch:
+        if args.trgroup != 0 or args.trprefetch:
             dycore.set_tracer_grouping(args.trgroup, args.trprefetch)
         self.lane_mapping = dycore.get_lane_mapping()
         self.chunks = args.chunks
@@ -932,7 +932,7 @@ def main():
                     help="x direction: a wavefront per line span / a lane per cell with LDS exchange (auto: tile when nens < 64)")
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
     ap.add_argument("--exp", action="append", default=[], help="name=value: pam_amd_awfl_set_experiment switch (repeatable)")
-    ap.add_argument("--trgroup", type=int, default=2, choices=(2, 4), help="further tracers per wavefront of the separate x tracer sweeps")
+    ap.add_argument("--trgroup", type=int, default=0, choices=(0, 1, 2, 4), help="further tracers per wavefront of the separate x tracer sweeps (0 = automatic)")
     ap.add_argument("--trprefetch", type=int, default=0, choices=(0, 1), help="phase 2 of those sweeps: next trip's loads one trip ahead")
     ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),
                     help="x tile kernels: neighbouring cells exchange through LDS + barriers / by wavefront shuffles (a line inside one wavefront)")

@@ -210,10 +210,14 @@ int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_bel
  * defaults a handle created AFTERWARDS starts from, so that in the one-process / N-handle host path (examples/driver.cpp --gpus N)
  * tuning one handle never re-shapes the launches of another.  Drains the handle's streams and rebuilds its member ranges. */
 int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_units, long long two_phase_below, long long split_below);
-/* Separately launched x sweeps of the further tracers (awfl_xtr_kernel) -- two experiment knobs, measured in DESIGN.md section 6, same bits
- * (ABI 4): tracers_per_wavefront 2 (default) or 4 -- four halve the wavefronts and share the loads a pair shares (face mass flux, three
- * densities) among four tracers, at twice the registers; prefetch 1 -- phase 2 requests the loads of the next trip one trip ahead (pairs
- * only; one more set of loaded values in registers). */
+/* Separately launched x sweeps of the further tracers (awfl_xtr_kernel / awfl_xtrn_kernel); same bits whatever is chosen (ABI 4).
+ *   tracers_per_wavefront   0 = automatic (measured, DESIGN.md section 6: phase 1 one tracer per wavefront -- 83 registers, five
+ *                           wavefronts per SIMD; phase 2 pairs -- the densities and the face mass flux are loaded once per pair -- except
+ *                           for three further tracers, where three equal wavefronts beat one double and one single); 1, 2, 4 force a
+ *                           grouping in both phases (four: half the wavefronts at twice the registers; slower everywhere measured);
+ *   prefetch                1: phase 2 requests the loads of the next trip one trip ahead (pairs only: tracers_per_wavefront = 2; one
+ *                           more set of loaded values in registers, 2 instead of 3 wavefronts per SIMD; slower, kept as a measured
+ *                           experiment). */
 int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront, int prefetch);
 /* Switches of measured experiments that stayed OFF (DESIGN.md section 6 gives each A/B); same bits either way (ABI 4):
  *   "ftile_ahead"    the y/z flux TILE kernel (small ensembles) requests the 5-point stencils of the next group of quantities before it

@@ -690,9 +690,14 @@ PAMA_D LineLane flat_lane(const Params &P, unsigned q) {
   return ll;
 }
 
-template <int DIR, bool VZ_PER_ENS, bool DIFF>
+//   PART / NFW (compile-time forms of pair_sel for the launches that run ONE part: the kernel then holds only that part's code and
+//   registers): PART -1 = whatever pair_sel says; 0 = pass 1 only; 1 = only the group pair_sel >= 1 of advected fields, NFW fields per
+//   group (2: pairs, the grouping of the whole-sweep form; 1: one field per wavefront)
+template <int DIR, bool VZ_PER_ENS, bool DIFF, int PART = -1, int NFW = 2>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
                            int f0, int span, int pair_sel = -1) {
+  static_assert(NFW == 1 || NFW == 2, "one or two advected fields per sweep");
+  static_assert(PART == 1 || NFW == 2, "the whole-sweep form groups the advected fields in pairs");
   const unsigned eu = ll.eu;
   const int e = ll.et;
   const LineGeom g = line_geom(P, DIR);
@@ -728,7 +733,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   // pair_sel: -1 = the whole sweep in this wavefront; 0 = pass 1 only; p >= 1 = only the p-th pair of advected fields (small
   // ensembles: the passes of a sweep are spread over wavefronts, pass 1 in a launch of its own before the pairs)
   // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
-  if (pair_sel <= 0) {
+  if (PART != 1 && pair_sel <= 0) {
     const double *pr = prim + (long long)P_RHO * P.prim_fs;
     const double *pn = prim + (long long)ncomp * P.prim_fs;
     const double *pp = prim + (long long)P_PRES * P.prim_fs;
@@ -867,22 +872,22 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int n = 0; n < nf; n++) ns += (fa[n] < 4) ? 1 : 0;
     using std::integral_constant;
     if (nf == 1) { if (ns == 1) sweep(integral_constant<int, 1>{}, integral_constant<int, 1>{}, fa); else sweep(integral_constant<int, 1>{}, integral_constant<int, 0>{}, fa); }
-    else if (nf == 2) {
+    else if (NFW == 2 && nf == 2) {
       if (ns == 2) sweep(integral_constant<int, 2>{}, integral_constant<int, 2>{}, fa);
       else if (ns == 1) sweep(integral_constant<int, 2>{}, integral_constant<int, 1>{}, fa);
       else sweep(integral_constant<int, 2>{}, integral_constant<int, 0>{}, fa);
     }
   };
   static_assert(FLUX_NF == 2, "the sweep dispatch is written for two fields per sweep");
-  if (pair_sel == 0) return;
+  if (PART == 0 || pair_sel == 0) return;
   int fa[FLUX_NF], nfa = 0, ipair = 0;
   for (int a = 0; a < nadv; a++) {
     if (P_U + a == ncomp) continue;
     if (skip_advected_v(P, DIFF) && a == 1) continue;
     fa[nfa++] = a;
-    if (nfa == FLUX_NF) {
+    if (nfa == NFW) {
       ipair++;
-      if (pair_sel < 0 || pair_sel == ipair) run(FLUX_NF, fa);
+      if (pair_sel < 0 || pair_sel == ipair) run(NFW, fa);
       nfa = 0;
     }
   }
@@ -893,10 +898,10 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 }
 
 // lanes = members of one line (the layout of large ensembles; also what the host emulation runs)
-template <int DIR, bool VZ_PER_ENS, bool DIFF>
+template <int DIR, bool VZ_PER_ENS, bool DIFF, int PART = -1, int NFW = 2>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
                            int f0, int span, int pair_sel = -1) {
-  flux_line_body<DIR, VZ_PER_ENS, DIFF>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
+  flux_line_body<DIR, VZ_PER_ENS, DIFF, PART, NFW>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
 }
 
 // ------------------------------------------------------------------------------------------------

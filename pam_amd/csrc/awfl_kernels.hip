@@ -149,6 +149,36 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
   }
 }
 
+// The two PARTS of a member-lane y/z sweep of the fused stage as kernels of their own (small launches: flux_line_body's PART / NFW):
+// PART 0 = pass 1 (three windows), PART 1 = the advected fields, NFW per wavefront -- each holds only its part's code and registers
+// (the whole-sweep kernel above allocates for pass 1 AND the pairs: 126-128), so a part launch runs with more wavefronts per SIMD.
+template <bool VZ_PER_ENS, int PART, int NFW>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_part_kernel(Params P, FluxGrid G, EnsRange R, const double *__restrict__ prim,
+                                                                     double *__restrict__ fy, double *__restrict__ fz) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nblk = (R.ne + 63) >> 6;
+  int b = (int)blockIdx.x - G.nbz;                // z-sweep workgroups first (as awfl_flux_kernel)
+  if (b < 0) b += G.nby + G.nbz;
+  if (b < G.nby) {
+    const int u = b * FLUX_WAVES + wave;
+    if (u < G.nuy) {
+      const int up = (PART == 1) ? uni_int(u / G.npy) : u, psel = (PART == 1) ? 1 + (u - up * G.npy) : 0;
+      const int grp = uni_int(up / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      if (el < R.ne)
+        flux_line_body<1, VZ_PER_ENS, true, PART, NFW>(P, prim, fy, line, R.e0 + el, (up - grp * G.nsy) * G.spy, G.spy, psel);
+    }
+  } else {
+    const int u = (b - G.nby) * FLUX_WAVES + wave;
+    if (u < G.nuz) {
+      const int up = (PART == 1) ? uni_int(u / G.npz) : u, psel = (PART == 1) ? 1 + (u - up * G.npz) : 0;
+      const int grp = uni_int(up / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
+      if (el < R.ne)
+        flux_line_body<2, VZ_PER_ENS, true, PART, NFW>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
@@ -212,30 +242,33 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
       x_tracer_sweep<1, STAGE, PHASE, AHEAD>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
-// The same sweeps with up to FOUR further tracers per wavefront (pam_amd_awfl_set_tracer_grouping; VERDICT r3 / r4 experiment (a)): half the
-// wavefronts, the per-wavefront loads shared by a pair (face mass flux, the three densities) shared by four tracers -- and twice the
-// windows in registers.  A kernel of its own so that the pair form keeps its register count.  Same arithmetic per tracer: same bits.
-template <int STAGE, int PHASE>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr4_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+// The same sweeps with G = 4 or G = 1 further tracers per wavefront (pam_amd_awfl_set_tracer_grouping; experiment (a) of VERDICT r3 / r4
+// and its opposite).  Four: half the wavefronts, the per-wavefront loads a pair shares (face mass flux, the three densities) shared by
+// four tracers -- and twice the windows in registers.  One: twice the wavefronts, each with half the registers (more wavefronts per
+// SIMD), the shared loads repeated per tracer.  Kernels of their own so that the pair form keeps its register count.  Same arithmetic
+// per tracer: same bits.
+template <int STAGE, int PHASE, int G>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtrn_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
                                                                 const double *__restrict__ prim0, double *__restrict__ prim_out,
                                                                 const double *__restrict__ fx, const double *__restrict__ fy,
                                                                 const double *__restrict__ fz, double *__restrict__ seed,
                                                                 double *__restrict__ mult, FctRows rows, double dt_dyn,
                                                                 double dt_stage, int ngroups, int span, int nspan) {
+  static_assert(G == 1 || G == 4, "groups of one or four tracers");
   fct_rows_resolve(rows);
   const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
-  const int g2 = uni_int(u / ngroups), grp4 = u - g2 * ngroups;
+  const int g2 = uni_int(u / ngroups), grpn = u - g2 * ngroups;
   const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
   const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne) {
-    const int first = 4 * grp4, left = P.nt - 1 - first;
+    const int first = G * grpn, left = P.nt - 1 - first;
     const int fa[4] = {4 + further_tracer(P, first), 4 + further_tracer(P, first + 1), 4 + further_tracer(P, first + 2), 4 + further_tracer(P, first + 3)};
-    if (left >= 4)
+    if (G == 4 && left >= 4)
       x_tracer_sweep<4, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
-    else if (left == 3)
+    else if (G == 4 && left == 3)
       x_tracer_sweep<3, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
-    else if (left == 2)
+    else if (G == 4 && left == 2)
       x_tracer_sweep<2, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
     else
       x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
@@ -781,8 +814,10 @@ struct pam_amd_awfl {
   bool fused_supported = false;
   size_t flux_lds_floor = 0;   // tuning: dynamic LDS requested per flux workgroup (the kernel uses none: a residency cap per CU)
   long long want_units = 3072, two_phase_below = 8192, split_below = 8192;   // launch-shape thresholds (pam_amd_awfl_set_handle_launch_tuning)
-  int tracers_per_wave = 2;    // further tracers swept by one wavefront of the separately launched x tracer sweeps: 2 (default) or 4
+  int tracers_per_wave = 0;    // further tracers swept by one wavefront of the separately launched x tracer sweeps: 0 automatic, 1, 2, 4
   bool tracer_prefetch = false;   // phase 2 of those sweeps requests the next trip's loads one trip ahead (pairs only; experiment)
+  int flux_part_mode = 0;      // two-phase member-lane y/z sweeps: 0 = part kernels (each part with its own registers), 1 = the whole-sweep kernel
+  int flux_part_fields = 2;    // ... advected fields per wavefront of part 1: 2 (pairs) or 1
   bool ftile_ahead = false;    // flux tile kernel: the 512-lane instance that requests the next group's stencils one group ahead (experiment)
   bool tile_pow_lds = false;   // x tile kernel with the pressure inside: pow tables staged in LDS (experiment)
   std::vector<Chunk> chunks;
@@ -944,8 +979,13 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // Small ensembles: a wavefront that sweeps its span for pass 1 and then for every pair of advected fields, one after the
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
-  const int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
+  int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
   const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < h->two_phase_below;
+  // two-phase member-lane sweeps of the fused stage run as PART kernels (awfl_flux_part_kernel: each part with its own register
+  // count); flux_part_fields: advected fields per wavefront of part 1 (2 = pairs, 1 = one field per wavefront)
+  const bool part_kernels = two_phase && diff && !flat && h->flux_part_mode != 1;
+  const int nfw = (part_kernels && h->flux_part_fields == 1) ? 1 : 2;
+  if (nfw == 1) npairs = 3 + P.nt - (skip_advected_v(P, diff) ? 1 : 0);       // groups of ONE advected field
   const int nphase = two_phase ? 2 : 1;
   if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
     return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
@@ -969,10 +1009,18 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
 #define PAMA_LAUNCH_FLUX(VZ, DF, FL)                                                                                    \
   hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF, FL>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
+#define PAMA_LAUNCH_PART(VZ, PT, NW)                                                                                    \
+  hipLaunchKernelGGL((awfl_flux_part_kernel<VZ, PT, NW>), grid, block, 0, s, P, G, r, prim, h->flux_y, h->flux_z)
+  if (part_kernels) {
+    if (phase == 0) { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 0, 2); else PAMA_LAUNCH_PART(false, 0, 2); }
+    else if (nfw == 1) { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 1, 1); else PAMA_LAUNCH_PART(false, 1, 1); }
+    else { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 1, 2); else PAMA_LAUNCH_PART(false, 1, 2); }
+  } else
   if (flat) { if (P.vz_per_ens) PAMA_LAUNCH_FLUX(true, true, true); else PAMA_LAUNCH_FLUX(false, true, true); }
   else if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true, false); else PAMA_LAUNCH_FLUX(true, false, false); }
   else { if (diff) PAMA_LAUNCH_FLUX(false, true, false); else PAMA_LAUNCH_FLUX(false, false, false); }
 #undef PAMA_LAUNCH_FLUX
+#undef PAMA_LAUNCH_PART
   HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;
@@ -1109,15 +1157,36 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     HIP_TRY(hipGetLastError());
   }
   // the tracer launches have npairs wavefronts per (line, member block, span): their lines are cut less (or not at all)
-  const bool quads = h->tracers_per_wave == 4;
-  const int ngroups = quads ? (P.nt - 1 + 3) / 4 : npairs;        // wavefronts per (line, member block, span): pairs or groups of four
+  // Further tracers per wavefront of these launches (0 = automatic; measured on MI355X, round 5, profiles/r05_ab_experiments.txt):
+  //   phase 1 -- ONE: 83 instead of 119 registers (5 instead of 4 wavefronts per SIMD), and only the face mass flux is loaded twice:
+  //              C4 shard 0.091 -> 0.083 ms, C3 0.206 -> 0.196, C4 whole 0.552 -> 0.530;
+  //   phase 2 -- PAIRS (the three densities and the mass flux are shared: singles move 23 % more bytes through a kernel that runs at
+  //              5.2 TB/s: C4 shard 0.123 -> 0.142 ms), except for three further tracers, where pairs are one double and one single
+  //              wavefront per line and singles three equal ones (C3: 0.316 -> 0.300 ms);
+  //   four per wavefront lose everywhere (2 wavefronts per SIMD: C4 shard 0.82 -> 0.75 G although 12 % fewer bytes move).
+  const int nfur = P.nt - 1;
+  const int per1 = h->tracers_per_wave ? h->tracers_per_wave : 1;
+  const int per2 = h->tracers_per_wave ? h->tracers_per_wave : (nfur == 3 ? 1 : 2);
   int tspan = span, tnspan = nspan;
-  if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * ngroups, P.nens, P.seg, h->span_override, tspan, tnspan);
-  const long long tunits = nlb * tnspan * ngroups;
+  long long tunits = 0;
+  int ngroups = npairs;
+  bool quads = false, singles = false;
+  auto shape = [&](int per) {        // the launch shape of one phase
+    quads = per == 4; singles = per == 1;
+    ngroups = quads ? (nfur + 3) / 4 : (singles ? nfur : npairs);     // wavefronts per (line, member block, span)
+    tspan = span; tnspan = nspan;
+    if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * ngroups, P.nens, P.seg, h->span_override, tspan, tnspan);
+    tunits = nlb * tnspan * ngroups;
+  };
   if (split) {     // phase 1 of the further tracers (their FCT multipliers) in a launch of its own
+    shape(per1);
     ScopedTimer st(h, "xtr1", s);
     if (quads)
-      hipLaunchKernelGGL((awfl_xtr4_kernel<STAGE, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+      hipLaunchKernelGGL((awfl_xtrn_kernel<STAGE, 1, 4>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         ngroups, tspan, tnspan);
+    else if (singles)
+      hipLaunchKernelGGL((awfl_xtrn_kernel<STAGE, 1, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
                          prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
                          ngroups, tspan, tnspan);
     else
@@ -1127,9 +1196,14 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     HIP_TRY(hipGetLastError());
   }
   if (npairs > 0) {   // phase 2: their complete update, one wavefront per (line, member block, span, pair)
+    shape(per2);
     ScopedTimer st(h, "xtr2", s);
     if (quads)
-      hipLaunchKernelGGL((awfl_xtr4_kernel<STAGE, 2>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+      hipLaunchKernelGGL((awfl_xtrn_kernel<STAGE, 2, 4>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
+                         prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
+                         ngroups, tspan, tnspan);
+    else if (singles)
+      hipLaunchKernelGGL((awfl_xtrn_kernel<STAGE, 2, 1>), dim3(nblocks(tunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r, prim_in,
                          prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn, dt_stage,
                          ngroups, tspan, tnspan);
     else if (h->tracer_prefetch)      // (experiment (b): phase 2 with the next trip's loads requested one trip ahead)
@@ -2070,7 +2144,8 @@ int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_unit
 
 int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront, int prefetch) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (tracers_per_wavefront != 2 && tracers_per_wavefront != 4) return fail(PAM_AMD_EINVAL, "set_tracer_grouping: 2 or 4 tracers per wavefront");
+  if (tracers_per_wavefront != 0 && tracers_per_wavefront != 1 && tracers_per_wavefront != 2 && tracers_per_wavefront != 4)
+    return fail(PAM_AMD_EINVAL, "set_tracer_grouping: 0 (automatic), 1, 2 or 4 tracers per wavefront");
   if (prefetch && tracers_per_wavefront != 2) return fail(PAM_AMD_EINVAL, "set_tracer_grouping: the one-trip-ahead form exists for pairs only");
   drop_graphs(h);
   h->tracers_per_wave = tracers_per_wavefront;
@@ -2084,6 +2159,8 @@ int pam_amd_awfl_set_experiment(pam_amd_awfl_t *h, const char *name, int value) 
   drop_graphs(h);
   if (k == "ftile_ahead") h->ftile_ahead = value != 0;
   else if (k == "tile_pow_lds") h->tile_pow_lds = value != 0;
+  else if (k == "flux_part_kernels") h->flux_part_mode = value ? 0 : 1;
+  else if (k == "flux_part_fields") { if (value != 1 && value != 2) return fail(PAM_AMD_EINVAL, "set_experiment: flux_part_fields is 1 or 2"); h->flux_part_fields = value; }
   else return fail(PAM_AMD_EINVAL, "set_experiment: unknown switch " + k);
   return PAM_AMD_OK;
 }

@@ -264,9 +264,9 @@ class Dycore:
         """switches of measured experiments that stayed off (include/pam_amd_awfl.h); same bits"""
         check(self._lib.pam_amd_awfl_set_experiment(self._h, name.encode(), int(value)))
 
-    def set_tracer_grouping(self, tracers_per_wavefront=2, prefetch=False):
-        """separately launched x sweeps of the further tracers: 2 or 4 tracers per wavefront; phase 2 with the next trip's loads requested
-        one trip ahead (experiment knobs; same bits)"""
+    def set_tracer_grouping(self, tracers_per_wavefront=0, prefetch=False):
+        """separately launched x sweeps of the further tracers: 0 (automatic), 1, 2 or 4 tracers per wavefront; phase 2 with the next
+        trip's loads requested one trip ahead (pairs only; experiment); same bits"""
         check(self._lib.pam_amd_awfl_set_tracer_grouping(self._h, int(tracers_per_wavefront), int(bool(prefetch))))
 
     def set_x_exchange(self, mode="auto"):

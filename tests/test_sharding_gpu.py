@@ -171,15 +171,18 @@ def test_four_tracers_per_wavefront_equal_pairs_bit_for_bit(trname):
     a_c, a_d = _mk_large(128, tr)
     b_c, b_d = _mk_large(128, tr)
     p_c, p_d = _mk_large(128, tr)
-    for d in (a_d, b_d, p_d):
+    s_c, s_d = _mk_large(128, tr)
+    for d in (a_d, b_d, p_d, s_d):
         d.set_launch_tuning(0, -1, 1 << 30)          # phase 1 of the tracer sweeps as a launch of its own
+    a_d.set_tracer_grouping(2)                       # pairs in both phases (the round-3 / round-4 form)
     b_d.set_tracer_grouping(4)
     p_d.set_tracer_grouping(2, prefetch=True)        # experiment (b): phase 2 with the next trip's loads one trip ahead
+    s_d.set_tracer_grouping(0)                       # automatic: phase 1 one tracer per wavefront, phase 2 pairs (three further tracers: singles)
     for _ in range(2):
-        assert a_d.timeStep(a_c) == b_d.timeStep(b_c) == p_d.timeStep(p_c)
+        assert a_d.timeStep(a_c) == b_d.timeStep(b_c) == p_d.timeStep(p_c) == s_d.timeStep(s_c)
     torch.cuda.synchronize()
-    a, b, pf = a_c.dump_fields(), b_c.dump_fields(), p_c.dump_fields()
+    a, b, pf, sg = a_c.dump_fields(), b_c.dump_fields(), p_c.dump_fields(), s_c.dump_fields()
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
-        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]) and np.array_equal(a[k], pf[k]), k
-    for c, d in ((a_c, a_d), (b_c, b_d), (p_c, p_d)):
+        assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]) and np.array_equal(a[k], pf[k]) and np.array_equal(a[k], sg[k]), k
+    for c, d in ((a_c, a_d), (b_c, b_d), (p_c, p_d), (s_c, s_d)):
         d.finalize(c)

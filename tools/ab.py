@@ -58,6 +58,7 @@ def main():
                                                                      ("%.4f" % st) if st else "-", ks))
     print("\n".join(lines))
     if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "a") as fh:
             fh.write("# common: %s\n" % a.common)
             fh.write("\n".join(lines) + "\n")
