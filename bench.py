@@ -337,11 +337,8 @@ class Job:
             dycore.set_x_tile(*[int(v) for v in args.xtile.split(",")])
         if args.xexchange != "auto":
             dycore.set_x_exchange(args.xexchange)
-        for e in args.exp:
-            k, _, v = e.partition("=")
-            dycore.set_experiment(k, int(v or 1))
         if args.trgroup != 0 or args.trprefetch:
-            dycore.set_tracer_grouping(args.trgroup, args.trprefetch)
+            dycore.set_tracer_grouping(2 if (args.trprefetch and not args.trgroup) else args.trgroup, args.trprefetch)
         self.lane_mapping = dycore.get_lane_mapping()
         self.chunks = args.chunks
         self.lds_floor = args.lds_floor
@@ -931,7 +928,6 @@ def main():
     ap.add_argument("--xkernels", default="auto", choices=("auto", "sweep", "tile"),
                     help="x direction: a wavefront per line span / a lane per cell with LDS exchange (auto: tile when nens < 64)")
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
-    ap.add_argument("--exp", action="append", default=[], help="name=value: pam_amd_awfl_set_experiment switch (repeatable)")
     ap.add_argument("--trgroup", type=int, default=0, choices=(0, 1, 2, 4), help="further tracers per wavefront of the separate x tracer sweeps (0 = automatic)")
     ap.add_argument("--trprefetch", type=int, default=0, choices=(0, 1), help="phase 2 of those sweeps: next trip's loads one trip ahead")
     ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),

@@ -219,11 +219,6 @@ int pam_amd_awfl_set_handle_launch_tuning(pam_amd_awfl_t *h, long long want_unit
  *                           more set of loaded values in registers, 2 instead of 3 wavefronts per SIMD; slower, kept as a measured
  *                           experiment). */
 int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefront, int prefetch);
-/* Switches of measured experiments that stayed OFF (DESIGN.md section 6 gives each A/B); same bits either way (ABI 4):
- *   "ftile_ahead"    the y/z flux TILE kernel (small ensembles) requests the 5-point stencils of the next group of quantities before it
- *                    builds the polynomials of the current one (a 512-lane instance with 143 instead of 113 registers);
- *   "tile_pow_lds"   the x tile kernel with the pressure pass inside stages the tables of its pow in LDS (as awfl_ptail_kernel does). */
-int pam_amd_awfl_set_experiment(pam_amd_awfl_t *h, const char *name, int value);
 /* the resolved mapping: y/z lanes (0 member, 1 flat-lane sweeps, 2 flat lanes + tile kernel), x tile kernels (0 sweeps, 1 tiles with
  * LDS exchange, 2 tiles with wavefront shuffles), pointwise kernels on a
  * grid flat over every cell (0/1 each) and the x tile

@@ -690,14 +690,9 @@ PAMA_D LineLane flat_lane(const Params &P, unsigned q) {
   return ll;
 }
 
-//   PART / NFW (compile-time forms of pair_sel for the launches that run ONE part: the kernel then holds only that part's code and
-//   registers): PART -1 = whatever pair_sel says; 0 = pass 1 only; 1 = only the group pair_sel >= 1 of advected fields, NFW fields per
-//   group (2: pairs, the grouping of the whole-sweep form; 1: one field per wavefront)
-template <int DIR, bool VZ_PER_ENS, bool DIFF, int PART = -1, int NFW = 2>
+template <int DIR, bool VZ_PER_ENS, bool DIFF>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
                            int f0, int span, int pair_sel = -1) {
-  static_assert(NFW == 1 || NFW == 2, "one or two advected fields per sweep");
-  static_assert(PART == 1 || NFW == 2, "the whole-sweep form groups the advected fields in pairs");
   const unsigned eu = ll.eu;
   const int e = ll.et;
   const LineGeom g = line_geom(P, DIR);
@@ -733,7 +728,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   // pair_sel: -1 = the whole sweep in this wavefront; 0 = pass 1 only; p >= 1 = only the p-th pair of advected fields (small
   // ensembles: the passes of a sweep are spread over wavefronts, pass 1 in a launch of its own before the pairs)
   // ---------------- pass 1: acoustic pair + normal momentum (Dycore.h:341-366, :368-385 for u_n) -------------
-  if (PART != 1 && pair_sel <= 0) {
+  if (pair_sel <= 0) {
     const double *pr = prim + (long long)P_RHO * P.prim_fs;
     const double *pn = prim + (long long)ncomp * P.prim_fs;
     const double *pp = prim + (long long)P_PRES * P.prim_fs;
@@ -872,22 +867,22 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int n = 0; n < nf; n++) ns += (fa[n] < 4) ? 1 : 0;
     using std::integral_constant;
     if (nf == 1) { if (ns == 1) sweep(integral_constant<int, 1>{}, integral_constant<int, 1>{}, fa); else sweep(integral_constant<int, 1>{}, integral_constant<int, 0>{}, fa); }
-    else if (NFW == 2 && nf == 2) {
+    else if (nf == 2) {
       if (ns == 2) sweep(integral_constant<int, 2>{}, integral_constant<int, 2>{}, fa);
       else if (ns == 1) sweep(integral_constant<int, 2>{}, integral_constant<int, 1>{}, fa);
       else sweep(integral_constant<int, 2>{}, integral_constant<int, 0>{}, fa);
     }
   };
   static_assert(FLUX_NF == 2, "the sweep dispatch is written for two fields per sweep");
-  if (PART == 0 || pair_sel == 0) return;
+  if (pair_sel == 0) return;
   int fa[FLUX_NF], nfa = 0, ipair = 0;
   for (int a = 0; a < nadv; a++) {
     if (P_U + a == ncomp) continue;
     if (skip_advected_v(P, DIFF) && a == 1) continue;
     fa[nfa++] = a;
-    if (nfa == NFW) {
+    if (nfa == FLUX_NF) {
       ipair++;
-      if (pair_sel < 0 || pair_sel == ipair) run(NFW, fa);
+      if (pair_sel < 0 || pair_sel == ipair) run(FLUX_NF, fa);
       nfa = 0;
     }
   }
@@ -898,10 +893,10 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 }
 
 // lanes = members of one line (the layout of large ensembles; also what the host emulation runs)
-template <int DIR, bool VZ_PER_ENS, bool DIFF, int PART = -1, int NFW = 2>
+template <int DIR, bool VZ_PER_ENS, bool DIFF>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
                            int f0, int span, int pair_sel = -1) {
-  flux_line_body<DIR, VZ_PER_ENS, DIFF, PART, NFW>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
+  flux_line_body<DIR, VZ_PER_ENS, DIFF>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2569,31 +2564,19 @@ PAMA_D void ftile_acoustic_face(const Params &P, double *__restrict__ flux, cons
   if (X.own) uniw(flux)[X.fo] = ruf;
 }
 // the advected quantities fa[0..nf) (advected-field indices: 0 u, 1 v, 2 w, 3 theta, 4.. tracers)
-//   ftile_adv_load: the 5-point stencils of a group (requested one group AHEAD by the device kernel: the next group's values travel
-//   while this group's polynomials are built -- a group is otherwise a full memory round trip behind a barrier)
-PAMA_D void ftile_adv_load(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf, double (&w)[FT_NG][5]) {
-#pragma unroll
-  for (int n = 0; n < FT_NG; n++) {
-    gc_ptr f = uni(prim + (long long)(P_U + ((n < nf) ? fa[n] : 0)) * P.prim_fs);
-#pragma unroll
-    for (int s = 0; s < 5; s++) w[n][s] = (n < nf && X.poly) ? f[X.o5[s]] : 0.0;
-  }
-}
 template <int DIR, bool VZ_PER_ENS>
-PAMA_D void ftile_adv_polys_from(const Params &P, const FLane &X, int nf, const double (&w)[FT_NG][5], double (&L)[FT_NG], double (&R)[FT_NG]) {
+PAMA_D void ftile_adv_polys(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf,
+                            double (&L)[FT_NG], double (&R)[FT_NG]) {
   const WenoConsts wc = weno_consts();
 #pragma unroll
   for (int n = 0; n < FT_NG; n++) {
     if (n >= nf) { L[n] = R[n] = 0.0; continue; }
-    ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, w[n], L[n], R[n]);
+    gc_ptr f = uni(prim + (long long)(P_U + fa[n]) * P.prim_fs);
+    double w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = f[X.o5[s]];
+    ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, w, L[n], R[n]);
   }
-}
-template <int DIR, bool VZ_PER_ENS>
-PAMA_D void ftile_adv_polys(const Params &P, const double *__restrict__ prim, const FLane &X, const int *fa, int nf,
-                            double (&L)[FT_NG], double (&R)[FT_NG]) {
-  double w[FT_NG][5];
-  ftile_adv_load(P, prim, X, fa, nf, w);
-  ftile_adv_polys_from<DIR, VZ_PER_ENS>(P, X, nf, w, L, R);
 }
 // their fluxes through the lane's lower face; tracers leave as faces at once, state variables wait for the difference
 template <int DIR>

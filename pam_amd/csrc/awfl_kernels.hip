@@ -149,36 +149,6 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
   }
 }
 
-// The two PARTS of a member-lane y/z sweep of the fused stage as kernels of their own (small launches: flux_line_body's PART / NFW):
-// PART 0 = pass 1 (three windows), PART 1 = the advected fields, NFW per wavefront -- each holds only its part's code and registers
-// (the whole-sweep kernel above allocates for pass 1 AND the pairs: 126-128), so a part launch runs with more wavefronts per SIMD.
-template <bool VZ_PER_ENS, int PART, int NFW>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_flux_part_kernel(Params P, FluxGrid G, EnsRange R, const double *__restrict__ prim,
-                                                                     double *__restrict__ fy, double *__restrict__ fz) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nblk = (R.ne + 63) >> 6;
-  int b = (int)blockIdx.x - G.nbz;                // z-sweep workgroups first (as awfl_flux_kernel)
-  if (b < 0) b += G.nby + G.nbz;
-  if (b < G.nby) {
-    const int u = b * FLUX_WAVES + wave;
-    if (u < G.nuy) {
-      const int up = (PART == 1) ? uni_int(u / G.npy) : u, psel = (PART == 1) ? 1 + (u - up * G.npy) : 0;
-      const int grp = uni_int(up / G.nsy), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne)
-        flux_line_body<1, VZ_PER_ENS, true, PART, NFW>(P, prim, fy, line, R.e0 + el, (up - grp * G.nsy) * G.spy, G.spy, psel);
-    }
-  } else {
-    const int u = (b - G.nby) * FLUX_WAVES + wave;
-    if (u < G.nuz) {
-      const int up = (PART == 1) ? uni_int(u / G.npz) : u, psel = (PART == 1) ? 1 + (u - up * G.npz) : 0;
-      const int grp = uni_int(up / G.nsz), line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
-      if (el < R.ne)
-        flux_line_body<2, VZ_PER_ENS, true, PART, NFW>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
                                                        const double *__restrict__ fy, const double *__restrict__ fz,
                                                        const double *__restrict__ seed, double *__restrict__ mult,
@@ -402,16 +372,9 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   const int tid = (int)((threadIdx.z * blockDim.y + threadIdx.y) * blockDim.x + threadIdx.x);
   const XLane X = xtile_lane(P, G, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, (int)threadIdx.y, (int)threadIdx.z);
   const int TS = xtile_stage_elems(G);
-  // the pressure pass inside this kernel (small ensembles): the tables of pow_pos_fast (3.5 KB) go to LDS, as in awfl_ptail_kernel --
-  // a pow is two dependent per-lane table look-ups, and the lanes of a boundary level chain nine of them (the density / pressure
-  // ghosts, Dycore.h:682-709): those wavefronts are the last to finish
-  __shared__ PowTab sh_tab;
-  const bool pow_lds = with_pressure == 2;
-  if (pow_lds) {
-    const double *src = reinterpret_cast<const double *>(P.pw);
-    double *dst = reinterpret_cast<double *>(&sh_tab);
-    for (int i = tid; i < (int)(sizeof(PowTab) / sizeof(double)); i += T) dst[i] = src[i];
-  }
+  // (round 5, measured and removed -- commit 38c84c8: the tables of pow_pos_fast staged in LDS for the pressure pass inside this kernel,
+  // as awfl_ptail_kernel does: 0.628 -> 0.621 G at nens = 1, 0.106 -> 0.108 G on the 250 x 1 x 50 shape -- the staging and its barrier
+  // cost what the nine chained look-ups of a boundary-level lane save)
   XShuf S = {};
   if (SHUF) S = xtile_shuffle_lanes(P, G, tid & 63, (int)threadIdx.x, (int)threadIdx.y);
   double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
@@ -419,10 +382,6 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   xtile_state_fields(P, fields);
   if (SHUF) {
     xtile_load_own<XT_NS>(P, prim_in, X, fields, own);
-    if (pow_lds) {              // (the one barrier of the shuffle form: the table is complete; reached long before it is needed)
-      __syncthreads();
-      P.pw = &sh_tab;
-    }
     if (X.poly) {
       xtile_state_polys_from(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
 #pragma unroll
@@ -438,7 +397,6 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
     double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
     xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
     __syncthreads();
-    if (pow_lds) P.pw = &sh_tab;
     if (X.poly) {
       xtile_state_polys(P, X, st, TS, own, L, R, cen);
 #pragma unroll
@@ -510,7 +468,7 @@ __global__ void __launch_bounds__(1024) awfl_xtr_tile_kernel(Params P, XTileGeom
 // two ping-pong sets of FT_NG right-edge values + 4 face fluxes (the state variables' differences).
 constexpr int FT_MAXG = (4 + MAXT + FT_NG - 1) / FT_NG + 1;
 struct FTileGroups { int ny_groups, nz_groups; int gy[FT_MAXG][FT_NG], gz[FT_MAXG][FT_NG]; };
-template <int DIR, bool VZ_PER_ENS, bool AHEAD>
+template <int DIR, bool VZ_PER_ENS>
 __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &G, int bx, int by, int T, const int (*grp)[FT_NG],
                                               int ngroups, const double *__restrict__ prim, double *__restrict__ flux, double *lds) {
   const int rows = ftile_rows(G), per = rows * G.W;
@@ -521,19 +479,8 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
   double *ldsR[2] = {lds, lds + FT_NG * T}, *ldsF = lds + 2 * FT_NG * T;
   const int ncomp_a = (DIR == 1) ? 1 : 2;
   double L[FT_NG], R[FT_NG], F[FT_NG], ruf = 0.0, fn = 0.0;
-  // the stencils of the advected groups are requested one group ahead (wn): group 0's before the acoustic polynomials are built
-  double wn[FT_NG][5];
-  auto group_fields = [&](int g, int (&fa)[FT_NG]) -> int {
-    int nf = 0;
-#pragma unroll
-    for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; }
-    return nf;
-  };
-  if (AHEAD) {
-    int fa0[FT_NG];
-    const int nf0 = (ngroups > 0) ? group_fields(0, fa0) : 0;
-    ftile_adv_load(P, prim, X, fa0, nf0, wn);
-  }
+  // (round 5, measured and removed -- commit 38c84c8: the stencils of group g + 1 requested before the polynomials of group g are
+  // built, in a 512-lane instance with 143 instead of 113 registers: flux tile kernel 18.0 -> 21.8 us at nens = 1, 0.63 -> 0.57 G)
   if (X.poly) {
     ftile_acoustic_polys<DIR, VZ_PER_ENS>(P, prim, X, L, R);
 #pragma unroll
@@ -548,21 +495,11 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
   }
   for (int g = 0; g < ngroups; g++) {
     double *buf = ldsR[(g + 1) & 1];
-    int fa[FT_NG];
-    const int nf = group_fields(g, fa);
-    double w[FT_NG][5];
-    if (!AHEAD) ftile_adv_load(P, prim, X, fa, nf, wn);
+    int fa[FT_NG], nf = 0;
 #pragma unroll
-    for (int n = 0; n < FT_NG; n++)
-#pragma unroll
-      for (int s5 = 0; s5 < 5; s5++) w[n][s5] = wn[n][s5];
-    if (AHEAD && g + 1 < ngroups) {
-      int fa1[FT_NG];
-      const int nf1 = group_fields(g + 1, fa1);
-      ftile_adv_load(P, prim, X, fa1, nf1, wn);
-    }
+    for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; }
     if (X.poly) {
-      ftile_adv_polys_from<DIR, VZ_PER_ENS>(P, X, nf, w, L, R);
+      ftile_adv_polys<DIR, VZ_PER_ENS>(P, prim, X, fa, nf, L, R);
 #pragma unroll
       for (int n = 0; n < FT_NG; n++) buf[n * T + X.slot] = R[n];
     }
@@ -587,16 +524,14 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
     }
   }
 }
-// MAXT: the largest workgroup the instance may be launched with (1024, or 512: twice the registers per lane -- the stencils requested one
-// group ahead do not fit the 128 registers a 1024-lane workgroup leaves a lane)
-template <bool VZ_PER_ENS, int MAXT>
-__global__ void __launch_bounds__(MAXT) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
+template <bool VZ_PER_ENS>
+__global__ void __launch_bounds__(1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
                                                               const double *__restrict__ prim, double *__restrict__ fy,
                                                               double *__restrict__ fz) {
   extern __shared__ double ft_lds[];
   const int T = (int)blockDim.x, b = (int)blockIdx.x;
-  if (b < nby) flux_tile_run<1, VZ_PER_ENS, (MAXT <= 512)>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
-  else flux_tile_run<2, VZ_PER_ENS, (MAXT <= 512)>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
+  if (b < nby) flux_tile_run<1, VZ_PER_ENS>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
+  else flux_tile_run<2, VZ_PER_ENS>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
 }
 
 // Test hook: the device WENO arithmetic on its own (v_rcp_f64 + Newton reciprocals, FMA contraction, difference form).
@@ -816,10 +751,6 @@ struct pam_amd_awfl {
   long long want_units = 3072, two_phase_below = 8192, split_below = 8192;   // launch-shape thresholds (pam_amd_awfl_set_handle_launch_tuning)
   int tracers_per_wave = 0;    // further tracers swept by one wavefront of the separately launched x tracer sweeps: 0 automatic, 1, 2, 4
   bool tracer_prefetch = false;   // phase 2 of those sweeps requests the next trip's loads one trip ahead (pairs only; experiment)
-  int flux_part_mode = 0;      // two-phase member-lane y/z sweeps: 0 = part kernels (each part with its own registers), 1 = the whole-sweep kernel
-  int flux_part_fields = 2;    // ... advected fields per wavefront of part 1: 2 (pairs) or 1
-  bool ftile_ahead = false;    // flux tile kernel: the 512-lane instance that requests the next group's stencils one group ahead (experiment)
-  bool tile_pow_lds = false;   // x tile kernel with the pressure inside: pow tables staged in LDS (experiment)
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   bool hydro_declared = false;
@@ -955,11 +886,8 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     if (T > 1024) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes");
     const size_t lds = (size_t)(2 * FT_NG + 4) * T * sizeof(double);
     ScopedTimer st(h, "flux", s);
-#define PAMA_LAUNCH_FTILE(VZ, MT) \
-  hipLaunchKernelGGL((awfl_flux_tile_kernel<VZ, MT>), dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z)
-    if (T <= 512 && h->ftile_ahead) { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 512); else PAMA_LAUNCH_FTILE(false, 512); }
-    else { if (P.vz_per_ens) PAMA_LAUNCH_FTILE(true, 1024); else PAMA_LAUNCH_FTILE(false, 1024); }
-#undef PAMA_LAUNCH_FTILE
+    if (P.vz_per_ens) hipLaunchKernelGGL(awfl_flux_tile_kernel<true>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
+    else hipLaunchKernelGGL(awfl_flux_tile_kernel<false>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
     HIP_TRY(hipGetLastError());
     return PAM_AMD_OK;
   }
@@ -979,13 +907,11 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // Small ensembles: a wavefront that sweeps its span for pass 1 and then for every pair of advected fields, one after the
   // other, is a long serial chain on a mostly empty chip.  Then pass 1 runs in a launch of its own (`part` 0) and the pairs in a
   // second one with one wavefront per (span, pair) (`part` 1); decided from the WHOLE ensemble (chunking-independent).
-  int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
+  const int npairs = flux_sweep_pairs(P, diff);   // advected fields besides the normal velocity, two per sweep
+  // (round 5, measured and removed -- commit 38c84c8, profiles/r05_ab_experiments.txt: the two parts as kernels of their own, each with
+  // its own register count -- pass 1 alone 127, pairs 118, one field per wavefront 86 registers -- C4 flux 0.121 -> 0.126 / 0.127 ms,
+  // C3 0.411 -> 0.414 / 0.434: the whole-sweep kernel at 128 registers already runs 4 wavefronts per SIMD)
   const bool two_phase = (ux0 + uy0 + uz0) * nblk_all < h->two_phase_below;
-  // two-phase member-lane sweeps of the fused stage run as PART kernels (awfl_flux_part_kernel: each part with its own register
-  // count); flux_part_fields: advected fields per wavefront of part 1 (2 = pairs, 1 = one field per wavefront)
-  const bool part_kernels = two_phase && diff && !flat && h->flux_part_mode != 1;
-  const int nfw = (part_kernels && h->flux_part_fields == 1) ? 1 : 2;
-  if (nfw == 1) npairs = 3 + P.nt - (skip_advected_v(P, diff) ? 1 : 0);       // groups of ONE advected field
   const int nphase = two_phase ? 2 : 1;
   if ((ux0 + uy0 + uz0) * nblk * (two_phase ? npairs : 1) > 0x3fffffffll)
     return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 wavefronts in one launch");
@@ -1009,18 +935,10 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
 #define PAMA_LAUNCH_FLUX(VZ, DF, FL)                                                                                    \
   hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF, FL>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
-#define PAMA_LAUNCH_PART(VZ, PT, NW)                                                                                    \
-  hipLaunchKernelGGL((awfl_flux_part_kernel<VZ, PT, NW>), grid, block, 0, s, P, G, r, prim, h->flux_y, h->flux_z)
-  if (part_kernels) {
-    if (phase == 0) { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 0, 2); else PAMA_LAUNCH_PART(false, 0, 2); }
-    else if (nfw == 1) { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 1, 1); else PAMA_LAUNCH_PART(false, 1, 1); }
-    else { if (P.vz_per_ens) PAMA_LAUNCH_PART(true, 1, 2); else PAMA_LAUNCH_PART(false, 1, 2); }
-  } else
   if (flat) { if (P.vz_per_ens) PAMA_LAUNCH_FLUX(true, true, true); else PAMA_LAUNCH_FLUX(false, true, true); }
   else if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true, false); else PAMA_LAUNCH_FLUX(true, false, false); }
   else { if (diff) PAMA_LAUNCH_FLUX(false, true, false); else PAMA_LAUNCH_FLUX(false, false, false); }
 #undef PAMA_LAUNCH_FLUX
-#undef PAMA_LAUNCH_PART
   HIP_TRY(hipGetLastError());
   }
   return PAM_AMD_OK;
@@ -1085,7 +1003,7 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     const dim3 block((unsigned)G.W, (unsigned)xtile_rows(G), (unsigned)G.lpb);
     const dim3 grid((unsigned)(G.ntl * G.nmb), (unsigned)((nlines + G.lpb - 1) / G.lpb), 1);
     if (grid.y > 65535u) return fail(PAM_AMD_EINVAL, "x-tile launch: more than 65535 groups of x lines");
-    if (!h->xshuf && (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) + sizeof(PowTab) > 160 * 1024)
+    if (!h->xshuf && (size_t)XT_NS * (threads + xtile_stage_elems(G)) * sizeof(double) > 160 * 1024)
       return fail(PAM_AMD_EINVAL, "x-tile launch: the staged tile does not fit the 160 KB of LDS");
     // a wavefront is one row of FCT flags only when a row of the tile is exactly one 64-member block
     const bool wave_is_row = (G.W == 64 && P.nens % 64 == 0);
@@ -1098,11 +1016,11 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       if (shuf)
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), grid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? (h->tile_pow_lds ? 2 : 1) : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
       else
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), grid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? (h->tile_pow_lds ? 2 : 1) : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
@@ -1558,19 +1476,17 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // the tile kernels stage their tiles in LDS: up to 14 doubles per lane of a 1024-lane workgroup
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)sizeof(PowTab)));   // (static LDS: the pow tables)
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<1, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xtr_tile_kernel<3, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef INIT_TRY
   h->flux_lds_floor = 0;   // no residency cap by default
   h->want_units = g_want_units.load(); h->two_phase_below = g_two_phase_below.load(); h->split_below = g_split_below.load();
@@ -2069,7 +1985,7 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
   const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group);
   if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
-  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) + sizeof(PowTab) > 160 * 1024)
+  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) > 160 * 1024)
     return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");
   USE_DEVICE(h);
   h->xt_w = row_lanes; h->xt_tc = cells_per_tile; h->xt_lpb = lines_per_group;
@@ -2150,18 +2066,6 @@ int pam_amd_awfl_set_tracer_grouping(pam_amd_awfl_t *h, int tracers_per_wavefron
   drop_graphs(h);
   h->tracers_per_wave = tracers_per_wavefront;
   h->tracer_prefetch = prefetch != 0;
-  return PAM_AMD_OK;
-}
-
-int pam_amd_awfl_set_experiment(pam_amd_awfl_t *h, const char *name, int value) {
-  if (!h || !name) return fail(PAM_AMD_EINVAL, "set_experiment: null argument");
-  const std::string k(name);
-  drop_graphs(h);
-  if (k == "ftile_ahead") h->ftile_ahead = value != 0;
-  else if (k == "tile_pow_lds") h->tile_pow_lds = value != 0;
-  else if (k == "flux_part_kernels") h->flux_part_mode = value ? 0 : 1;
-  else if (k == "flux_part_fields") { if (value != 1 && value != 2) return fail(PAM_AMD_EINVAL, "set_experiment: flux_part_fields is 1 or 2"); h->flux_part_fields = value; }
-  else return fail(PAM_AMD_EINVAL, "set_experiment: unknown switch " + k);
   return PAM_AMD_OK;
 }
 

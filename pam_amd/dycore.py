@@ -260,10 +260,6 @@ class Dycore:
     def set_x_tile(self, row_lanes=0, cells_per_tile=0, lines_per_group=0):
         check(self._lib.pam_amd_awfl_set_x_tile(self._h, int(row_lanes), int(cells_per_tile), int(lines_per_group)))
 
-    def set_experiment(self, name, value):
-        """switches of measured experiments that stayed off (include/pam_amd_awfl.h); same bits"""
-        check(self._lib.pam_amd_awfl_set_experiment(self._h, name.encode(), int(value)))
-
     def set_tracer_grouping(self, tracers_per_wavefront=0, prefetch=False):
         """separately launched x sweeps of the further tracers: 0 (automatic), 1, 2 or 4 tracers per wavefront; phase 2 with the next
         trip's loads requested one trip ahead (pairs only; experiment); same bits"""
