@@ -533,7 +533,8 @@ def measure_roofline(job, args, profile_key=None):
         pk = prof["kernels"]
 
         def pkey(name):      # "awfl_xtr_kernel<2>" is one template family in the profile; small ensembles run the _tile_ forms
-            for cand in (name, name.replace("_kernel", "_tile_kernel"), name.split("<")[0], name.split("<")[0].replace("_kernel", "_tile_kernel")):
+            for cand in (name, name.replace("xtr_kernel", "xtrn_kernel"), name.replace("_kernel", "_tile_kernel"), name.split("<")[0],
+                         name.split("<")[0].replace("_kernel", "_tile_kernel")):
                 if cand in pk:
                     return cand
             if name.startswith("awfl_trfix") and "awfl_trfix_flat_kernel" in pk:

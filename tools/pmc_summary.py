@@ -79,7 +79,7 @@ def main():
         def family(k):
             """template instances of one kernel are one family -- except the two PHASES of the tracer sweeps, which are different
             kernels in all but name: awfl_xtr_kernel<STAGE, PHASE> -> awfl_xtr_kernel<PHASE> (bench.py's name for them)"""
-            m = re.match(r"(awfl_xtr4?(?:_tile)?_kernel)<\s*\d+\s*,\s*(\d+)\s*[,>]", k)      # (further template arguments: variants of the phase)
+            m = re.match(r"(awfl_xtrn?(?:_tile)?_kernel)<\s*\d+\s*,\s*(\d+)\s*[,>]", k)      # (further template arguments: variants of the phase)
             return "%s<%s>" % (m.group(1), m.group(2)) if m else re.sub(r"<.*", "", k)
         out = {}
         for k in acc:
