@@ -2,10 +2,15 @@
 // sponge_layer: pam_core/modules/sponge_layer.h:8-95.  Both kernels are tiny and HBM-bound (top 5 of 60 levels).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/pam_amd_awfl.h"
 #include "../../include/pam_amd_modules.h"
+#include "awfl_device.h"       // pow_pos_fast + its tables (the step's own x^y for positive bases)
+#include "awfl_vertical.h"     // build_pow_tab
 #include "supercell_sounding.h"
 
 namespace {
@@ -82,8 +87,20 @@ __global__ void __launch_bounds__(256) sponge_relax_kernel(FieldPtrs F, int nens
 // coupler arrays between the two kernels; only the old Exner function needs scratch.  velqr, r, rhalf, pc are pure
 // functions of stored values and are recomputed (bitwise the same as the reference's stored temporaries).
 
-__device__ __forceinline__ double kessler_velqr(double qr, double r, double rhalf) {
-  return 36.34 * pow(qr * r, 0.1364) * rhalf;   // :375, :449
+// Every x^y of the scheme has a non-negative base: it goes through pow_pos_fast (awfl_device.h: ~65 instructions, 0.52 ulp against
+// 80-bit powl, 0 -> 0) instead of the device library's pow (~260-440 instructions, half of them for negative / special bases) -- six of
+// them per cell and sub-cycle made the column kernel VALU-bound (round 5: 4.2 -> 2.x ms per timeStep at 1024 x 32x32x60).  T: its
+// tables, staged in LDS by the kernels (two dependent per-lane look-ups per pow).
+using pama::PowTab;
+__device__ __forceinline__ double kpow(double x, double y, const PowTab *T) { return pama::pow_pos_fast(x, y, T); }
+__device__ __forceinline__ void kessler_stage_tab(const PowTab *__restrict__ src, PowTab *dst) {
+  const double *s = reinterpret_cast<const double *>(src);
+  double *d = reinterpret_cast<double *>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(PowTab) / sizeof(double)); i += blockDim.x) d[i] = s[i];
+  __syncthreads();
+}
+__device__ __forceinline__ double kessler_velqr(double qr, double r, double rhalf, const PowTab *T) {
+  return 36.34 * kpow(qr * r, 0.1364, T) * rhalf;   // :375, :449
 }
 
 // timeStep :167-174 + kessler "main 1" :369-386, in two forms.  WRITE=false only evaluates the sedimentation time-step
@@ -97,7 +114,10 @@ __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long nco
                                                            double *rho_r, const double *__restrict__ rho_dry, double *temp,
                                                            double *precl, const double *__restrict__ zmid, double dt,
                                                            double R_d, double R_v, double cp_d, double p0, double *exner_out,
-                                                           unsigned long long *dt_max_bits) {
+                                                           unsigned long long *dt_max_bits, const PowTab *__restrict__ tab) {
+  __shared__ PowTab sh_tab;
+  kessler_stage_tab(tab, &sh_tab);
+  const PowTab *PT = &sh_tab;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
   if (WRITE) {
@@ -106,7 +126,7 @@ __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long nco
     const double rho = rho_dry[idx];
     const double rv = rho_v[idx], T = temp[idx];
     const double pressure = R_d * rho * T + R_v * rv * T;
-    const double ex = pow(pressure / p0, R_d / cp_d);
+    const double ex = kpow(pressure / p0, R_d / cp_d, PT);
     rho_v[idx] = rv / rho;
     rho_c[idx] = rho_c[idx] / rho;
     rho_r[idx] = rho_r[idx] / rho;
@@ -123,7 +143,7 @@ __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long nco
     const int e = (int)(col % nens);
     const double rho = rho_dry[idx];
     const double qr = rho_r[idx] / rho;
-    const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho_dry[col] / rho));
+    const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho_dry[col] / rho), PT);
     double dt2d = dt;
     if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
     bits = (velqr >= 0 && dt2d > 0) ? (unsigned long long)__double_as_longlong(dt2d) : 0ull;
@@ -143,7 +163,10 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
                                                             double *qr_a, const double *__restrict__ rho_dry, double *theta_a,
                                                             double *precl, const double *__restrict__ zmid,
                                                             const double *__restrict__ exner, double dt, int rainsplit,
-                                                            double Rd, double cp, double p0) {
+                                                            double Rd, double cp, double p0, const PowTab *__restrict__ tab) {
+  __shared__ PowTab sh_tab;
+  kessler_stage_tab(tab, &sh_tab);
+  const PowTab *PT = &sh_tab;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncol) return;
   const int e = (int)(col % nens);
@@ -156,7 +179,7 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
     // level-k values carried from the previous iteration's "k+1" loads
     double rho_k = rho0, z_k = zmid[e], qr_k = qr_a[col];
     double r_k = 0.001 * rho_k, rhalf_k = sqrt(rho0 / rho_k);
-    double vel_k = kessler_velqr(qr_k, r_k, rhalf_k);
+    double vel_k = kessler_velqr(qr_k, r_k, rhalf_k, PT);
     double z_km1 = 0;
     pr = pr + rho0 * qr_k * vel_k / rhoqr;                                       // :397
     for (int k = 0; k < nz; k++) {
@@ -167,14 +190,14 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
       } else {
         rho_n = rho_dry[idx + ncol]; z_n = zmid[(long long)(k + 1) * nens + e]; qr_n = qr_a[idx + ncol];
         r_n = 0.001 * rho_n; rhalf_n = sqrt(rho0 / rho_n);
-        vel_n = kessler_velqr(qr_n, r_n, rhalf_n);
+        vel_n = kessler_velqr(qr_n, r_n, rhalf_n, PT);
         sed = dt0 * (r_n * qr_n * vel_n - r_k * qr_k * vel_k) / (r_k * (z_n - z_k));   // :403
       }
       double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k;
       const double pk = exner[idx];
-      const double pc = 3.8 / (pow(pk, cp / Rd) * psl);                            // :374
+      const double pc = 3.8 / (kpow(pk, cp / Rd, PT) * psl);                        // :374
       // autoconversion and accretion (:412-414)
-      const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * pow(qr, 0.875));
+      const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * kpow(qr, 0.875, PT));
       qc = fmax(qc - qrprod, 0.);
       qr = fmax(qr + qrprod + sed, 0.);
       // saturation vapour mixing ratio (:417-422)
@@ -183,7 +206,7 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
       const double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
       // evaporation of rain (:425-430)
       const double rq = r_k * qr;
-      const double tmp1 = dt0 * (((1.6 + 124.9 * pow(rq, 0.2046)) * pow(rq, 0.525)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
+      const double tmp1 = dt0 * (((1.6 + 124.9 * kpow(rq, 0.2046, PT)) * kpow(rq, 0.525, PT)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
                           (fmax(qvs - qv, 0.) / (r_k * qvs));
       const double tmp2 = fmax(-prod - qc, 0.);
       const double ern = fmin(tmp1, fmin(tmp2, qr));
@@ -544,6 +567,25 @@ int kessler_check(int nens, int nx, int ny, int nz, const void *a, const void *b
   return PAM_AMD_OK;
 }
 
+// the tables of pow_pos_fast on the current device (built once per device and process; 4 KB)
+const PowTab *kessler_pow_tab() {
+  static std::mutex m;
+  static std::vector<PowTab *> tabs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+  std::lock_guard<std::mutex> lk(m);
+  if ((int)tabs.size() <= dev) tabs.resize(dev + 1, nullptr);
+  if (!tabs[dev]) {
+    PowTab host;
+    pama::build_pow_tab(host);
+    PowTab *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(PowTab)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, &host, sizeof(PowTab), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    tabs[dev] = d;
+  }
+  return tabs[dev];
+}
+
 int kessler_read_dt_max(const double *slot, hipStream_t s, double *out) {
   double v = 0;
   if (hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
@@ -558,13 +600,15 @@ extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, c
                                              const double *zmid, double dt, double *workspace, void *stream, double *dt_max) {
   if (!dt_max) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null dt_max");
   if (int rc = kessler_check(nens, nx, ny, nz, rho_r, rho_r, rho_r, rho_dry, rho_dry, zmid, workspace, dt, 1, 1, 1, 1)) return rc;
+  const PowTab *tab = kessler_pow_tab();
+  if (!tab) return pam_amd_set_last_error_(PAM_AMD_ENOMEM, "kessler: cannot allocate the pow tables");
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
   if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
   hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
                      (double *)nullptr, (double *)nullptr, const_cast<double *>(rho_r), rho_dry, (double *)nullptr,
-                     (double *)nullptr, zmid, dt, 1., 1., 1., 1., (double *)nullptr, slot);
+                     (double *)nullptr, zmid, dt, 1., 1., 1., 1., (double *)nullptr, slot, tab);
   return kessler_read_dt_max((const double *)slot, s, dt_max);
 }
 
@@ -574,6 +618,8 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
                                          int rainsplit_hint, int *rainsplit) {
   if (!precl) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null precl");
   if (int rc = kessler_check(nens, nx, ny, nz, rho_v, rho_c, rho_r, rho_dry, temp, zmid, workspace, dt, R_d, R_v, cp_d, p0)) return rc;
+  const PowTab *tab = kessler_pow_tab();
+  if (!tab) return pam_amd_set_last_error_(PAM_AMD_ENOMEM, "kessler: cannot allocate the pow tables");
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
@@ -585,7 +631,7 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     // T -> theta in place and cannot be undone from an error path.
     if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
     hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
-                       rho_v, rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
+                       rho_v, rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot, tab);
     double dt_max;
     if (int rc = kessler_read_dt_max((const double *)slot, s, &dt_max)) return rc;
     const double want = ceil(dt / dt_max);
@@ -594,9 +640,9 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     if (n < 1) n = 1;
   }
   hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
-                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot);
+                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot, tab);
   hipLaunchKernelGGL(kessler_column_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
-                     rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, cp_d, p0);
+                     rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, cp_d, p0, tab);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   if (rainsplit) *rainsplit = n;

@@ -42,7 +42,7 @@ def main():
         def g(k):
             mm = re.search(k + r": (\d+)", b)
             return int(mm.group(1)) if mm else -1
-        d = re.sub(r"^void ", "", d)
+        d = re.sub(r"^void ", "", d).replace("(anonymous namespace)::", "")
         d = re.sub(r"\(.*", "", d)
         print("%-64s %5d %5d %5d %8d %5d %8d %7d" % (d[:64], g("VGPRs"), g("AGPRs"), g("SGPRs"), g(r"ScratchSize \[bytes/lane\]"),
                                                     g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]"), sizes.get(n, -1)))
