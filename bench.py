@@ -69,12 +69,13 @@ STAGE_KERNELS = ("flux", "xupd", "xtr1", "xtr2", "ptail", "trfix", "fct_mult", "
 
 
 def csrc_hash():
-    """content hash of the kernel sources: ties a committed PMC profile to the build it was measured on"""
+    """content hash of the DYCORE kernel sources (pam_amd/csrc/awfl_*): ties a committed PMC profile of the stage kernels to the build
+    it was measured on (the coupler modules' kernels, modules_kernels.hip, are not in those profiles)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pam_amd", "csrc")
     for f in sorted(os.listdir(d)):
         p = os.path.join(d, f)
-        if os.path.isfile(p) and f.endswith((".h", ".hip")):
+        if os.path.isfile(p) and f.startswith("awfl_") and f.endswith((".h", ".hip")):
             h.update(f.encode())
             h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
@@ -335,6 +336,9 @@ class Job:
             dycore.set_lane_mapping(args.lanes, args.xkernels)
         if args.xtile:
             dycore.set_x_tile(*[int(v) for v in args.xtile.split(",")])
+        if args.ftile:
+            ty, tz = [int(v) for v in args.ftile.split(",")]
+            dycore.set_flux_tile("auto", ty, tz)
         if args.xexchange != "auto":
             dycore.set_x_exchange(args.xexchange)
         if args.trgroup != 0 or args.trprefetch:
@@ -931,6 +935,7 @@ def main():
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
     ap.add_argument("--trgroup", type=int, default=0, choices=(0, 1, 2, 4), help="further tracers per wavefront of the separate x tracer sweeps (0 = automatic)")
     ap.add_argument("--trprefetch", type=int, default=0, choices=(0, 1), help="phase 2 of those sweeps: next trip's loads one trip ahead")
+    ap.add_argument("--ftile", default="", help="y/z flux tile kernel: cells per y tile,levels per z tile (0 = automatic each)")
     ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),
                     help="x tile kernels: neighbouring cells exchange through LDS + barriers / by wavefront shuffles (a line inside one wavefront)")
     ap.add_argument("--launcher", default="python", choices=("python", "cpp"),

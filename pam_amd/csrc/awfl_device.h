@@ -1955,7 +1955,12 @@ struct XTileGeom {
 PAMA_HD int xtile_rows(const XTileGeom &G) { return G.tc + 2 * G.halo; }
 PAMA_HD int xtile_threads(const XTileGeom &G) { return G.W * xtile_rows(G) * G.lpb; }
 // automatic geometry (w_req / tc_req / lpb_req > 0 override: tuning and tests; results never depend on the geometry)
-PAMA_HD XTileGeom xtile_geometry(const Params &P, int w_req, int tc_req, int lpb_req) {
+//   ncu: compute units of the device (0: unknown -- the host emulation).  Whole-line tiles of a small grid are a LATENCY problem: the
+//   launch is over when the most loaded CU is, so the lines per workgroup are chosen to minimise (workgroups per CU, rounded up) x
+//   (lanes per workgroup), ties going to 256-lane workgroups (one wavefront per SIMD) -- measured on MI355X (round 5,
+//   profiles/r05_ab_experiments.txt): 32x32x60 with one member 6 -> 8 lines (320 -> 240 workgroups on 256 CUs) 14.5 -> 13.9 us, with two
+//   members 3 -> 4 lines (640 -> 480) 17.0 -> 15.7 us.
+PAMA_HD XTileGeom xtile_geometry(const Params &P, int w_req, int tc_req, int lpb_req, int ncu = 0) {
   XTileGeom G;
   G.W = (P.nens <= 64) ? P.nens : 64;
   // fewer than 64 members whose whole line does not fit a workgroup: rows of an even share of the members (at least 16: 128-byte
@@ -1987,6 +1992,19 @@ PAMA_HD XTileGeom xtile_geometry(const Params &P, int w_req, int tc_req, int lpb
     G.lpb = most;
     for (int l = 1; l <= most; l++)
       if (used(l) >= best - 0.03 && (l * row >= 192 || l == most)) { G.lpb = l; break; }
+    if (ncu > 0) {
+      const long long nlines = (long long)P.nz * P.ny;
+      long long best_cost = -1;
+      int best_dist = 0;
+      for (int l = 1; l <= most; l++) {
+        if (used(l) < best - 0.03) continue;
+        const int T = ((l * row + 63) / 64) * 64;
+        const long long nwg = (long long)G.nmb * ((nlines + l - 1) / l);
+        const long long cost = ((nwg + ncu - 1) / ncu) * T;
+        const int dist = T > 256 ? T - 256 : 256 - T;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && dist < best_dist)) { best_cost = cost; best_dist = dist; G.lpb = l; }
+      }
+    }
     if (lpb_req > 0) G.lpb = lpb_req < most ? lpb_req : most;
     if (G.lpb < 1) G.lpb = 1;
   } else {

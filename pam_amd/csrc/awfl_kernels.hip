@@ -744,6 +744,8 @@ struct pam_amd_awfl {
   int ftile_mode = 0;          // 0 automatic, 1 flat-lane sweeps, 2 tile kernel
   bool ftile = true;           // resolved -- flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
   int ft_tc_y = 0, ft_tc_z = 0;          // cells / levels per y / z tile (0 = automatic)
+  int ft_auto_y = 0, ft_auto_z = 0;      // ... the automatic choice (choose_flux_tiles; 0 = ftile_geometry's own default)
+  int ncu = 0;                           // compute units of the handle's device
   XTileGeom xg;
   bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
   bool fused_supported = false;
@@ -875,7 +877,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   if (flat && (r.e0 != 0 || r.ne != P.nens)) return fail(PAM_AMD_EINVAL, "flux launch: flat lanes sweep the whole ensemble in one range");
   if (flat && h->ftile && sweeps == 6) {
     // tile kernel: a lane per cell, both directions in one launch (small ensembles)
-    const FTileGeom Gy = ftile_geometry(P, 1, h->ft_tc_y), Gz = ftile_geometry(P, 2, h->ft_tc_z);
+    const FTileGeom Gy = ftile_geometry(P, 1, h->ft_tc_y ? h->ft_tc_y : h->ft_auto_y), Gz = ftile_geometry(P, 2, h->ft_tc_z ? h->ft_tc_z : h->ft_auto_z);
     FTileGroups Q;
     Q.ny_groups = ftile_groups(P, 1, Q.gy, FT_MAXG);
     Q.nz_groups = ftile_groups(P, 2, Q.gz, FT_MAXG);
@@ -1209,6 +1211,39 @@ void drop_graphs(pam_amd_awfl *h) {
   h->graph_gen++;
 }
 
+// Tile sizes of the y/z flux TILE kernel (small grids: below 2.6e5 cells).  One launch, one workgroup size T = the larger of the y and
+// the z tile: such a launch is a latency problem -- it is over when the most loaded CU is -- so (cells per y tile, levels per z tile)
+// are chosen to minimise (workgroups per CU, rounded up) x T, among geometries whose launched lanes are at least 80 % active; ties go
+// to fewer launched lanes.  Measured on MI355X (round 5, profiles/r05_ab_experiments.txt), 32x32x60 with one member: 340 workgroups of
+// 512 lanes (11, 6) -> 248 of 640 (16, 8): 17.8 -> 16.1 us, 0.645 -> 0.688 G; a geometry with 276 workgroups of 768: 22.2 us; the
+// reference's 250 x 1 x 50 shape: 36 workgroups of 512 -> 100 of 256: 12.8 -> 11.3 us.
+void choose_flux_tiles(pam_amd_awfl *h) {
+  const Params &P = h->P;
+  h->ft_auto_y = h->ft_auto_z = 0;
+  if (h->ncu <= 0 || P.ncell > 262144) return;
+  long long best_cost = -1, best_lanes = 0;
+  for (int ty = 0; ty <= (P.sim2d ? 0 : (P.ny < 30 ? P.ny : 30)); ty++) {         // (0: ftile_geometry's own choice, e.g. whole short lines)
+    if (ty == 1) continue;
+    for (int tz = 2; tz <= 14; tz++) {
+      const FTileGeom Gy = ftile_geometry(P, 1, ty), Gz = ftile_geometry(P, 2, tz);
+      if (ty > 0 && Gy.tc != ty) continue;                          // (clamped: the same geometry as a smaller request)
+      if (Gz.tc != tz) continue;
+      const long long nby = P.sim2d ? 0 : (long long)Gy.nch * Gy.ntl * ((P.nz + Gy.lpb - 1) / Gy.lpb), nbz = (long long)Gz.nch * Gz.ntl;
+      int T = ftile_threads(Gz);
+      if (!P.sim2d && ftile_threads(Gy) > T) T = ftile_threads(Gy);
+      T = ((T + 63) / 64) * 64;
+      if (T > 1024) continue;
+      const long long launched = (nby + nbz) * T;
+      const long long active = (P.sim2d ? 0 : nby * ftile_threads(Gy)) + nbz * ftile_threads(Gz);
+      if (active * 5 < launched * 4) continue;
+      const long long cost = ((nby + nbz + h->ncu - 1) / h->ncu) * T;
+      if (best_cost < 0 || cost < best_cost || (cost == best_cost && launched < best_lanes)) {
+        best_cost = cost; best_lanes = launched; h->ft_auto_y = P.sim2d ? 0 : ty; h->ft_auto_z = tz;
+      }
+    }
+  }
+}
+
 // Lane mapping of the fused stage (decided from the WHOLE ensemble; results never depend on it):
 //   flat   the y/z sweeps take 64 consecutive (x, member) items per wavefront (flat_lane) instead of 64 members of one line
 //   xtile  the x direction runs as tile kernels (a lane per cell) instead of sweeps (a wavefront per line span)
@@ -1224,7 +1259,7 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // ranges, which need member lanes, are worth more
   const bool ragged = P.nens % 64 != 0 && P.nens < 128;
   h->flat = h->flat_supported && (h->lane_mode == 2 || (h->lane_mode == 0 && (small || ragged)));
-  h->xg = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb);
+  h->xg = xtile_geometry(P, h->xt_w, h->xt_tc, h->xt_lpb, h->ncu);
   // (the groups of x lines are the y dimension of the tile kernels' launch grid: at most 65535)
   const bool grid_ok = ((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb <= 65535;
   h->xtile = xtile_supported(P) && grid_ok && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
@@ -1235,6 +1270,7 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
   // build no halo rows; measured on MI355X, 32x32x60: 1 member 67 -> 20 us per stage, 8 members 85 -> 82, 32 members 184 -> 320)
   h->ftile = h->ftile_mode == 2 || (h->ftile_mode == 0 && P.ncell <= 262144);
+  choose_flux_tiles(h);
   // the pressure pass inside the x tile kernel while a stage is a handful of short launches (one launch of ~10 us less); above, the
   // separate pass with the pow tables in LDS and 6 levels per lane is cheaper than the tile kernel's longer lanes
   h->tile_pressure = h->tile_pressure_mode == 2 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
@@ -1370,6 +1406,7 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   pam_amd_awfl *h = new pam_amd_awfl();
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(PAM_AMD_ENOGPU, "init: hipGetDevice failed"); }
+  if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
   h->stream = (hipStream_t)cfg->stream;
   auto opt = [](double v, double dflt) { return std::isnan(v) ? dflt : v; };
   h->R_d = opt(cfg->R_d, 287.);   h->cp_d = opt(cfg->cp_d, 1003.);
@@ -1983,7 +2020,7 @@ int pam_amd_awfl_set_lane_mapping(pam_amd_awfl_t *h, int yz_lanes, int x_kernels
 int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile, int lines_per_group) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
-  const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group);
+  const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group, h->ncu);
   if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
   if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) > 160 * 1024)
     return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");

@@ -227,6 +227,19 @@ def test_wavefronts_are_at_least_90_percent_full_when_nx_times_nens_reaches_64(n
         assert z_use == cols / (64.0 * -(-cols // 64))
 
 
+def test_tile_geometry_puts_one_workgroup_on_every_cu_when_the_grid_allows():
+    """Small grids are launch-latency problems: the x tile geometry minimises (workgroups per CU, rounded up) x (lanes per workgroup),
+    ties going to 256-lane workgroups (round 5: BASELINE's 32x32x60 grid with one member 8 lines per workgroup = 240 workgroups of 256
+    lanes instead of 320 of 192; with two members 4 lines = 480 of 256 instead of 640 of 192).  Results do not depend on it (the
+    bit-for-bit tests above run both)."""
+    import torch
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the expected geometry is that of a 256-CU device")
+    for nens, want in ((1, 8), (2, 4), (8, 1)):
+        _, _, _, g = _lane_use(nens, 32, 32, 60)
+        assert g["lpb"] == want and g["halo"] == 0, (nens, g)
+
+
 @pytest.mark.parametrize("case", ["nens1_c2grid_slab", "nens1_ref_shape_nt4", "nens8_nt4_B", "nens5_vapour_limited", "nens40_vapour_limited_B"])
 def test_time_step_replayed_from_a_hip_graph_equals_eager_launches_bit_for_bit(case):
     """pam_amd_awfl_set_graph_replay: the whole timeStep captured once per (coupler arrays, sub-cycle count, buffer parity) and replayed.
