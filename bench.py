@@ -336,6 +336,8 @@ class Job:
             dycore.set_lane_mapping(args.lanes, args.xkernels)
         if args.xtile:
             dycore.set_x_tile(*[int(v) for v in args.xtile.split(",")])
+        if args.tilefusion != "auto":
+            dycore.set_tile_fusion(args.tilefusion)
         if args.ftile:
             ty, tz = [int(v) for v in args.ftile.split(",")]
             dycore.set_flux_tile("auto", ty, tz)
@@ -935,6 +937,9 @@ def main():
     ap.add_argument("--xtile", default="", help="tile geometry W,tc,lpb (0 = automatic each)")
     ap.add_argument("--trgroup", type=int, default=0, choices=(0, 1, 2, 4), help="further tracers per wavefront of the separate x tracer sweeps (0 = automatic)")
     ap.add_argument("--trprefetch", type=int, default=0, choices=(0, 1), help="phase 2 of those sweeps: next trip's loads one trip ahead")
+    ap.add_argument("--tilefusion", default="auto", choices=("auto", "separate", "inside", "beside"),
+                    help="x tile kernels of small ensembles: pressure pass / tracer phase 1 in launches of their own, inside the state kernel, "
+                         "or inside its launch with phase 1 in workgroups beside the state pass")
     ap.add_argument("--ftile", default="", help="y/z flux tile kernel: cells per y tile,levels per z tile (0 = automatic each)")
     ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),
                     help="x tile kernels: neighbouring cells exchange through LDS + barriers / by wavefront shuffles (a line inside one wavefront)")

@@ -193,7 +193,10 @@ int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_ti
 /* x tile kernels of small ensembles, where a launch costs more than its work: the state kernel (awfl_xupd_tile_kernel) also makes the
  * next stage's pressure + density / pressure ghosts (Dycore.h:310-321, :682-709; otherwise awfl_ptail_kernel) and phase 1 of the
  * further tracers (their FCT multipliers, Dycore.h:525-540; otherwise awfl_xtr_tile_kernel<., 1>): two launches less per stage.
- * mode 2 = fused, 1 = separate launches, 0 = automatic (fused while the ensemble is below ~1e6 cells).  Same bits either way. */
+ * mode 2 = fused (phase 1 of the tracers BEHIND the state pass of the same wavefront), 3 = fused with phase 1 in workgroups of its own
+ * BESIDE the state pass (z slices of the same launch; they rebuild the face mass flux from the polynomials of rho*u and p instead of
+ * waiting for it: same values, same functions, same bits), 1 = separate launches, 0 = automatic (fused while the ensemble is below ~1e6
+ * cells; beside the state pass while every workgroup of the launch still finds a CU of its own).  Same bits either way. */
 int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode);
 /* Launch-bound ensembles: a whole time_step (coupler -> dycore, every stage, dycore -> coupler: ~10 launches per sub-step of a few
  * microseconds each) is captured once into a HIP graph on an internal stream and replayed -- one graph per (coupler arrays, number

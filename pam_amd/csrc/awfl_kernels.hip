@@ -356,6 +356,80 @@ __device__ __forceinline__ void xtr_tile_run(const Params &P, const XLane &X, co
     xtile_tracer_finish<NF, STAGE, PHASE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
   }
 }
+// Phase 1 of one tracer pair in a workgroup of its OWN inside the state kernel's launch (small grids with idle CUs: the state kernel's
+// z slices 1.. ; round 5).  Inline, the pairs' phase 1 runs behind the state pass of the same wavefront -- one serial chain; here it runs
+// BESIDE it, and instead of waiting for the state pass's face mass flux (another workgroup of the same launch) it forms that flux
+// itself: the polynomials of rho*u and p of the lane's cell (the first two of xtile_state_polys: same products, same weno5_const) and
+// acoustic_face on them -- the same values in the same functions, hence the same bits as the flux the state workgroup computes.
+template <int STAGE, int NF, bool SHUF>
+__device__ __forceinline__ void xtr_tile_run_own_flux(const Params &P, const XLane &X, const XShuf &S, int T, int TS,
+                                                      const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                                                      double *__restrict__ prim_out, const double *__restrict__ fx,
+                                                      const double *__restrict__ fy, const double *__restrict__ fz,
+                                                      double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows,
+                                                      double dt_dyn, double dt_stage, const int *fa, double *lds) {
+  constexpr int NQ = NF + 3;                         // staged: rho, p, u, the tracers
+  constexpr int NE = NF + 2;                         // exchanged right-edge values: rho*u, p, the tracers
+  const WenoConsts wc = weno_consts();
+  int fields[NQ];
+  fields[0] = P_RHO; fields[1] = P_PRES; fields[2] = P_U;
+#pragma unroll
+  for (int n = 0; n < NF; n++) fields[3 + n] = P_U + fa[n];
+  double own[NQ], L[NE], R[NE], cen[NF], F[NF];
+  double *st = lds, *ex = lds + NQ * TS;
+  if (SHUF) {
+    xtile_load_own<NQ>(P, prim_in, X, fields, own);
+  } else {
+    xtile_stage<NQ>(P, prim_in, X, fields, st, TS, own);
+    __syncthreads();
+  }
+  auto nb = [&](int f, int s) -> double { return SHUF ? xtile_shfl(own[f], S.ln[s]) : st[f * TS + X.s5[s]]; };
+  if (X.poly) {
+    double r[5], u[5], w[5];
+#pragma unroll
+    for (int s = 0; s < 5; s++) { r[s] = (s == 2) ? own[0] : nb(0, s); u[s] = (s == 2) ? own[2] : nb(2, s); }
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = mul_rn(r[s], u[s]);
+    weno5_const(w, wc, L[0], R[0]);
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[s] = (s == 2) ? own[1] : nb(1, s);
+    weno5_const(w, wc, L[1], R[1]);
+#pragma unroll
+    for (int n = 0; n < NF; n++) {
+#pragma unroll
+      for (int s = 0; s < 5; s++) w[s] = (s == 2) ? own[3 + n] : nb(3 + n, s);
+      cen[n] = w[2];
+      weno5_const(w, wc, L[2 + n], R[2 + n]);
+    }
+    if (!SHUF) {
+#pragma unroll
+      for (int f = 0; f < NE; f++) ex[f * T + X.slot] = R[f];
+    }
+  }
+  if (!SHUF) __syncthreads();
+  if (X.face) {
+    double Rl[NE];
+#pragma unroll
+    for (int f = 0; f < NE; f++) Rl[f] = SHUF ? xtile_shfl(R[f], S.l) : ex[f * T + X.slot_l];
+    double ruf, ppf;
+    acoustic_face(Rl[0], L[0], Rl[1], L[1], false, ruf, ppf);
+    double Lt[NF], Rt[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) { Lt[n] = L[2 + n]; Rt[n] = Rl[2 + n]; }
+    xtile_tracer_face<NF>(P, fx, X, Lt, Rt, F, true, ruf);
+    if (!SHUF) {
+#pragma unroll
+      for (int f = 0; f < NF; f++) st[f * T + X.slot] = F[f];
+    }
+  }
+  if (!SHUF) __syncthreads();
+  if (X.upd) {
+    double Fhi[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) Fhi[f] = SHUF ? xtile_shfl(F[f], S.r) : st[f * T + X.slot_r];
+    xtile_tracer_finish<NF, STAGE, 1>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
+  }
+}
 // TILE form of the fused x-sweep (xtile_* in awfl_device.h): a lane per cell, right-edge values and face fluxes exchanged through
 // LDS (XT_NS doubles per lane, used twice) -- or, SHUF, by wavefront shuffles when a line lies inside one wavefront.
 // grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
@@ -377,6 +451,16 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   // cost what the nine chained look-ups of a boundary-level lane save)
   XShuf S = {};
   if (SHUF) S = xtile_shuffle_lanes(P, G, tid & 63, (int)threadIdx.x, (int)threadIdx.y);
+  if (blockIdx.z > 0) {
+    // tracers_inline == 2: z slice p >= 1 of the launch is phase 1 of the p-th pair of further tracers, beside the state pass (slice 0)
+    const int i = 2 * ((int)blockIdx.z - 1);
+    const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
+    if (i + 1 < P.nt - 1)
+      xtr_tile_run_own_flux<STAGE, 2, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+    else
+      xtr_tile_run_own_flux<STAGE, 1, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
+    return;
+  }
   double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
   int fields[XT_NS];
   xtile_state_fields(P, fields);
@@ -420,7 +504,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   }
   // phase 1 of the further tracers (their FCT multipliers) inline -- small ensembles, where a launch costs more than the work: the
   // mass flux through the lane's left face is still in its register
-  if (tracers_inline) {
+  if (tracers_inline == 1) {
     for (int i = 0; i < P.nt - 1; i += 2) {
       const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
       if (!SHUF) __syncthreads();
@@ -741,6 +825,7 @@ struct pam_amd_awfl {
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
   int tile_pressure_mode = 0;  // 0 automatic, 1 separate pressure pass, 2 inside the x tile kernel
   bool tile_pressure = true;   // x tile kernels: the next stage's pressure inside awfl_xupd_tile_kernel (no awfl_ptail_kernel launch)
+  bool tile_tracers_parallel = false;   // ... and phase 1 of the further tracers in z slices of that launch BESIDE the state pass (idle CUs)
   int ftile_mode = 0;          // 0 automatic, 1 flat-lane sweeps, 2 tile kernel
   bool ftile = true;           // resolved -- flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
   int ft_tc_y = 0, ft_tc_z = 0;          // cells / levels per y / z tile (0 = automatic)
@@ -1015,14 +1100,19 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     const size_t lds_pair = shuf ? 0 : (size_t)2 * (threads + xtile_stage_elems(G)) * sizeof(double);
     {
       ScopedTimer st(h, "xupd", s);
+      // phase 1 of the further tracers: 0 in a launch of its own (below), 1 inline behind the state pass, 2 in z slices of this launch
+      // beside the state pass (small grids with idle CUs)
+      const int npairs_x = (P.nt - 1 + 1) / 2;
+      const int tr_mode = h->tile_pressure ? ((h->tile_tracers_parallel && npairs_x > 0 && npairs_x < 65535) ? 2 : 1) : 0;
+      const dim3 sgrid(grid.x, grid.y, tr_mode == 2 ? (unsigned)(1 + npairs_x) : 1u);
       if (shuf)
-        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), grid, block, lds_state, s, P, G, prim_in, prim0,
+        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), sgrid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? 1 : 0, tr_mode);
       else
-        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), grid, block, lds_state, s, P, G, prim_in, prim0,
+        hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), sgrid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, h->tile_pressure ? 1 : 0);
+                           h->tile_pressure ? 1 : 0, tr_mode);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
@@ -1273,7 +1363,16 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   choose_flux_tiles(h);
   // the pressure pass inside the x tile kernel while a stage is a handful of short launches (one launch of ~10 us less); above, the
   // separate pass with the pow tables in LDS and 6 levels per lane is cheaper than the tile kernel's longer lanes
-  h->tile_pressure = h->tile_pressure_mode == 2 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
+  h->tile_pressure = h->tile_pressure_mode == 2 || h->tile_pressure_mode == 3 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
+  // phase 1 of the further tracers beside the state pass instead of behind it, when every workgroup of such a launch still finds a CU
+  // of its own (the tracer workgroups rebuild the face mass flux: two more polynomials per cell on CUs that would be idle).  Measured
+  // (round 5): the 250 x 1 x 50 shape with 4 tracers, 50 -> 150 workgroups: x kernel 18.3 -> 13.x us
+  {
+    const long long nwg = (long long)h->xg.ntl * h->xg.nmb * (((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb);
+    const int npairs_x = (P.nt - 1 + 1) / 2;
+    h->tile_tracers_parallel = h->tile_pressure && npairs_x > 0 &&
+                               (h->tile_pressure_mode == 3 || (h->tile_pressure_mode == 0 && nwg * (1 + npairs_x) <= (long long)h->ncu));
+  }
 }
 
 // (Re)build the chunk list: n contiguous member ranges whose sizes are multiples of 64 where possible.
@@ -2057,7 +2156,8 @@ int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_ti
 
 int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
-  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_tile_fusion: 0 = automatic, 1 = separate pressure pass, 2 = inside the x tile kernel");
+  if (mode < 0 || mode > 3)
+    return fail(PAM_AMD_EINVAL, "set_tile_fusion: 0 = automatic, 1 = separate launches, 2 = inside the x tile kernel (tracer phase 1 behind the state pass), 3 = inside, tracer phase 1 in workgroups beside it");
   h->tile_pressure_mode = mode;
   resolve_lane_mapping(h);
   return PAM_AMD_OK;

@@ -276,8 +276,9 @@ class Dycore:
                                                    int(levels_per_z_tile)))
 
     def set_tile_fusion(self, mode="auto"):
-        """x tile kernels: the pressure pass "inside" the tile kernel | "separate" | "auto" """
-        check(self._lib.pam_amd_awfl_set_tile_fusion(self._h, {"auto": 0, "separate": 1, "inside": 2}[mode]))
+        """x tile kernels: the pressure pass and tracer phase 1 "inside" the tile kernel (phase 1 behind the state pass) | "beside" (inside the
+        launch, phase 1 in workgroups of its own) | "separate" launches | "auto" """
+        check(self._lib.pam_amd_awfl_set_tile_fusion(self._h, {"auto": 0, "separate": 1, "inside": 2, "beside": 3}[mode]))
 
     def set_graph_replay(self, mode="auto"):
         """a whole timeStep replayed from a captured HIP graph: "on" | "off" | "auto" (launch-bound ensembles)"""

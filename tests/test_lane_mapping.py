@@ -52,7 +52,8 @@ def _fields(case):
     return f, xlen, ylen
 
 
-def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=("auto", 0, 0), graph="auto", dts=(2.0, 0.7), xex="auto"):
+def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=("auto", 0, 0), graph="auto", dts=(2.0, 0.7), xex="auto",
+         fusion=None):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts, limiter, tiles = CASES[case]
@@ -76,7 +77,7 @@ def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=
     if xex != "auto":
         dycore.set_x_exchange(xex)
     dycore.set_flux_tile(*ftile)
-    dycore.set_tile_fusion("inside" if ftile[0] == "tile" else ("separate" if ftile[0] == "sweep" else "auto"))
+    dycore.set_tile_fusion(fusion or ("inside" if ftile[0] == "tile" else ("separate" if ftile[0] == "sweep" else "auto")))
     dycore.set_graph_replay(graph)
     mapping = dycore.get_lane_mapping()
     coupler.load_fields(f)
@@ -106,8 +107,12 @@ def test_flat_lanes_and_tile_kernels_equal_member_lanes_and_sweeps_bit_for_bit(c
     variants = [("flat", "sweep", (0, 0, 0), ("tile", 0, 0)), ("member", "tile", (0, 0, 0), ("auto", 0, 0)), ("flat", "tile", (0, 0, 0), ("tile", 0, 0)),
                 ("flat", "tile", (0, 0, 0), ("sweep", 0, 0)), ("flat", "sweep", (0, 0, 0), ("tile", 2, 3)), ("flat", "tile", (0, 0, 0), ("tile", 5, 14))]
     variants += [("flat", "tile", t, ("auto", 0, 0)) for t in tiles]
-    for yz, xk, tile, ftile in variants:
-        n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile, ftile=ftile)
+    variants = [v + (None,) for v in variants]
+    # tracer phase 1 in workgroups BESIDE the state pass (they rebuild the face mass flux themselves) and BEHIND it, LDS exchange
+    variants += [("flat", "tile", (0, 0, 0), ("auto", 0, 0), "beside"), ("flat", "tile", (0, 0, 0), ("auto", 0, 0), "inside")]
+    variants += [("flat", "tile", t, ("auto", 0, 0), "beside") for t in tiles]
+    for yz, xk, tile, ftile, fusion in variants:
+        n1, got, m1, _ = _run(case, f, xlen, ylen, yz, xk, tile, ftile=ftile, fusion=fusion, xex="lds" if fusion else "auto")
         assert m1["yz_flat"] == (yz == "flat") and m1["x_tiles"] == (xk == "tile"), m1
         if yz == "flat" and ftile[0] != "auto":
             assert m1["yz_tile_kernel"] == (ftile[0] == "tile"), m1
@@ -132,8 +137,9 @@ def test_wavefront_shuffle_exchange_equals_the_lds_exchange_and_the_sweeps_bit_f
     for tile in [(0, 0, 0)] + [t for t in tiles if t[1] == 0]:      # (whole-line tiles: tiles of cells with halo rows exchange through LDS)
         for ftile in (("auto", 0, 0), ("sweep", 0, 0)):         # ("sweep": the pressure pass and tracer phase 1 as launches of their own)
             outs = {}
-            for xex in ("lds", "shuffle", "auto"):
-                n1, got, m1, _ = _run(case, f, xlen, ylen, "flat", "tile", tile, ftile=ftile, xex=xex)
+            for xex in ("lds", "shuffle", "auto", "shuffle+beside"):      # (beside: tracer phase 1 in workgroups of its own, shuffle form)
+                n1, got, m1, _ = _run(case, f, xlen, ylen, "flat", "tile", tile, ftile=ftile, xex=xex.split("+")[0],
+                                      fusion="beside" if "+" in xex else None)
                 assert m1["x_tiles"] and m1["x_shuffles"] == (xex != "lds"), (xex, m1)
                 assert n1 == n0
                 outs[xex] = got
