@@ -190,6 +190,11 @@ int pam_amd_awfl_set_x_exchange(pam_amd_awfl_t *h, int mode);
  * walks its line serially): enable = 0 automatic (tile kernel while the whole ensemble is below ~2.6e5 cells), 1 sweeps, 2 tile
  * kernel; cells per y tile / levels per z tile, 0 = automatic.  Same bits either way. */
 int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_tile, int levels_per_z_tile);
+/* The parts of a y/z flux tile -- the acoustic triple (face mass flux + normal momentum) and the groups of three advected quantities --
+ * run BEHIND each other in one workgroup (mode 1: one exchange + barrier per part, a serial chain) or BESIDE each other in workgroups
+ * of their own (mode 2: the workgroups of the advected groups rebuild the face mass flux from the polynomials of rho*u_n and p
+ * instead of waiting for it: same values, same functions, same bits); 0 = automatic.  (ABI 4) */
+int pam_amd_awfl_set_flux_tile_parts(pam_amd_awfl_t *h, int mode);
 /* x tile kernels of small ensembles, where a launch costs more than its work: the state kernel (awfl_xupd_tile_kernel) also makes the
  * next stage's pressure + density / pressure ghosts (Dycore.h:310-321, :682-709; otherwise awfl_ptail_kernel) and phase 1 of the
  * further tracers (their FCT multipliers, Dycore.h:525-540; otherwise awfl_xtr_tile_kernel<., 1>): two launches less per stage.

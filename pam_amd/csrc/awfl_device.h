@@ -2555,7 +2555,9 @@ PAMA_D void ftile_weno(const Params &P, const FLane &X, const WenoConsts &wc, co
   }
 }
 // group 0, A: rho*u_n, p, u_n
-template <int DIR, bool VZ_PER_ENS>
+//   WITH_N false: only rho*u_n and p (what the face mass flux needs) -- the workgroups that take one group of advected quantities
+//   BESIDE the acoustic workgroup rebuild the mass flux themselves (flux_tile_part)
+template <int DIR, bool VZ_PER_ENS, bool WITH_N = true>
 PAMA_D void ftile_acoustic_polys(const Params &P, const double *__restrict__ prim, const FLane &X, double (&L)[FT_NG], double (&R)[FT_NG]) {
   const WenoConsts wc = weno_consts();
   const int ncomp = (DIR == 1) ? P_V : P_W;
@@ -2569,7 +2571,8 @@ PAMA_D void ftile_acoustic_polys(const Params &P, const double *__restrict__ pri
   }
   ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, m, L[0], R[0]);
   ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, p, L[1], R[1]);
-  ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, n, L[2], R[2]);
+  if (WITH_N) ftile_weno<DIR, VZ_PER_ENS>(P, X, wc, n, L[2], R[2]);
+  else L[2] = R[2] = 0.0;
 }
 // group 0, B: face mass flux (stored as a face by the lane that owns it) and normal-momentum flux (Dycore.h:341-366,:477-496)
 template <int DIR>

@@ -608,12 +608,86 @@ __device__ __forceinline__ void flux_tile_run(const Params &P, const FTileGeom &
     }
   }
 }
+// The same tile with its parts BESIDE each other instead of behind each other (small grids with idle CUs; round 5): `part` 0 = the
+// acoustic triple (face mass flux, stored; normal-momentum difference), part g + 1 = group g of the advected quantities in a workgroup
+// of its own, which rebuilds the face mass flux from the polynomials of rho*u_n and p -- the same products and the same weno /
+// acoustic_face as part 0: the same bits -- instead of waiting for it.  One exchange per workgroup instead of one per group in a chain.
+template <int DIR, bool VZ_PER_ENS>
+__device__ __forceinline__ void flux_tile_part(const Params &P, const FTileGeom &G, int bx, int by, int T, const int (*grp)[FT_NG],
+                                               int ngroups, int part, const double *__restrict__ prim, double *__restrict__ flux,
+                                               double *lds) {
+  if (part > ngroups) return;
+  const int rows = ftile_rows(G), per = rows * G.W;
+  const int t = (int)threadIdx.x;
+  const int tz = t / per, r = t - tz * per, ty = r / G.W, tx = r - ty * G.W;
+  FLane X = ftile_lane<DIR>(P, G, bx, by, tx, ty, tz < G.lpb ? tz : 0);
+  if (tz >= G.lpb) { X.poly = X.face = X.own = X.pay = false; X.slot = X.slot_l = X.slot_r = 0; }
+  double *ldsA = lds, *ldsR = lds + FT_NG * T, *ldsF = lds + 2 * FT_NG * T;
+  const int ncomp_a = (DIR == 1) ? 1 : 2;
+  double La[FT_NG], Ra[FT_NG], L[FT_NG], R[FT_NG], F[FT_NG], ruf = 0.0, fn = 0.0;
+  if (part == 0) {
+    if (X.poly) {
+      ftile_acoustic_polys<DIR, VZ_PER_ENS>(P, prim, X, La, Ra);
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++) ldsA[n * T + X.slot] = Ra[n];
+    }
+    __syncthreads();
+    if (X.face) {
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++) Ra[n] = ldsA[n * T + X.slot_l];
+      ftile_acoustic_face<DIR>(P, flux, X, La, Ra, ruf, fn);
+      ldsF[X.slot] = fn;
+    }
+    __syncthreads();
+    if (X.pay) ftile_store_diff<DIR>(P, flux, X, ncomp_a, fn, ldsF[X.slot_r]);
+    return;
+  }
+  const int g = part - 1;
+  int fa[FT_NG], nf = 0;
+  bool has_state = false;
+#pragma unroll
+  for (int n = 0; n < FT_NG; n++) { fa[n] = grp[g][n]; nf += (fa[n] >= 0) ? 1 : 0; has_state |= (fa[n] >= 0 && fa[n] < 4); }
+  if (X.poly) {
+    ftile_acoustic_polys<DIR, VZ_PER_ENS, false>(P, prim, X, La, Ra);
+    ftile_adv_polys<DIR, VZ_PER_ENS>(P, prim, X, fa, nf, L, R);
+#pragma unroll
+    for (int n = 0; n < 2; n++) ldsA[n * T + X.slot] = Ra[n];
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) ldsR[n * T + X.slot] = R[n];
+  }
+  __syncthreads();
+  if (X.face) {
+    double ppf;
+    acoustic_face(ldsA[X.slot_l], La[0], ldsA[T + X.slot_l], La[1], (DIR == 2) && X.wall, ruf, ppf);     // (as ftile_acoustic_face)
+#pragma unroll
+    for (int n = 0; n < FT_NG; n++) R[n] = ldsR[n * T + X.slot_l];
+    ftile_adv_face<DIR>(P, flux, X, fa, nf, L, R, ruf, F);
+    if (has_state) {
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++) ldsF[n * T + X.slot] = F[n];
+    }
+  }
+  if (has_state) {            // (wave-uniform: the group is the workgroup's)
+    __syncthreads();
+    if (X.pay) {
+#pragma unroll
+      for (int n = 0; n < FT_NG; n++)
+        if (fa[n] >= 0 && fa[n] < 4) ftile_store_diff<DIR>(P, flux, X, fa[n], F[n], ldsF[n * T + X.slot_r]);
+    }
+  }
+}
+// parts: 0 = every part of a tile in one workgroup, one behind the other; 1 = grid.y indexes the part (flux_tile_part)
 template <bool VZ_PER_ENS>
 __global__ void __launch_bounds__(1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
                                                               const double *__restrict__ prim, double *__restrict__ fy,
-                                                              double *__restrict__ fz) {
+                                                              double *__restrict__ fz, int parts) {
   extern __shared__ double ft_lds[];
   const int T = (int)blockDim.x, b = (int)blockIdx.x;
+  if (parts) {
+    if (b < nby) flux_tile_part<1, VZ_PER_ENS>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, (int)blockIdx.y, prim, fy, ft_lds);
+    else flux_tile_part<2, VZ_PER_ENS>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, (int)blockIdx.y, prim, fz, ft_lds);
+    return;
+  }
   if (b < nby) flux_tile_run<1, VZ_PER_ENS>(P, Gy, b % gyx, b / gyx, T, Q.gy, Q.ny_groups, prim, fy, ft_lds);
   else flux_tile_run<2, VZ_PER_ENS>(P, Gz, b - nby, 0, T, Q.gz, Q.nz_groups, prim, fz, ft_lds);
 }
@@ -830,6 +904,8 @@ struct pam_amd_awfl {
   bool ftile = true;           // resolved -- flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
   int ft_tc_y = 0, ft_tc_z = 0;          // cells / levels per y / z tile (0 = automatic)
   int ft_auto_y = 0, ft_auto_z = 0;      // ... the automatic choice (choose_flux_tiles; 0 = ftile_geometry's own default)
+  int ftile_parts_mode = 0;              // 0 automatic, 1 the parts of a tile behind each other (one workgroup), 2 beside each other
+  bool ftile_parts = false;              // resolved
   int ncu = 0;                           // compute units of the handle's device
   XTileGeom xg;
   bool fused = false;          // fused x-sweep + state update (needs the third state buffer prim2)
@@ -973,8 +1049,13 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     if (T > 1024) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes");
     const size_t lds = (size_t)(2 * FT_NG + 4) * T * sizeof(double);
     ScopedTimer st(h, "flux", s);
-    if (P.vz_per_ens) hipLaunchKernelGGL(awfl_flux_tile_kernel<true>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
-    else hipLaunchKernelGGL(awfl_flux_tile_kernel<false>, dim3(nby + nbz), dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z);
+    // the parts of a tile (acoustic triple, groups of advected quantities) beside each other in workgroups of their own -- grid.y --
+    // while every workgroup still finds a CU of its own (choose: resolve_lane_mapping), else behind each other in one workgroup
+    const int maxg = Q.ny_groups > Q.nz_groups ? Q.ny_groups : Q.nz_groups;
+    const int parts = h->ftile_parts ? 1 : 0;
+    const dim3 fgrid((unsigned)(nby + nbz), parts ? (unsigned)(1 + maxg) : 1u, 1u);
+    if (P.vz_per_ens) hipLaunchKernelGGL(awfl_flux_tile_kernel<true>, fgrid, dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z, parts);
+    else hipLaunchKernelGGL(awfl_flux_tile_kernel<false>, fgrid, dim3(T), lds, s, P, Gy, Gz, Q, nby, gyx > 0 ? gyx : 1, prim, h->flux_y, h->flux_z, parts);
     HIP_TRY(hipGetLastError());
     return PAM_AMD_OK;
   }
@@ -1361,6 +1442,7 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // build no halo rows; measured on MI355X, 32x32x60: 1 member 67 -> 20 us per stage, 8 members 85 -> 82, 32 members 184 -> 320)
   h->ftile = h->ftile_mode == 2 || (h->ftile_mode == 0 && P.ncell <= 262144);
   choose_flux_tiles(h);
+  h->ftile_parts = h->ftile_parts_mode == 2;
   // the pressure pass inside the x tile kernel while a stage is a handful of short launches (one launch of ~10 us less); above, the
   // separate pass with the pow tables in LDS and 6 levels per lane is cheaper than the tile kernel's longer lanes
   h->tile_pressure = h->tile_pressure_mode == 2 || h->tile_pressure_mode == 3 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
@@ -2150,6 +2232,14 @@ int pam_amd_awfl_set_flux_tile(pam_amd_awfl_t *h, int enable, int cells_per_y_ti
   h->ftile_mode = enable;
   h->ft_tc_y = cells_per_y_tile;
   h->ft_tc_z = levels_per_z_tile;
+  resolve_lane_mapping(h);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_flux_tile_parts(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_flux_tile_parts: 0 = automatic, 1 = behind each other (one workgroup per tile), 2 = beside each other");
+  h->ftile_parts_mode = mode;
   resolve_lane_mapping(h);
   return PAM_AMD_OK;
 }
