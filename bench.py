@@ -60,6 +60,8 @@ CONFIGS = {
     "c2": (1024, 32, 32, "none", "default", 2.0, "AWFL supercell idealized, nens=%d/GPU, 32x32x60 L60, NT=1, fp64"),
     "c3": (4096, 32, 1, "kessler_shoc", "default", 2.0, "AWFL moist (4 advected tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
     "c4": (512, 32, 1, "p3_shoc", "p3", 2.0, "AWFL + P3/SHOC tracer set (10 tracers), nens=%d/GPU, 2-D 32x1x60 L60, fp64"),
+    # C2's 3-D grid with the Kessler + SHOC tracer set (not a BASELINE config: the 3-D many-tracer case of the small-ensemble kernels)
+    "c2k": (1024, 32, 32, "kessler_shoc", "default", 2.0, "AWFL moist 3-D (4 advected tracers), nens=%d/GPU, 32x32x60 L60, fp64"),
     # the shape of the reference's own input file (standalone/mmf_simplified/inputs/input_pama.yaml: crm_nx 250, crm_ny 1,
     # nens 1, 50 equal levels to 20 km, xlen 128 km) with the Kessler + SHOC tracer registrations
     "ref": (1, 250, 1, "kessler_shoc", "default", 2.0, "reference input shape (input_pama.yaml), nens=%d/GPU, 2-D 250x1x50 uniform 20 km, NT=4, fp64",

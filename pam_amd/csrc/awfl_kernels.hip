@@ -1442,18 +1442,36 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // build no halo rows; measured on MI355X, 32x32x60: 1 member 67 -> 20 us per stage, 8 members 85 -> 82, 32 members 184 -> 320)
   h->ftile = h->ftile_mode == 2 || (h->ftile_mode == 0 && P.ncell <= 262144);
   choose_flux_tiles(h);
-  h->ftile_parts = h->ftile_parts_mode == 2;
+  // the parts of a flux tile BESIDE each other while every part's workgroup can be resident at once (16 wavefronts per CU at the
+  // kernel's ~110 registers); measured (round 5): the 250 x 1 x 50 shape, 100 -> 300 workgroups of 256 lanes: 12.7 -> 9.6 us; 32x32x60 with
+  // one member, 248 -> 744 workgroups of 640 lanes (one per CU at a time): 16.8 -> 24.4 us
+  {
+    const FTileGeom Gy = ftile_geometry(P, 1, h->ft_tc_y ? h->ft_tc_y : h->ft_auto_y), Gz = ftile_geometry(P, 2, h->ft_tc_z ? h->ft_tc_z : h->ft_auto_z);
+    const long long nby = P.sim2d ? 0 : (long long)Gy.nch * Gy.ntl * ((P.nz + Gy.lpb - 1) / Gy.lpb), nbz = (long long)Gz.nch * Gz.ntl;
+    int T = ftile_threads(Gz);
+    if (!P.sim2d && ftile_threads(Gy) > T) T = ftile_threads(Gy);
+    T = ((T + 63) / 64) * 64;
+    const int nadv = 3 + P.nt - (P.sim2d ? 1 : 0), maxg = (nadv + FT_NG - 1) / FT_NG;      // groups of advected quantities per sweep
+    const long long per_cu = T > 0 ? 16 / (T / 64) : 0;
+    h->ftile_parts = h->ftile_parts_mode == 2 ||
+                     (h->ftile_parts_mode == 0 && h->ncu > 0 && per_cu > 0 && (nby + nbz) * (1 + maxg) <= (long long)h->ncu * per_cu);
+  }
   // the pressure pass inside the x tile kernel while a stage is a handful of short launches (one launch of ~10 us less); above, the
   // separate pass with the pow tables in LDS and 6 levels per lane is cheaper than the tile kernel's longer lanes
   h->tile_pressure = h->tile_pressure_mode == 2 || h->tile_pressure_mode == 3 || (h->tile_pressure_mode == 0 && P.ncell <= 1048576);
-  // phase 1 of the further tracers beside the state pass instead of behind it, when every workgroup of such a launch still finds a CU
-  // of its own (the tracer workgroups rebuild the face mass flux: two more polynomials per cell on CUs that would be idle).  Measured
-  // (round 5): the 250 x 1 x 50 shape with 4 tracers, 50 -> 150 workgroups: x kernel 18.3 -> 13.x us
+  // phase 1 of the further tracers beside the state pass instead of behind it, while the launch's workgroups fit the chip about twice
+  // over (16 wavefronts per CU at the kernel's ~120 registers; the tracer workgroups rebuild the face mass flux: two more polynomials
+  // per cell on SIMDs that would be idle).  Measured (round 5, profiles/r05_ab_experiments.txt): the 250 x 1 x 50 shape with 4 tracers,
+  // 50 -> 150 workgroups: x kernel 18.5 -> 13.6 us, 0.112 -> 0.127 G; 32x32x60 with 4 tracers: one member 0.450 -> 0.496 G, two 0.651 ->
+  // 0.688 G; a single 2-D column set with 10 tracers (32 x 1 x 60): x kernel 20.7 -> 11.6 us
   {
     const long long nwg = (long long)h->xg.ntl * h->xg.nmb * (((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb);
     const int npairs_x = (P.nt - 1 + 1) / 2;
+    const int T = ((xtile_threads(h->xg) + 63) / 64) * 64;
+    const long long per_cu = 16 / (T / 64 > 0 ? T / 64 : 1);       // workgroups a CU holds at the kernel's ~120 registers (16 wavefronts)
     h->tile_tracers_parallel = h->tile_pressure && npairs_x > 0 &&
-                               (h->tile_pressure_mode == 3 || (h->tile_pressure_mode == 0 && nwg * (1 + npairs_x) <= (long long)h->ncu));
+                               (h->tile_pressure_mode == 3 ||
+                                (h->tile_pressure_mode == 0 && h->ncu > 0 && per_cu > 0 && nwg * (1 + npairs_x) <= 2 * (long long)h->ncu * per_cu));
   }
 }
 
