@@ -342,6 +342,8 @@ class Job:
             dycore.set_tile_fusion(args.tilefusion)
         if args.ftileparts != "auto":
             dycore.set_flux_tile_parts(args.ftileparts)
+        if args.stateparts != "auto":
+            dycore.set_tile_state_parts(args.stateparts)
         if args.ftile:
             ty, tz = [int(v) for v in args.ftile.split(",")]
             dycore.set_flux_tile("auto", ty, tz)
@@ -944,6 +946,7 @@ def main():
     ap.add_argument("--tilefusion", default="auto", choices=("auto", "separate", "inside", "beside"),
                     help="x tile kernels of small ensembles: pressure pass / tracer phase 1 in launches of their own, inside the state kernel, "
                          "or inside its launch with phase 1 in workgroups beside the state pass")
+    ap.add_argument("--stateparts", default="auto", choices=("auto", "one", "parts"), help="fused x tile kernel: the state pass by one lane / in three parts beside each other")
     ap.add_argument("--ftileparts", default="auto", choices=("auto", "behind", "beside"), help="y/z flux tile kernel: the parts of a tile behind / beside each other")
     ap.add_argument("--ftile", default="", help="y/z flux tile kernel: cells per y tile,levels per z tile (0 = automatic each)")
     ap.add_argument("--xexchange", default="auto", choices=("auto", "lds", "shuffle"),

@@ -203,6 +203,12 @@ int pam_amd_awfl_set_flux_tile_parts(pam_amd_awfl_t *h, int mode);
  * waiting for it: same values, same functions, same bits), 1 = separate launches, 0 = automatic (fused while the ensemble is below ~1e6
  * cells; beside the state pass while every workgroup of the launch still finds a CU of its own).  Same bits either way. */
 int pam_amd_awfl_set_tile_fusion(pam_amd_awfl_t *h, int mode);
+/* The state pass of the fused x tile kernel (seven polynomials, face, finish, pressure: one chain per lane) in THREE parts beside each
+ * other -- u (+ the stores of the new density and the face mass flux) | v, w | theta, pressure, water vapour -- in workgroups of their
+ * own (z slices of the launch), each rebuilding the polynomials of rho*u and p, the face mass flux and the new density instead of
+ * waiting for them: same values, same functions, same bits.  mode 2 = parts, 1 = one lane per cell does all, 0 = automatic (parts while
+ * every workgroup of the launch can be resident at once).  Implies tracer phase 1 beside the state pass.  (ABI 4) */
+int pam_amd_awfl_set_tile_state_parts(pam_amd_awfl_t *h, int mode);
 /* Launch-bound ensembles: a whole time_step (coupler -> dycore, every stage, dycore -> coupler: ~10 launches per sub-step of a few
  * microseconds each) is captured once into a HIP graph on an internal stream and replayed -- one graph per (coupler arrays, number
  * of sub-cycles, buffer parity); the caller's stream is ordered before and after it with events.  mode 2 = on (fused stage, one

@@ -67,6 +67,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_x_tile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pam_amd_awfl_set_x_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_flux_tile_parts": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_set_tile_state_parts": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_tracer_grouping": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pam_amd_awfl_set_flux_tile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pam_amd_awfl_set_tile_fusion": (C.c_int, [C.c_void_p, C.c_int]),

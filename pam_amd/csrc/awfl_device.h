@@ -2145,21 +2145,24 @@ constexpr int XT_NS = 7;    // right-edge values a lane hands to its right neigh
 constexpr int XT_NF = 6;    // face fluxes a lane hands to its left neighbour: rho, rho u, rho v, rho w, rho theta, vapour
 // phase 0: the lane's share of the staged tile.  fields[f]: prim field index of staged field f; st: the staged fields, TS elements
 // each; own[f]: the values of the lane's own cell (kept in registers: the centre of its stencils)
+//   fmask: bit f set = staged field f is needed (the parts of the state pass stage only their own fields)
 template <int NSF>
 PAMA_D void xtile_stage(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double *st, int TS,
-                        double (&own)[NSF]) {
+                        double (&own)[NSF], unsigned fmask = ~0u) {
   // every load is issued before the first LDS store (a loop of load -> store per cell would wait for each load in turn)
   double v1[NSF], v2[NSF];
   const bool has0 = X.nstage > 0, has1 = X.nstage > 1, has2 = X.nstage > 2;
 #pragma unroll
   for (int f = 0; f < NSF; f++) {
+    const bool need = ((fmask >> f) & 1u) != 0;
     gc_ptr fp = uni(prim_in + (long long)fields[f] * P.prim_fs);
-    own[f] = has0 ? fp[X.stage_po[0]] : 0.0;
-    v1[f] = has1 ? fp[X.stage_po[1]] : 0.0;
-    v2[f] = has2 ? fp[X.stage_po[2]] : 0.0;
+    own[f] = (has0 && need) ? fp[X.stage_po[0]] : 0.0;
+    v1[f] = (has1 && need) ? fp[X.stage_po[1]] : 0.0;
+    v2[f] = (has2 && need) ? fp[X.stage_po[2]] : 0.0;
   }
 #pragma unroll
   for (int f = 0; f < NSF; f++) {
+    if (!((fmask >> f) & 1u)) continue;
     if (has0) st[f * TS + X.stage_el[0]] = own[f];
     if (has1) st[f * TS + X.stage_el[1]] = v1[f];
     if (has2) st[f * TS + X.stage_el[2]] = v2[f];
@@ -2195,9 +2198,15 @@ PAMA_D double xtile_shfl(double v, int) { return v; }     // (host emulation: th
 #endif
 // the stage-input values of the lane's own cell (whole-line tiles: every lane stages exactly its own cell)
 template <int NSF>
-PAMA_D void xtile_load_own(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double (&own)[NSF]) {
+PAMA_D void xtile_load_own(const Params &P, const double *__restrict__ prim_in, const XLane &X, const int (&fields)[NSF], double (&own)[NSF],
+                           unsigned fmask = ~0u) {
 #pragma unroll
-  for (int f = 0; f < NSF; f++) own[f] = (X.nstage > 0) ? uni(prim_in + (long long)fields[f] * P.prim_fs)[X.stage_po[0]] : 0.0;
+  for (int f = 0; f < NSF; f++)
+    own[f] = (X.nstage > 0 && ((fmask >> f) & 1u)) ? uni(prim_in + (long long)fields[f] * P.prim_fs)[X.stage_po[0]] : 0.0;
+}
+// staged fields (rho, p, u, v, w, theta, vapour) a part of the state pass needs
+PAMA_HD unsigned xtile_part_fields(int part) {
+  return 0x7u | ((part & 2) ? 0x18u : 0u) | ((part & 4) ? 0x60u : 0u);
 }
 PAMA_D void xtile_state_fields(const Params &P, int (&fields)[XT_NS]) {
   fields[0] = P_RHO; fields[1] = P_PRES; fields[2] = P_U; fields[3] = P_V; fields[4] = P_W; fields[5] = P_THETA; fields[6] = P_TR0 + P.idWV;
@@ -2207,7 +2216,16 @@ PAMA_D void xtile_state_fields(const Params &P, int (&fields)[XT_NS]) {
 // density
 //   nb(f, s): the value of staged field f in the cell s - 2 cells away (s = 0, 1, 3, 4) -- from the LDS image of the tile, or (a line
 //   that lies inside ONE wavefront) from the lane that holds it, by a wavefront shuffle (XShuf below)
-template <class Neighbour>
+// PARTS of the state pass (round 5).  The state pass of a cell is one chain -- seven polynomials, the face, the finish, the pressure.
+// On a small grid with idle SIMDs it is cut into three parts that run BESIDE each other in workgroups of their own (z slices of the
+// launch), each rebuilding what it needs of the others instead of waiting for it -- the polynomials of rho*u and p, the face mass flux
+// and the new density: the same products in the same functions, hence the same bits:
+//   XP_U   the acoustic part: u (normal momentum: mass flux x upwinded u + face pressure), and it STORES the new density and the face
+//          mass flux;                      XP_VW  v and w (gravity);
+//   XP_T   theta, the next stage's pressure (+ density / pressure ghosts) and water vapour (own multiplier, update, seed, x flux).
+// XP_ALL = the whole pass in one lane (every case where the chip is busy anyway).
+constexpr int XP_U = 1, XP_VW = 2, XP_T = 4, XP_ALL = 7;
+template <int PART = XP_ALL, class Neighbour>
 PAMA_D void xtile_state_polys_from(const Params &P, Neighbour &&nb, const double (&own)[XT_NS], double (&L)[XT_NS], double (&R)[XT_NS],
                                    double (&cen)[6]) {
   const WenoConsts wc = weno_consts();
@@ -2215,6 +2233,9 @@ PAMA_D void xtile_state_polys_from(const Params &P, Neighbour &&nb, const double
 #pragma unroll
     for (int s = 0; s < 5; s++) u[s] = (s == 2) ? own[f] : nb(f, s);
   };
+#pragma unroll
+  for (int f = 0; f < XT_NS; f++) L[f] = R[f] = 0.0;
+  cen[1] = cen[2] = cen[3] = cen[4] = 0.0;
   double r[5], u[5], w[5];
   stencil(0, r);
   stencil(2, u);
@@ -2223,25 +2244,27 @@ PAMA_D void xtile_state_polys_from(const Params &P, Neighbour &&nb, const double
   cen[0] = w[2];
   cen[5] = r[2];
   weno5_const(w, wc, L[0], R[0]);
-  weno5_const(u, wc, L[2], R[2]);
+  if (PART & XP_U) weno5_const(u, wc, L[2], R[2]);
   stencil(1, w);
   weno5_const(w, wc, L[1], R[1]);
-  cen[1] = own[3];
-  if (!P.sim2d) {
-    stencil(3, w);
-    weno5_const(w, wc, L[3], R[3]);
-  } else {                                                  // 2-D: the v flux is never used (skip_advected_v)
-    L[3] = R[3] = 0.0;
+  if (PART & XP_VW) {
+    cen[1] = own[3];
+    if (!P.sim2d) {
+      stencil(3, w);
+      weno5_const(w, wc, L[3], R[3]);
+    }                                                         // 2-D: the v flux is never used (skip_advected_v)
+    stencil(4, w);
+    cen[2] = w[2];
+    weno5_const(w, wc, L[4], R[4]);
   }
-  stencil(4, w);
-  cen[2] = w[2];
-  weno5_const(w, wc, L[4], R[4]);
-  stencil(5, w);
-  cen[3] = w[2];
-  weno5_const(w, wc, L[5], R[5]);
-  stencil(6, w);
-  cen[4] = w[2];
-  weno5_const(w, wc, L[6], R[6]);
+  if (PART & XP_T) {
+    stencil(5, w);
+    cen[3] = w[2];
+    weno5_const(w, wc, L[5], R[5]);
+    stencil(6, w);
+    cen[4] = w[2];
+    weno5_const(w, wc, L[6], R[6]);
+  }
 }
 PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st, int TS, const double (&own)[XT_NS],
                               double (&L)[XT_NS], double (&R)[XT_NS], double (&cen)[6]) {
@@ -2250,24 +2273,33 @@ PAMA_D void xtile_state_polys(const Params &P, const XLane &X, const double *st,
 // B: the fluxes through the lane's LEFT face from the right-edge values of the cell to its left (Rl) and its own left-edge values
 // (Dycore.h:341-386).  own_face: the face belongs to this tile (its cell is one the tile completes): the mass flux (when further
 // tracers follow) and water vapour's flux go to flux_x as in the sweep.
+template <int PART = XP_ALL>
 PAMA_D void xtile_state_face(const Params &P, double *__restrict__ fx, const XLane &X, const double (&L)[XT_NS],
                              const double (&Rl)[XT_NS], bool own_face, double (&F)[XT_NF]) {
   double ruf, ppf;
   acoustic_face(Rl[0], L[0], Rl[1], L[1], false, ruf, ppf);
   const bool up = ruf > 0.0;                               // upwind (Dycore.h:368)
-  const double Ft = mul_rn(ruf, up ? Rl[6] : L[6]);
-  if (own_face) {
-    if (P.nt > 1) uniw(fx)[X.io] = ruf;                     // for the tracer tiles
-    uniw(fx + (long long)(5 + P.idWV) * P.ncell)[X.io] = Ft;   // (read again where the limiter acts: tracer_fixup_line_body)
-  }
-  F[0] = ruf;
-  F[1] = fma(ruf, up ? Rl[2] : L[2], ppf);
 #pragma unroll
-  for (int n = 1; n < 4; n++) F[1 + n] = mul_rn(ruf, up ? Rl[2 + n] : L[2 + n]);
-  F[5] = Ft;
+  for (int n = 0; n < XT_NF; n++) F[n] = 0.0;
+  F[0] = ruf;
+  if (PART & XP_U) {
+    if (own_face && P.nt > 1) uniw(fx)[X.io] = ruf;         // for the tracer tiles
+    F[1] = fma(ruf, up ? Rl[2] : L[2], ppf);
+  }
+  if (PART & XP_VW) {
+#pragma unroll
+    for (int n = 1; n < 3; n++) F[1 + n] = mul_rn(ruf, up ? Rl[2 + n] : L[2 + n]);
+  }
+  if (PART & XP_T) {
+    const double Ft = mul_rn(ruf, up ? Rl[6] : L[6]);
+    if (own_face) uniw(fx + (long long)(5 + P.idWV) * P.ncell)[X.io] = Ft;   // (read again where the limiter acts: tracer_fixup_line_body)
+    F[4] = mul_rn(ruf, up ? Rl[5] : L[5]);
+    F[5] = Ft;
+  }
 }
-// C: the lane's cell complete (the `finish` of flux_x_update_body): Flo / Fhi = the fluxes through its left / right face
-template <int STAGE>
+// C: the lane's cell complete (the `finish` of flux_x_update_body): Flo / Fhi = the fluxes through its left / right face.
+// PART (above): which variables this lane finishes; the new density is formed by every part (same function, same inputs) and stored by XP_U
+template <int STAGE, int PART = XP_ALL>
 PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
                                double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
@@ -2280,34 +2312,41 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
   const unsigned kp1 = member_offset((int)(io + (unsigned)P.sz));
   const double dzk = P.dz[X.ke];
   const double rdzk = fast_rcp(dzk);
-  const double gcoef = gravity_coef(P, X.ke);
+  const double gcoef = (PART & XP_VW) ? gravity_coef(P, X.ke) : 0.0;
   const int tr = P.idWV;
   const double rho_in = cen[5];
   const double rho_0 = (STAGE > 1) ? uni(prim0 + (long long)P_RHO * P.prim_fs)[po] : 0.0;
+  // which of the four momentum / theta variables (n = 0 rho u, 1 rho v, 2 rho w, 3 rho theta) this part finishes
+  const bool mine[4] = {(PART & XP_U) != 0, (PART & XP_VW) != 0, (PART & XP_VW) != 0, (PART & XP_T) != 0};
   double q0[4];
 #pragma unroll
-  for (int n = 0; n < 4; n++) q0[n] = (STAGE > 1) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs)[po] : 0.0;
+  for (int n = 0; n < 4; n++) q0[n] = (STAGE > 1 && mine[n]) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs)[po] : 0.0;
   const double y0l = have_y ? uni(fy)[io] : 0.0, y0h = have_y ? uni(fy)[jp1] : 0.0;
   const double z0l = uni(fz)[io], z0h = uni(fz)[kp1];
   double dy[5], dz[5];
 #pragma unroll
   for (int l = 1; l <= 4; l++) {
-    dy[l] = have_y ? uni(fy + (long long)l * P.ncell)[io] : 0.0;
-    dz[l] = (l == 2 && !have_y) ? 0.0 : uni(fz + (long long)l * P.fz_fs)[io];     // 2-D: no v tendency, nothing stored
+    dy[l] = (have_y && mine[l - 1]) ? uni(fy + (long long)l * P.ncell)[io] : 0.0;
+    dz[l] = ((l == 2 && !have_y) || !mine[l - 1]) ? 0.0 : uni(fz + (long long)l * P.fz_fs)[io];     // 2-D: no v tendency, nothing stored
   }
-  const double tyl = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[io] : 0.0;
-  const double tyh = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[jp1] : 0.0;
-  const double tzl = uni(fz + (long long)(5 + tr) * P.fz_fs)[io], tzh = uni(fz + (long long)(5 + tr) * P.fz_fs)[kp1];
-  const double tseed = uni(seed + (long long)tr * P.ncell)[io];
-  const double tq0 = (STAGE > 1) ? uni(prim0 + (long long)(P_TR0 + tr) * P.prim_fs)[po] : 0.0;
+  double tyl = 0.0, tyh = 0.0, tzl = 0.0, tzh = 0.0, tseed = 0.0, tq0 = 0.0;
+  if (PART & XP_T) {
+    tyl = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[io] : 0.0;
+    tyh = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[jp1] : 0.0;
+    tzl = uni(fz + (long long)(5 + tr) * P.fz_fs)[io];
+    tzh = uni(fz + (long long)(5 + tr) * P.fz_fs)[kp1];
+    tseed = uni(seed + (long long)tr * P.ncell)[io];
+    tq0 = (STAGE > 1) ? uni(prim0 + (long long)(P_TR0 + tr) * P.prim_fs)[po] : 0.0;
+  }
   const unsigned lo = po - (unsigned)(k + HS) * (unsigned)P.sz;                     // the cell inside its level
 
   const double qn = rk_combine<STAGE>(rho_0, rho_in, dt_dyn, flux_divergence(P, Flo[0], Fhi[0], y0l, y0h, z0l, z0h, rdzk));
   const double rrho = fast_rcp(qn);
-  uniw(prim_out + (long long)P_RHO * P.prim_fs)[po] = qn;
+  if (PART & XP_U) uniw(prim_out + (long long)P_RHO * P.prim_fs)[po] = qn;
   const double q_in[4] = {0.0, cen[1], cen[2], cen[3]};
 #pragma unroll
   for (int n = 0; n < 4; n++) {
+    if (!mine[n]) continue;
     const int l = 1 + n;                                   // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
     double tend = flux_divergence_d(P, Flo[l], Fhi[l], dy[l], dz[l], rdzk);
     if (l == 3) tend = add_gravity(P, tend, rho_in, gcoef);
@@ -2323,12 +2362,14 @@ PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_
       else uniw(prim_out + (long long)P_PRES * P.prim_fs)[po] = v;
     }
   }
-  // water vapour (finish_tracer_cell): its own multiplier (sparse store + flags) and the update an unlimited neighbourhood gets
-  own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, tseed, dzk, rdzk, dt_stage);
-  double v, new_seed;
-  tracer_new_value<STAGE>(P, tr, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, cen[4], tq0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
-  uniw(seed + (long long)tr * P.ncell)[io] = new_seed;
-  store_adv_l(P, prim_out, P_TR0 + tr, k, lo, v * rrho, v * rrho);
+  if (PART & XP_T) {
+    // water vapour (finish_tracer_cell): its own multiplier (sparse store + flags) and the update an unlimited neighbourhood gets
+    own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, tseed, dzk, rdzk, dt_stage);
+    double v, new_seed;
+    tracer_new_value<STAGE>(P, tr, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, cen[4], tq0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+    uniw(seed + (long long)tr * P.ncell)[io] = new_seed;
+    store_adv_l(P, prim_out, P_TR0 + tr, k, lo, v * rrho, v * rrho);
+  }
 }
 
 // ---- tracer tiles (the arithmetic of x_tracer_sweep, cell by cell): NF further tracers per lane ------------------------------

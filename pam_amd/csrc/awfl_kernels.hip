@@ -430,6 +430,56 @@ __device__ __forceinline__ void xtr_tile_run_own_flux(const Params &P, const XLa
     xtile_tracer_finish<NF, STAGE, 1>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, fa, F, Fhi, cen, dt_dyn, dt_stage);
   }
 }
+// The state pass of a tile (or one PART of it: XP_U / XP_VW / XP_T, awfl_device.h) for the lane's cell; F: the fluxes through its left face
+template <int STAGE, bool SHUF, int PART>
+__device__ __forceinline__ void xupd_tile_state(const Params &P, const XLane &X, const XShuf &S, int T, int TS, const double *__restrict__ prim_in,
+                                                const double *__restrict__ prim0, double *__restrict__ prim_out, double *__restrict__ fx,
+                                                const double *__restrict__ fy, const double *__restrict__ fz, double *__restrict__ seed,
+                                                double *__restrict__ mult, const FctRows &rows, double dt_dyn, double dt_stage,
+                                                bool with_pressure, double *xt_lds, double (&F)[XT_NF]) {
+  double L[XT_NS], R[XT_NS], cen[6], own[XT_NS];
+  int fields[XT_NS];
+  xtile_state_fields(P, fields);
+  const unsigned fmask = xtile_part_fields(PART);
+  if (SHUF) {
+    xtile_load_own<XT_NS>(P, prim_in, X, fields, own, fmask);
+    if (X.poly) {
+      xtile_state_polys_from<PART>(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
+#pragma unroll
+      for (int f = 0; f < XT_NS; f++) R[f] = xtile_shfl(R[f], S.l);       // now: the right-edge values of the cell to the left
+      xtile_state_face<PART>(P, fx, X, L, R, X.upd, F);
+      double Fhi[XT_NF];
+#pragma unroll
+      for (int f = 0; f < XT_NF; f++) Fhi[f] = xtile_shfl(F[f], S.r);
+      xtile_state_finish<STAGE, PART>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure);
+    }
+  } else {
+    // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
+    double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
+    xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own, fmask);
+    __syncthreads();
+    if (X.poly) {
+      xtile_state_polys_from<PART>(P, [&](int f, int s) { return st[f * TS + X.s5[s]]; }, own, L, R, cen);
+#pragma unroll
+      for (int f = 0; f < XT_NS; f++) ex[f * T + X.slot] = R[f];
+    }
+    __syncthreads();
+    if (X.face) {
+#pragma unroll
+      for (int f = 0; f < XT_NS; f++) R[f] = ex[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
+      xtile_state_face<PART>(P, fx, X, L, R, X.upd, F);
+#pragma unroll
+      for (int f = 0; f < XT_NF; f++) st[f * T + X.slot] = F[f];          // (every stencil read of the staged tile is behind the barrier)
+    }
+    __syncthreads();
+    if (X.upd) {
+      double Fhi[XT_NF];
+#pragma unroll
+      for (int f = 0; f < XT_NF; f++) Fhi[f] = st[f * T + X.slot_r];
+      xtile_state_finish<STAGE, PART>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure);
+    }
+  }
+}
 // TILE form of the fused x-sweep (xtile_* in awfl_device.h): a lane per cell, right-edge values and face fluxes exchanged through
 // LDS (XT_NS doubles per lane, used twice) -- or, SHUF, by wavefront shuffles when a line lies inside one wavefront.
 // grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
@@ -439,7 +489,7 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
                                                               double *__restrict__ fx, const double *__restrict__ fy,
                                                               const double *__restrict__ fz, double *__restrict__ seed,
                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
-                                                              double dt_stage, int with_pressure, int tracers_inline) {
+                                                              double dt_stage, int with_pressure, int tracers_inline, int state_parts) {
   fct_rows_resolve(rows);
   extern __shared__ double xt_lds[];
   const int T = (int)(blockDim.x * blockDim.y * blockDim.z);
@@ -451,9 +501,10 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
   // cost what the nine chained look-ups of a boundary-level lane save)
   XShuf S = {};
   if (SHUF) S = xtile_shuffle_lanes(P, G, tid & 63, (int)threadIdx.x, (int)threadIdx.y);
-  if (blockIdx.z > 0) {
-    // tracers_inline == 2: z slice p >= 1 of the launch is phase 1 of the p-th pair of further tracers, beside the state pass (slice 0)
-    const int i = 2 * ((int)blockIdx.z - 1);
+  const int nz_state = state_parts ? 3 : 1;
+  if ((int)blockIdx.z >= nz_state) {
+    // tracers_inline == 2: the z slices behind the state pass's are phase 1 of the pairs of further tracers, beside the state pass
+    const int i = 2 * ((int)blockIdx.z - nz_state);
     const int fa[2] = {4 + further_tracer(P, i), 4 + further_tracer(P, i + 1)};
     if (i + 1 < P.nt - 1)
       xtr_tile_run_own_flux<STAGE, 2, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
@@ -461,47 +512,14 @@ __global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeo
       xtr_tile_run_own_flux<STAGE, 1, SHUF>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, fa, xt_lds);
     return;
   }
-  double L[XT_NS], R[XT_NS], cen[6], F[XT_NF], own[XT_NS];
-  int fields[XT_NS];
-  xtile_state_fields(P, fields);
-  if (SHUF) {
-    xtile_load_own<XT_NS>(P, prim_in, X, fields, own);
-    if (X.poly) {
-      xtile_state_polys_from(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
-#pragma unroll
-      for (int f = 0; f < XT_NS; f++) R[f] = xtile_shfl(R[f], S.l);       // now: the right-edge values of the cell to the left
-      xtile_state_face(P, fx, X, L, R, X.upd, F);
-      double Fhi[XT_NF];
-#pragma unroll
-      for (int f = 0; f < XT_NF; f++) Fhi[f] = xtile_shfl(F[f], S.r);
-      xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
-    }
-  } else {
-    // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
-    double *st = xt_lds, *ex = xt_lds + XT_NS * TS;
-    xtile_stage<XT_NS>(P, prim_in, X, fields, st, TS, own);
-    __syncthreads();
-    if (X.poly) {
-      xtile_state_polys(P, X, st, TS, own, L, R, cen);
-#pragma unroll
-      for (int f = 0; f < XT_NS; f++) ex[f * T + X.slot] = R[f];
-    }
-    __syncthreads();
-    if (X.face) {
-#pragma unroll
-      for (int f = 0; f < XT_NS; f++) R[f] = ex[f * T + X.slot_l];       // now: the right-edge values of the cell to the left
-      xtile_state_face(P, fx, X, L, R, X.upd, F);
-#pragma unroll
-      for (int f = 0; f < XT_NF; f++) st[f * T + X.slot] = F[f];          // (every stencil read of the staged tile is behind the barrier)
-    }
-    __syncthreads();
-    if (X.upd) {
-      double Fhi[XT_NF];
-#pragma unroll
-      for (int f = 0; f < XT_NF; f++) Fhi[f] = st[f * T + X.slot_r];
-      xtile_state_finish<STAGE>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure != 0);
-    }
+  double F[XT_NF];
+  if (state_parts) {          // the state pass in three parts beside each other (z slices 0 .. 2; xtile_state_* PART)
+    if (blockIdx.z == 0) xupd_tile_state<STAGE, SHUF, XP_U>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, with_pressure != 0, xt_lds, F);
+    else if (blockIdx.z == 1) xupd_tile_state<STAGE, SHUF, XP_VW>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, with_pressure != 0, xt_lds, F);
+    else xupd_tile_state<STAGE, SHUF, XP_T>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, with_pressure != 0, xt_lds, F);
+    return;
   }
+  xupd_tile_state<STAGE, SHUF, XP_ALL>(P, X, S, T, TS, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, with_pressure != 0, xt_lds, F);
   // phase 1 of the further tracers (their FCT multipliers) inline -- small ensembles, where a launch costs more than the work: the
   // mass flux through the lane's left face is still in its register
   if (tracers_inline == 1) {
@@ -899,6 +917,8 @@ struct pam_amd_awfl {
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
   int tile_pressure_mode = 0;  // 0 automatic, 1 separate pressure pass, 2 inside the x tile kernel
   bool tile_pressure = true;   // x tile kernels: the next stage's pressure inside awfl_xupd_tile_kernel (no awfl_ptail_kernel launch)
+  bool tile_state_parts = false;        // ... and the state pass itself in three parts beside each other (XP_U / XP_VW / XP_T)
+  int tile_state_parts_mode = 0;        // 0 automatic, 1 one lane does the whole state pass, 2 three parts
   bool tile_tracers_parallel = false;   // ... and phase 1 of the further tracers in z slices of that launch BESIDE the state pass (idle CUs)
   int ftile_mode = 0;          // 0 automatic, 1 flat-lane sweeps, 2 tile kernel
   bool ftile = true;           // resolved -- flat lanes: the y/z fluxes as ONE tile kernel (a lane per cell) instead of flat-lane sweeps
@@ -1184,16 +1204,17 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
       // phase 1 of the further tracers: 0 in a launch of its own (below), 1 inline behind the state pass, 2 in z slices of this launch
       // beside the state pass (small grids with idle CUs)
       const int npairs_x = (P.nt - 1 + 1) / 2;
-      const int tr_mode = h->tile_pressure ? ((h->tile_tracers_parallel && npairs_x > 0 && npairs_x < 65535) ? 2 : 1) : 0;
-      const dim3 sgrid(grid.x, grid.y, tr_mode == 2 ? (unsigned)(1 + npairs_x) : 1u);
+      const int sparts = (h->tile_pressure && h->tile_state_parts) ? 1 : 0;      // (the parts exist for the fused form only)
+      const int tr_mode = h->tile_pressure ? (((h->tile_tracers_parallel || sparts) && npairs_x > 0 && npairs_x < 65535) ? 2 : 1) : 0;
+      const dim3 sgrid(grid.x, grid.y, (unsigned)((sparts ? 3 : 1) + (tr_mode == 2 ? npairs_x : 0)));
       if (shuf)
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, true>), sgrid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, tr_mode);
+                           h->tile_pressure ? 1 : 0, tr_mode, sparts);
       else
         hipLaunchKernelGGL((awfl_xupd_tile_kernel<STAGE, false>), sgrid, block, lds_state, s, P, G, prim_in, prim0,
                            prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, wave_is_row), dt_dyn, dt_stage,
-                           h->tile_pressure ? 1 : 0, tr_mode);
+                           h->tile_pressure ? 1 : 0, tr_mode, sparts);
       HIP_TRY(hipGetLastError());
     }
     const int npairs = (P.nt - 1 + 1) / 2;
@@ -1469,6 +1490,10 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
     const int npairs_x = (P.nt - 1 + 1) / 2;
     const int T = ((xtile_threads(h->xg) + 63) / 64) * 64;
     const long long per_cu = 16 / (T / 64 > 0 ? T / 64 : 1);       // workgroups a CU holds at the kernel's ~120 registers (16 wavefronts)
+    // the state pass itself in three parts beside each other (they rebuild the face mass flux and the new density) while all the
+    // launch's workgroups can be resident at once
+    h->tile_state_parts = h->tile_pressure && (h->tile_state_parts_mode == 2 ||
+                          (h->tile_state_parts_mode == 0 && h->ncu > 0 && per_cu > 0 && nwg * (3 + npairs_x) <= (long long)h->ncu * per_cu));
     h->tile_tracers_parallel = h->tile_pressure && npairs_x > 0 &&
                                (h->tile_pressure_mode == 3 ||
                                 (h->tile_pressure_mode == 0 && h->ncu > 0 && per_cu > 0 && nwg * (1 + npairs_x) <= 2 * (long long)h->ncu * per_cu));
@@ -2258,6 +2283,14 @@ int pam_amd_awfl_set_flux_tile_parts(pam_amd_awfl_t *h, int mode) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_flux_tile_parts: 0 = automatic, 1 = behind each other (one workgroup per tile), 2 = beside each other");
   h->ftile_parts_mode = mode;
+  resolve_lane_mapping(h);
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_tile_state_parts(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_tile_state_parts: 0 = automatic, 1 = one lane finishes a cell's whole state, 2 = three parts beside each other");
+  h->tile_state_parts_mode = mode;
   resolve_lane_mapping(h);
   return PAM_AMD_OK;
 }

@@ -275,6 +275,10 @@ class Dycore:
         check(self._lib.pam_amd_awfl_set_flux_tile(self._h, {"auto": 0, "sweep": 1, "tile": 2}[mode], int(cells_per_y_tile),
                                                    int(levels_per_z_tile)))
 
+    def set_tile_state_parts(self, mode="auto"):
+        """fused x tile kernel: the state pass of a cell by "one" lane | in three "parts" beside each other | "auto" """
+        check(self._lib.pam_amd_awfl_set_tile_state_parts(self._h, {"auto": 0, "one": 1, "parts": 2}[mode]))
+
     def set_flux_tile_parts(self, mode="auto"):
         """y/z flux tile kernel: the parts of a tile "behind" each other in one workgroup | "beside" each other in workgroups of their own | "auto" """
         check(self._lib.pam_amd_awfl_set_flux_tile_parts(self._h, {"auto": 0, "behind": 1, "beside": 2}[mode]))

@@ -79,6 +79,7 @@ def _run(case, f, xlen, ylen, yz, xk, tile=(0, 0, 0), nens_override=None, ftile=
     dycore.set_flux_tile(*ftile)
     if fusion:
         dycore.set_flux_tile_parts("beside" if fusion == "beside" else "behind")
+        dycore.set_tile_state_parts("parts" if fusion == "beside" else "one")
     dycore.set_tile_fusion(fusion or ("inside" if ftile[0] == "tile" else ("separate" if ftile[0] == "sweep" else "auto")))
     dycore.set_graph_replay(graph)
     mapping = dycore.get_lane_mapping()
