@@ -1490,10 +1490,12 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
     const int npairs_x = (P.nt - 1 + 1) / 2;
     const int T = ((xtile_threads(h->xg) + 63) / 64) * 64;
     const long long per_cu = 16 / (T / 64 > 0 ? T / 64 : 1);       // workgroups a CU holds at the kernel's ~120 registers (16 wavefronts)
-    // the state pass itself in three parts beside each other (they rebuild the face mass flux and the new density) while all the
-    // launch's workgroups can be resident at once
+    // the state pass itself in three parts beside each other (they rebuild the face mass flux and the new density) only while every
+    // workgroup of the launch finds a CU of its OWN: the polynomials are a minority of a lane's chain (two dependent rounds of loads
+    // and the launch itself are the rest), so the parts buy little -- measured (round 5): 250 x 1 x 50 with 4 tracers, 150 -> 250
+    // workgroups: x kernel 13.9 -> 12.8 us (0.135 -> 0.139 G); 32x32x60 with one member, 240 -> 720 workgroups: 14.6 -> 14.8 us; two: 17.5 -> 20.0
     h->tile_state_parts = h->tile_pressure && (h->tile_state_parts_mode == 2 ||
-                          (h->tile_state_parts_mode == 0 && h->ncu > 0 && per_cu > 0 && nwg * (3 + npairs_x) <= (long long)h->ncu * per_cu));
+                          (h->tile_state_parts_mode == 0 && h->ncu > 0 && nwg * (3 + npairs_x) <= (long long)h->ncu));
     h->tile_tracers_parallel = h->tile_pressure && npairs_x > 0 &&
                                (h->tile_pressure_mode == 3 ||
                                 (h->tile_pressure_mode == 0 && h->ncu > 0 && per_cu > 0 && nwg * (1 + npairs_x) <= 2 * (long long)h->ncu * per_cu));
