@@ -2299,65 +2299,48 @@ PAMA_D void xtile_state_face(const Params &P, double *__restrict__ fx, const XLa
 }
 // C: the lane's cell complete (the `finish` of flux_x_update_body): Flo / Fhi = the fluxes through its left / right face.
 // PART (above): which variables this lane finishes; the new density is formed by every part (same function, same inputs) and stored by XP_U
-// everything the finish of a cell loads besides the stage input: nothing of it depends on what the lane computes, so the shuffle form
-// requests it right behind the lane's own cell -- ONE round of loads per lane instead of two (XFin travels while the polynomials are built)
-struct XFin {
-  double dzk, gcoef, rho_0, q0[4], y0l, y0h, z0l, z0h, dy[5], dz[5], tyl, tyh, tzl, tzh, tseed, tq0;
-};
 template <int STAGE, int PART = XP_ALL>
-PAMA_D XFin xtile_finish_load(const Params &P, const double *__restrict__ prim0, const double *__restrict__ fy, const double *__restrict__ fz,
-                              const double *__restrict__ seed, const XLane &X) {
-  XFin Q;
+PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
+                               double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
+                               double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
+                               const double (&Flo)[XT_NF], const double (&Fhi)[XT_NF], const double (&cen)[6], double dt_dyn,
+                               double dt_stage, bool with_pressure) {
   const bool have_y = !P.sim2d;
-  const int j = X.j;
+  const int k = X.k, j = X.j;
   const unsigned po = X.po, io = X.io;
   const unsigned jp1 = member_offset((int)(io + (unsigned)((j == P.ny - 1) ? -(long long)(P.ny - 1) * P.sy : P.sy)));
   const unsigned kp1 = member_offset((int)(io + (unsigned)P.sz));
+  const double dzk = P.dz[X.ke];
+  const double rdzk = fast_rcp(dzk);
+  const double gcoef = (PART & XP_VW) ? gravity_coef(P, X.ke) : 0.0;
   const int tr = P.idWV;
-  Q.dzk = P.dz[X.ke];
-  Q.gcoef = (PART & XP_VW) ? gravity_coef(P, X.ke) : 0.0;
-  Q.rho_0 = (STAGE > 1) ? uni(prim0 + (long long)P_RHO * P.prim_fs)[po] : 0.0;
+  const double rho_in = cen[5];
+  const double rho_0 = (STAGE > 1) ? uni(prim0 + (long long)P_RHO * P.prim_fs)[po] : 0.0;
   // which of the four momentum / theta variables (n = 0 rho u, 1 rho v, 2 rho w, 3 rho theta) this part finishes
   const bool mine[4] = {(PART & XP_U) != 0, (PART & XP_VW) != 0, (PART & XP_VW) != 0, (PART & XP_T) != 0};
+  double q0[4];
 #pragma unroll
-  for (int n = 0; n < 4; n++) Q.q0[n] = (STAGE > 1 && mine[n]) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs)[po] : 0.0;
-  Q.y0l = have_y ? uni(fy)[io] : 0.0;
-  Q.y0h = have_y ? uni(fy)[jp1] : 0.0;
-  Q.z0l = uni(fz)[io];
-  Q.z0h = uni(fz)[kp1];
-  Q.dy[0] = Q.dz[0] = 0.0;
+  for (int n = 0; n < 4; n++) q0[n] = (STAGE > 1 && mine[n]) ? uni(prim0 + (long long)(P_U + n) * P.prim_fs)[po] : 0.0;
+  const double y0l = have_y ? uni(fy)[io] : 0.0, y0h = have_y ? uni(fy)[jp1] : 0.0;
+  const double z0l = uni(fz)[io], z0h = uni(fz)[kp1];
+  double dy[5], dz[5];
 #pragma unroll
   for (int l = 1; l <= 4; l++) {
-    Q.dy[l] = (have_y && mine[l - 1]) ? uni(fy + (long long)l * P.ncell)[io] : 0.0;
-    Q.dz[l] = ((l == 2 && !have_y) || !mine[l - 1]) ? 0.0 : uni(fz + (long long)l * P.fz_fs)[io];     // 2-D: no v tendency, nothing stored
+    dy[l] = (have_y && mine[l - 1]) ? uni(fy + (long long)l * P.ncell)[io] : 0.0;
+    dz[l] = ((l == 2 && !have_y) || !mine[l - 1]) ? 0.0 : uni(fz + (long long)l * P.fz_fs)[io];     // 2-D: no v tendency, nothing stored
   }
-  Q.tyl = Q.tyh = Q.tzl = Q.tzh = Q.tseed = Q.tq0 = 0.0;
+  double tyl = 0.0, tyh = 0.0, tzl = 0.0, tzh = 0.0, tseed = 0.0, tq0 = 0.0;
   if (PART & XP_T) {
-    Q.tyl = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[io] : 0.0;
-    Q.tyh = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[jp1] : 0.0;
-    Q.tzl = uni(fz + (long long)(5 + tr) * P.fz_fs)[io];
-    Q.tzh = uni(fz + (long long)(5 + tr) * P.fz_fs)[kp1];
-    Q.tseed = uni(seed + (long long)tr * P.ncell)[io];
-    Q.tq0 = (STAGE > 1) ? uni(prim0 + (long long)(P_TR0 + tr) * P.prim_fs)[po] : 0.0;
+    tyl = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[io] : 0.0;
+    tyh = have_y ? uni(fy + (long long)(5 + tr) * P.ncell)[jp1] : 0.0;
+    tzl = uni(fz + (long long)(5 + tr) * P.fz_fs)[io];
+    tzh = uni(fz + (long long)(5 + tr) * P.fz_fs)[kp1];
+    tseed = uni(seed + (long long)tr * P.ncell)[io];
+    tq0 = (STAGE > 1) ? uni(prim0 + (long long)(P_TR0 + tr) * P.prim_fs)[po] : 0.0;
   }
-  return Q;
-}
-// C: the lane's cell complete (the `finish` of flux_x_update_body): Flo / Fhi = the fluxes through its left / right face.
-// PART (above): which variables this lane finishes; the new density is formed by every part (same function, same inputs) and stored by XP_U
-template <int STAGE, int PART = XP_ALL>
-PAMA_D void xtile_state_finish(const Params &P, double *__restrict__ prim_out, double *__restrict__ seed, double *__restrict__ mult,
-                               const FctRows &rows, const XLane &X, const XFin &Q, const double (&Flo)[XT_NF], const double (&Fhi)[XT_NF],
-                               const double (&cen)[6], double dt_dyn, double dt_stage, bool with_pressure) {
-  const int k = X.k, j = X.j;
-  const unsigned po = X.po, io = X.io;
-  const double dzk = Q.dzk;
-  const double rdzk = fast_rcp(dzk);
-  const int tr = P.idWV;
-  const double rho_in = cen[5], rho_0 = Q.rho_0;
-  const bool mine[4] = {(PART & XP_U) != 0, (PART & XP_VW) != 0, (PART & XP_VW) != 0, (PART & XP_T) != 0};
   const unsigned lo = po - (unsigned)(k + HS) * (unsigned)P.sz;                     // the cell inside its level
 
-  const double qn = rk_combine<STAGE>(rho_0, rho_in, dt_dyn, flux_divergence(P, Flo[0], Fhi[0], Q.y0l, Q.y0h, Q.z0l, Q.z0h, rdzk));
+  const double qn = rk_combine<STAGE>(rho_0, rho_in, dt_dyn, flux_divergence(P, Flo[0], Fhi[0], y0l, y0h, z0l, z0h, rdzk));
   const double rrho = fast_rcp(qn);
   if (PART & XP_U) uniw(prim_out + (long long)P_RHO * P.prim_fs)[po] = qn;
   const double q_in[4] = {0.0, cen[1], cen[2], cen[3]};
@@ -2365,11 +2348,11 @@ PAMA_D void xtile_state_finish(const Params &P, double *__restrict__ prim_out, d
   for (int n = 0; n < 4; n++) {
     if (!mine[n]) continue;
     const int l = 1 + n;                                   // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
-    double tend = flux_divergence_d(P, Flo[l], Fhi[l], Q.dy[l], Q.dz[l], rdzk);
-    if (l == 3) tend = add_gravity(P, tend, rho_in, Q.gcoef);
+    double tend = flux_divergence_d(P, Flo[l], Fhi[l], dy[l], dz[l], rdzk);
+    if (l == 3) tend = add_gravity(P, tend, rho_in, gcoef);
     if (l == 2 && P.sim2d) tend = 0.0;
     const double m_in = (n == 0) ? cen[0] : mul_rn(q_in[n], rho_in);
-    const double m_0 = (STAGE > 1) ? mul_rn(Q.q0[n], rho_0) : 0.0;
+    const double m_0 = (STAGE > 1) ? mul_rn(q0[n], rho_0) : 0.0;
     const double v = rk_combine<STAGE>(m_0, m_in, dt_dyn, tend);
     store_adv_l(P, prim_out, P_U + n, k, lo, v * rrho, (l == 3) ? 0.0 : v * rrho);
     if (l == 4) {
@@ -2381,22 +2364,12 @@ PAMA_D void xtile_state_finish(const Params &P, double *__restrict__ prim_out, d
   }
   if (PART & XP_T) {
     // water vapour (finish_tracer_cell): its own multiplier (sparse store + flags) and the update an unlimited neighbourhood gets
-    own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], Q.tyl, Q.tyh, Q.tzl, Q.tzh, Q.tseed, dzk, rdzk, dt_stage);
+    own_multiplier_cell<false>(P, tr, mult, rows, k, j, X.i, X.e, io, 0, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, tseed, dzk, rdzk, dt_stage);
     double v, new_seed;
-    tracer_new_value<STAGE>(P, tr, Flo[5], Fhi[5], Q.tyl, Q.tyh, Q.tzl, Q.tzh, cen[4], Q.tq0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
+    tracer_new_value<STAGE>(P, tr, Flo[5], Fhi[5], tyl, tyh, tzl, tzh, cen[4], tq0, rho_in, rho_0, rdzk, dt_dyn, v, new_seed);
     uniw(seed + (long long)tr * P.ncell)[io] = new_seed;
     store_adv_l(P, prim_out, P_TR0 + tr, k, lo, v * rrho, v * rrho);
   }
-}
-// (the LDS form, the host emulation: the loads where the finish begins)
-template <int STAGE, int PART = XP_ALL>
-PAMA_D void xtile_state_finish(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
-                               double *__restrict__ prim_out, const double *__restrict__ fy, const double *__restrict__ fz,
-                               double *__restrict__ seed, double *__restrict__ mult, const FctRows &rows, const XLane &X,
-                               const double (&Flo)[XT_NF], const double (&Fhi)[XT_NF], const double (&cen)[6], double dt_dyn,
-                               double dt_stage, bool with_pressure) {
-  const XFin Q = xtile_finish_load<STAGE, PART>(P, prim0, fy, fz, seed, X);
-  xtile_state_finish<STAGE, PART>(P, prim_out, seed, mult, rows, X, Q, Flo, Fhi, cen, dt_dyn, dt_stage, with_pressure);
 }
 
 // ---- tracer tiles (the arithmetic of x_tracer_sweep, cell by cell): NF further tracers per lane ------------------------------

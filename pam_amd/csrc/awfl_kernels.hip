@@ -443,9 +443,6 @@ __device__ __forceinline__ void xupd_tile_state(const Params &P, const XLane &X,
   const unsigned fmask = xtile_part_fields(PART);
   if (SHUF) {
     xtile_load_own<XT_NS>(P, prim_in, X, fields, own, fmask);
-    // what the finish loads, requested NOW (the shuffle instances are compiled for 256-lane workgroups: 256 registers per lane)
-    XFin Q;
-    if (X.upd) Q = xtile_finish_load<STAGE, PART>(P, prim0, fy, fz, seed, X);
     if (X.poly) {
       xtile_state_polys_from<PART>(P, [&](int f, int s) { return xtile_shfl(own[f], S.ln[s]); }, own, L, R, cen);
 #pragma unroll
@@ -454,7 +451,7 @@ __device__ __forceinline__ void xupd_tile_state(const Params &P, const XLane &X,
       double Fhi[XT_NF];
 #pragma unroll
       for (int f = 0; f < XT_NF; f++) Fhi[f] = xtile_shfl(F[f], S.r);
-      xtile_state_finish<STAGE, PART>(P, prim_out, seed, mult, rows, X, Q, F, Fhi, cen, dt_dyn, dt_stage, with_pressure);
+      xtile_state_finish<STAGE, PART>(P, prim_in, prim0, prim_out, fy, fz, seed, mult, rows, X, F, Fhi, cen, dt_dyn, dt_stage, with_pressure);
     }
   } else {
     // LDS: XT_NS staged fields of TS elements each (later reused for the face fluxes), then XT_NS x T right-edge values
@@ -487,7 +484,7 @@ __device__ __forceinline__ void xupd_tile_state(const Params &P, const XLane &X,
 // LDS (XT_NS doubles per lane, used twice) -- or, SHUF, by wavefront shuffles when a line lies inside one wavefront.
 // grid (tiles per line x member blocks, groups of lines), block (W, rows, lines per group).
 template <int STAGE, bool SHUF>
-__global__ void __launch_bounds__(SHUF ? 256 : 1024) awfl_xupd_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
+__global__ void __launch_bounds__(1024) awfl_xupd_tile_kernel(Params P, XTileGeom G, const double *__restrict__ prim_in,
                                                               const double *__restrict__ prim0, double *__restrict__ prim_out,
                                                               double *__restrict__ fx, const double *__restrict__ fy,
                                                               const double *__restrict__ fz, double *__restrict__ seed,
@@ -1459,7 +1456,7 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   const bool grid_ok = ((long long)P.nz * P.ny + h->xg.lpb - 1) / h->xg.lpb <= 65535;
   h->xtile = xtile_supported(P) && grid_ok && (h->xtile_mode == 2 || (h->xtile_mode == 0 && small));
   // neighbours by wavefront shuffles instead of an LDS image + barriers wherever a line lies inside one wavefront
-  h->xshuf = h->xtile && h->xshuf_mode != 1 && xtile_line_in_wavefront(P, h->xg) && xtile_threads(h->xg) <= 256;   // (the SHUF instances: 256-lane workgroups)
+  h->xshuf = h->xtile && h->xshuf_mode != 1 && xtile_line_in_wavefront(P, h->xg);
   P.flat_cells = (h->lane_mode != 1 && (long long)P.nx * P.nens < 256 && P.ncell < (1ll << 31)) ? 1 : 0;
   // the y/z fluxes of a flat-lane stage: ONE tile kernel (a lane per cell) while the whole ensemble is below ~2.6e5 cells -- a flat-lane
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
