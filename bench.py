@@ -856,12 +856,12 @@ def worker(args):
     if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs and not args.limiter:
         others = {}
 
-        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, profile=None):
+        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, profile=None, warmup=1):
             try:
                 a2 = copy.copy(args)
                 a2.limiter = limiter
                 j = Job(cfg, a2, dev, 0, 1, nens)
-                u, el, sub = j.timed(steps, 1)
+                u, el, sub = j.timed(steps, warmup)
                 rows = j.dycore.debug_fct_rows()
                 others[key] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / steps * 1e3, "workload": j.desc % j.nens,
                                "num_tracers": j.nt, "substeps_per_step": sub / float(steps),
@@ -890,9 +890,10 @@ def worker(args):
         run_other("c2_limiter2", "c2", limiter=2, steps=2,
                   note="C2 with dry slabs at member-dependent places: nearly every row of 64 members flagged (--limiter 2)")
         # small ensembles (flat lanes + tile kernels): the reference's own input shape and the C2 grid with one member
-        run_other("ref_nens1", "ref", steps=5, profile="ref_nens1",
+        # (a timeStep of these is ~0.3 / ~0.8 ms: 40 steps behind 5 warm-up steps, or the first launches of a cold stream dominate)
+        run_other("ref_nens1", "ref", steps=40, warmup=5, profile="ref_nens1",
                   note="the shape of the reference's input file (input_pama.yaml: 250x1, nens = 1, 50 levels), Kessler + SHOC tracers")
-        run_other("c2grid_nens1", "c2", nens=1, steps=5, profile="c2grid_nens1", note="C2's 32x32x60 grid with ONE member")
+        run_other("c2grid_nens1", "c2", nens=1, steps=40, warmup=5, profile="c2grid_nens1", note="C2's 32x32x60 grid with ONE member")
         try:
             others["modules"] = modules_timing(torch, dev)
         except Exception as e:
