@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) sponge_relax_kernel(FieldPtrs F, int nens
 
 // Every x^y of the scheme has a non-negative base: it goes through pow_pos_fast (awfl_device.h: ~65 instructions, 0.52 ulp against
 // 80-bit powl, 0 -> 0) instead of the device library's pow (~260-440 instructions, half of them for negative / special bases) -- six of
-// them per cell and sub-cycle made the column kernel VALU-bound (round 5: 4.2 -> 2.x ms per timeStep at 1024 x 32x32x60).  T: its
+// them per cell and sub-cycle made the column kernel VALU-bound (round 5: 4.2 -> 2.9 ms per timeStep at 1024 x 32x32x60).  T: its
 // tables, staged in LDS by the kernels (two dependent per-lane look-ups per pow).
 using pama::PowTab;
 __device__ __forceinline__ double kpow(double x, double y, const PowTab *T) { return pama::pow_pos_fast(x, y, T); }
