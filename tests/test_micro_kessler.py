@@ -119,3 +119,30 @@ def test_gpu_kessler_rainsplit_hint_and_errors():
     assert lib.pam_amd_kessler_time_step(nens, nx, ny, 1, None, None, None, None, None, None, None, 1.0, 287., 461., 1003.,
                                          1e5, None, None, 0, None) == -1
     assert b"kessler" in lib.pam_amd_awfl_last_error()
+
+
+FUZZ_SEEDS = int(__import__("os").environ.get("PAM_AMD_FUZZ_SEEDS", "12"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_gpu_kessler_random_shapes_match_oracle(seed):
+    """seeded random shapes (1 .. 200 members, 2-D / 3-D, 4 .. 60 levels, light / heavy rain, short / long steps): the column kernel's
+    staging of the pow tables, its member / column indexing and the sub-cycle count against the oracle (PAM_AMD_FUZZ_SEEDS=N: N seeds)"""
+    rng = np.random.default_rng(90001 * seed + 3)
+    while True:
+        nens = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 65, 70, 128, 200]))
+        nx, ny, nz = int(rng.integers(1, 20)), int(rng.choice([1, 1, 2, 3, 5])), int(rng.integers(4, 61))
+        if nens * nx * ny * nz <= 150000:
+            break
+    heavy = bool(rng.random() < 0.5)
+    dt = float(rng.choice([1.0, 5.0, 30.0, 60.0]))
+    zint, zi, zm, s = _case(nens=nens, nx=nx, ny=ny, nz=nz, heavy_rain=heavy)
+    got, n, dt_max, micro = _gpu_run(s, zi, nens, nx, ny, nz, dt)
+    precl, n_ref = ao.kessler(s["rho_v"], s["rho_c"], s["rho_r"], s["rho_dry"], s["temp"], zm, dt, C0)
+    what = "seed %d: nens %d, %dx%dx%d, heavy %d, dt %g, rainsplit %d" % (seed, nens, nx, ny, nz, heavy, dt, n_ref)
+    assert n == n_ref and n == micro.rainsplit_for(dt, dt_max), what
+    s["precl"] = precl
+    for k in got:
+        assert np.isfinite(s[k]).all(), (what, k)
+        assert np.abs(got[k] - s[k]).max() <= 1e-12 * max(np.abs(s[k]).max(), 1e-300), (what, k)
