@@ -186,3 +186,46 @@ def test_four_tracers_per_wavefront_equal_pairs_bit_for_bit(trname):
         assert np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]) and np.array_equal(a[k], pf[k]) and np.array_equal(a[k], sg[k]), k
     for c, d in ((a_c, a_d), (b_c, b_d), (p_c, p_d), (s_c, s_d)):
         d.finalize(c)
+
+
+FUZZ_SEEDS = int(__import__("os").environ.get("PAM_AMD_FUZZ_SEEDS", "10"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_random_shards_equal_the_unsharded_run_bit_for_bit(seed):
+    """seeded random ensembles cut at random member indices into 2 .. 5 shards of ANY size (one member, ragged, across the 64-member
+    boundary where a shard switches from member lanes to tile kernels): with the dt minimum exchanged, the concatenation equals the
+    unsharded run bit for bit -- the lane mapping a shard resolves for ITS member count never shows in the result
+    (PAM_AMD_FUZZ_SEEDS=N: N seeds)"""
+    import torch
+    rng = np.random.default_rng(50021 * seed + 11)
+    while True:
+        nens = int(rng.choice([2, 3, 5, 8, 17, 40, 64, 65, 100, 130, 200]))
+        nx, ny, nz = int(rng.integers(3, 33)), int(rng.choice([1, 1, 3, 5])), int(rng.integers(4, 17))
+        if nens * nx * ny * nz <= 300000:
+            break
+    tr = [idz.TRACERS_NONE, idz.TRACERS_KESSLER_SHOC, idz.TRACERS_P3_SHOC][int(rng.integers(0, 3))]
+    zint = idz.stretched_interfaces(nz, 11000.0)
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5, id0=seed)
+    idz.add_tracer_blobs(f, tr, nx * 500.0, (ny if ny > 1 else nx) * 500.0, zint)
+    if rng.random() < 0.5:
+        idz.carve_dry_air(f, tr)
+    f["uvel"][..., int(rng.integers(0, nens))] += 40.0          # some member limits the CFL step of the whole ensemble
+    nshards = int(rng.integers(2, min(5, nens) + 1))
+    cuts = sorted(int(c) for c in rng.choice(np.arange(1, nens), size=nshards - 1, replace=False))
+    ranges = list(zip([0] + cuts, cuts + [nens]))
+    what = "seed %d: nens %d, %dx%dx%d, nt %d, shards %s" % (seed, nens, nx, ny, nz, len(tr), ranges)
+    whole_c, whole_d = _mk(f, 0, nens, nx, ny, nz, zint, tr)
+    shards = [_mk(f, lo, hi, nx, ny, nz, zint, tr) for lo, hi in ranges]
+    for _ in range(2):
+        n_whole = whole_d.timeStep(whole_c)
+        dt = min(d.compute_time_step(c) for c, d in shards)
+        assert [d.timeStep(c, dt_dyn_hint=dt) for c, d in shards] == [n_whole] * nshards, what
+    torch.cuda.synchronize()
+    w = whole_c.dump_fields()
+    s = [c.dump_fields() for c, d in shards]
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(w[k]).all(), (what, k)
+        assert np.array_equal(np.concatenate([x[k] for x in s], axis=-1), w[k]), (what, k)
+    for c, d in [(whole_c, whole_d)] + shards:
+        d.finalize(c)
