@@ -216,7 +216,7 @@ int pam_amd_awfl_set_tile_state_parts(pam_amd_awfl_t *h, int mode);
  * between dependent kernels are the same).  Same launches, same results. */
 int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode);
 /* Process-wide DEFAULTS of the launch-shape thresholds of the sweep kernels, in wavefronts (experiments; results do not depend on them): a sweep is
- * cut into spans until it has `want_units` wavefronts (> 0; default 3072); the y/z sweeps run pass 1 and the field pairs in launches
+ * cut into spans until it has `want_units` wavefronts (> 0; default 3072; the further tracers' own launches: twice that); the y/z sweeps run pass 1 and the field pairs in launches
  * of their own below `two_phase_below` (line, span) units (>= 0; 8192); phase 1 of the further tracers' x sweeps is a launch of its
  * own below `split_below` units (>= 0; 8192).  Negative / zero arguments leave a threshold as it is. */
 int pam_amd_awfl_set_launch_tuning(long long want_units, long long two_phase_below, long long split_below);

@@ -1031,11 +1031,12 @@ int launch_finalize(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, EnsRange r,
 static std::atomic<long long> g_want_units{3072};      // a sweep is cut into spans until it has this many wavefronts (or spans reach the shortest)
 static std::atomic<long long> g_two_phase_below{8192}; // y/z sweeps: pass 1 and the pairs in launches of their own below this many (line, span) units
 static std::atomic<long long> g_split_below{8192};     // x: phase 1 of the further tracers in a launch of its own below this many units
-static void choose_span(const pam_amd_awfl *h, int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan) {
+static void choose_span(const pam_amd_awfl *h, int nfaces, long long nlines, int nens, int min_span, int span_override, int &span, int &nspan,
+                        int want_scale = 1) {
   const long long nib = nlines * ((nens + 63) / 64);
   // (3072 since round 4, 6144 before: whole x lines and 2 z spans at C2's 128-member shard and at C3 instead of half lines --
   // fewer redundant start-up / closing polynomials; C2@128 +1 ... +3 %, C3 +1.4 %, C4 unchanged: it stops at the shortest span)
-  const long long want_units = h->want_units;
+  const long long want_units = h->want_units * want_scale;
   if (span_override > 0) {
     span = span_override < FLUX_MAX_SPAN ? span_override : FLUX_MAX_SPAN;
   } else {
@@ -1287,7 +1288,11 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
     quads = per == 4; singles = per == 1;
     ngroups = quads ? (nfur + 3) / 4 : (singles ? nfur : npairs);     // wavefronts per (line, member block, span)
     tspan = span; tnspan = nspan;
-    if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * ngroups, P.nens, P.seg, h->span_override, tspan, tnspan);
+    // (twice the wavefronts of a state sweep before the lines stay whole: the tracer launches are short, register-light kernels of two
+    // member ranges that run beside each other -- finer units pack better.  Measured on MI355X (round 5, profiles/r05_ab_experiments.txt),
+    // C4 shard, A/B on two boxes: phase 1 in half lines, phase 2 in quarter lines 0.799 -> 0.833 G and 0.822 -> 0.865 G; four times: the same;
+    // C3 and C4 whole have enough line blocks either way and keep whole lines)
+    if (npairs > 0) choose_span(h, P.nx, (long long)P.nz * P.ny * ngroups, P.nens, P.seg, h->span_override, tspan, tnspan, 2);
     tunits = nlb * tnspan * ngroups;
   };
   if (split) {     // phase 1 of the further tracers (their FCT multipliers) in a launch of its own
