@@ -919,7 +919,7 @@ def worker(args):
         dist.destroy_process_group()
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -965,7 +965,15 @@ def main():
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
-    args = ap.parse_args()
+    return ap
+
+
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)
+
+
+def main():
+    args = parse_args()
     if args.cpu_worker:
         c, n, t = args.cpu_worker.split(",")
         print(json.dumps(cpu_worker(c, int(n), int(t))))
