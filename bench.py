@@ -292,7 +292,7 @@ def cpu_baseline(cfg_name):
 class Job:
     """One config resident on this rank's GPU: coupler + dycore + synthetic inputs."""
 
-    def __init__(self, cfg_name, args, dev, rank, world, nens_override=0):
+    def __init__(self, cfg_name, args, dev, rank, world, nens_override=0, perens=False):
         import numpy as np
         import torch
         from pam_amd import Dycore, PamCoupler, idealized as idz, parallel
@@ -323,11 +323,22 @@ class Job:
         for k, v in self.consts.items():
             coupler.set_option(k, v)
         coupler.allocate_coupler_state(self.nz, ny, nx, nens_pg)
-        coupler.set_grid(self.xlen, self.ylen, self.zint)
+        self.perens = bool(perens or getattr(args, "perens", 0))
+        if self.perens:
+            # every member on its OWN vertical grid (the coupler's general contract: set_grid(..., realConst2d), pam_coupler.h:163-181 --
+            # an MMF host puts every CRM under a different GCM column): the interior interfaces move by up to +-2 %, differently for
+            # every member (bottom and top stay), so every (level, member) has its own WENO matrices (Dycore.h:897-940)
+            a = 0.02 * (((np.arange(nens_pg) * 37) % 101) - 50.0) / 50.0
+            kfrac = 1.0 - np.arange(self.nz + 1) / float(self.nz)
+            coupler.set_grid(self.xlen, self.ylen, np.asarray(self.zint)[:, None] * (1.0 + a[None, :] * kfrac[:, None]))
+        else:
+            coupler.set_grid(self.xlen, self.ylen, self.zint)
         for n, p, m in self.tracers:
             coupler.add_tracer(n, "", p, m)
         dycore = Dycore()
         dycore.init(coupler)
+        if getattr(args, "fold", "auto") != "auto":
+            dycore.set_yz_fold(args.fold)
         if args.seg > 0:
             dycore.set_flux_segment(args.seg)
         if args.span >= 0:
@@ -425,7 +436,7 @@ class Job:
         self.one_step()
         self.torch.cuda.synchronize()
         out = {}
-        for name in STAGE_KERNELS + ("init_prim", "finalize", "cfl"):
+        for name in STAGE_KERNELS + ("init_prim", "finalize", "cfl", "flux_xy", "flux_z"):
             ms, n = d.get_kernel_timing(name)
             if n:
                 out[name] = {"launches": n, "avg_ms": ms / n, "total_ms": ms}
@@ -726,7 +737,9 @@ def compact_line(full):
             elif isinstance(v, dict):
                 oo[k] = v.get("value")
                 rf = v.get("roofline") or {}
-                if k in ("c3", "c4", "ref_nens1", "c2grid_nens1") and rf:
+                if k in ("c3", "c4"):
+                    oo[k + "_ms_per_step"] = v.get("ms_per_step")
+                if k in ("c3", "c4", "c2_perens", "c4_perens", "ref_nens1", "c2grid_nens1") and rf:
                     oo[k + "_stage_frac"] = rf.get("stage_frac")
                     oo[k + "_stage_traffic_ratio"] = rf.get("stage_traffic_ratio")
         oo["unit"] = "cell-updates/s"
@@ -835,6 +848,8 @@ def worker(args):
         pkey = args.config if (plain and args.nens == 0) else ("c2grid_nens%d" % args.nens if (plain and args.config == "c2") else None)
         if plain and args.config == "ref" and args.nens in (0, 1):
             pkey = "ref_nens1"
+        if args.perens:
+            pkey = (args.config + "_perens") if (plain and args.nens == 0) else None
         roofline, kernels, kernel_rooflines = measure_roofline(job, args, pkey)
 
     cpu = None
@@ -856,11 +871,11 @@ def worker(args):
     if world == 1 and args.config == "c2" and args.nens == 0 and not args.no_other_configs and not args.limiter:
         others = {}
 
-        def run_other(key, cfg, nens=0, limiter=0, steps=3, note=None, profile=None, warmup=1):
+        def run_other(key, cfg, nens=0, limiter=0, steps=10, note=None, profile=None, warmup=1, perens=False):
             try:
                 a2 = copy.copy(args)
                 a2.limiter = limiter
-                j = Job(cfg, a2, dev, 0, 1, nens)
+                j = Job(cfg, a2, dev, 0, 1, nens, perens=perens)
                 u, el, sub = j.timed(steps, warmup)
                 rows = j.dycore.debug_fct_rows()
                 others[key] = {"value": u / el, "unit": "cell-updates/s", "ms_per_step": el / steps * 1e3, "workload": j.desc % j.nens,
@@ -879,15 +894,19 @@ def worker(args):
                 others[key] = {"value": None, "error": repr(e)}
         run_other("c3", "c3", profile="c3")
         run_other("c4", "c4", profile="c4")
+        # per-member vertical grids (every (level, member) has its own WENO matrices: Dycore.h:897-940, pam_coupler.h:163-181)
+        run_other("c2_perens", "c2", perens=True, steps=5, profile="c2_perens",
+                  note="C2 with every member on its own vertical grid: the z sweep stages each level's tables in LDS per workgroup (awfl_fluxz_pe_kernel)")
+        run_other("c4_perens", "c4", perens=True, profile="c4_perens", note="C4 (one GPU's shard) with per-member vertical grids")
         # the N = 1 denominators of the two strong-scaling rows and the per-GPU workload of C2 over 8 GPUs
-        run_other("c4_full", "c4", nens=4096, steps=2,
+        run_other("c4_full", "c4", nens=4096, steps=10,
                   note="BASELINE config C4 whole (nens = 4096, NT = 10) on ONE GPU: what c4 (one GPU's 512-member shard) is 1/8 of")
         run_other("c2_shard128", "c2", nens=128,
                   note="what one GPU runs of C2 strong-scaled over 8 GPUs (1024 / 8 members)")
         # the limiter acting on water vapour itself (NT = 1): the flagged paths of the state pass and the fix-up pass
-        run_other("c2_limiter1", "c2", limiter=1, steps=2,
+        run_other("c2_limiter1", "c2", limiter=1, steps=5,
                   note="C2 with dry slabs in the vapour at the same place in every member (--limiter 1)")
-        run_other("c2_limiter2", "c2", limiter=2, steps=2,
+        run_other("c2_limiter2", "c2", limiter=2, steps=5,
                   note="C2 with dry slabs at member-dependent places: nearly every row of 64 members flagged (--limiter 2)")
         # small ensembles (flat lanes + tile kernels): the reference's own input shape and the C2 grid with one member
         # (a timeStep of these is ~0.3 / ~0.8 ms: 40 steps behind 5 warm-up steps, or the first launches of a cold stream dominate)
@@ -960,6 +979,9 @@ def build_parser():
     ap.add_argument("--indep", type=int, default=-1, choices=(-1, 0, 1),
                     help="member ranges of the fused stage: 1 every range runs its whole stage on its own stream, 0 the polynomial kernels of "
                          "all ranges share one compute stream (round 2's schedule); -1 (default): the library's default (1)")
+    ap.add_argument("--perens", type=int, default=0, choices=(0, 1), help="1: every member on its own vertical grid (per-member WENO tables)")
+    ap.add_argument("--fold", default="auto", choices=("auto", "on", "off"),
+                    help="3-D member-lane stage: the z sweep stores the y+z part of the state's divergence (on) or its own differences (off)")
     ap.add_argument("--detail", default="bench_detail.json", help="file (beside bench.py) that receives the full measurement object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)

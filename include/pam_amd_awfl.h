@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PAM_AMD_AWFL_ABI_VERSION 4
+#define PAM_AMD_AWFL_ABI_VERSION 5
 
 #define PAM_AMD_OK 0
 #define PAM_AMD_EINVAL (-1)   /* bad argument / inconsistent dimensions (reference: endrun) */
@@ -158,6 +158,13 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
  * phases with another range's kernels; 0: the polynomial kernels of all ranges back to back on one stream (round 2's schedule).
  * Same results.  The automatic range count (set_ensemble_chunks(0)) of the fused stage is 2 from 128 members on. */
 int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent);
+/* Fused stage, 3-D grids swept with member lanes: the momentum components and rho*theta take their divergence as x + (y + z)
+ * (Dycore.h:553-571 sums the three directions; the density and the tracers keep (x + y) + z).  mode 2: the z sweep runs in a launch
+ * of its own behind the y sweep, reads the y sweep's flux differences and stores the y+z part, ONE field per variable, which is all
+ * the fused x-sweep then loads (it is the HBM-bound kernel of the stage); mode 1 / automatic: the z sweep stores its own differences
+ * and the x-sweep loads both and forms the same sum (measured: the flux kernel pays back what the x-sweep gains).
+ * Same bits either way (ABI 5). */
+int pam_amd_awfl_set_yz_fold(pam_amd_awfl_t *h, int mode);
 
 /* Stage structure.  1 (default): per stage  flux(y,z) -> fused x-sweep + update of the state and of the first tracer (incl.
  * its FCT multiplier) -> [FCT multiplier of further tracers] -> pointwise tail (further tracers, the first tracer where the

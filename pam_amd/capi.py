@@ -63,6 +63,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_ensemble_chunks": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pam_amd_awfl_set_fused_stage": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_range_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_set_yz_fold": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_lane_mapping": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pam_amd_awfl_set_x_tile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pam_amd_awfl_set_x_exchange": (C.c_int, [C.c_void_p, C.c_int]),

@@ -83,6 +83,9 @@ struct Params {
   const struct PowTab *pw;   // tables of pow_pos_fast
   unsigned long long pos_mask, mass_mask;  // tracer_positive / tracer_adds_mass bit sets
   int idWV;
+  int yz_fold;            // fused stage, 3-D member lanes: the z sweep adds the y differences of the state variables to its own and stores
+                          // ONE field per variable, the y+z part of the divergence (yz_divergence); the x-sweep loads that field only
+  const double *rdz;      // (nz,nens) fast_rcp(dz), formed once on the device (the z sweep of a folded stage reads it level by level)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -475,7 +478,8 @@ PAMA_D void acoustic_face(double ru_L, double ru_R, double pp_L, double pp_R, bo
   if (wall) ruf = 0.0;                                        // Dycore.h:496
 }
 
-// -(dFx)/dx - (dFy)/dy - (dFz)/dz of one variable (Dycore.h:553-571), reciprocal multiplies (<= 1 ulp per term)
+// -(dFx)/dx - (dFy)/dy - (dFz)/dz of one variable (Dycore.h:553-571), reciprocal multiplies (<= 1 ulp per term).  This association
+// ((x + y) + z) is the one of the density and of every tracer.
 PAMA_D double flux_divergence(const Params &P, double xlo, double xhi, double ylo, double yhi, double zlo, double zhi,
                               double rdzk) {
 #pragma clang fp contract(off)
@@ -484,12 +488,24 @@ PAMA_D double flux_divergence(const Params &P, double xlo, double xhi, double yl
   return fma(zlo - zhi, rdzk, tend);
 }
 
-// the same with the y and z differences already formed (ylo - yhi, zlo - zhi: what the DIFF sweeps store)
+// The momentum components and rho*theta in 3-D: x + (y + z).  The y+z part depends on nothing the x direction produces, so the z
+// sweep of the fused stage can form it (it then reads the y sweep's differences instead of the x-sweep: P.yz_fold) and hand ONE field
+// per variable to the x-sweep.  Every path -- folded or not, sweeps or tiles, the three-kernel stage, the host emulation -- forms it
+// with this function, so they all agree bit for bit.  dyv / dzv = F[c] - F[c+1] of the y / z direction (what the DIFF sweeps store).
+PAMA_D double yz_divergence(const Params &P, double dyv, double dzv, double rdzk) {
+#pragma clang fp contract(off)
+  return fma(dzv, rdzk, dyv * P.rdy);
+}
+// divergence of a state variable from its two x faces and the y+z part
+PAMA_D double flux_divergence_g(const Params &P, double xlo, double xhi, double yz) {
+#pragma clang fp contract(off)
+  return fma(xlo - xhi, P.rdx, yz);
+}
+// the same from the y and z differences (2-D: there is no y part and the association stays (x + z))
 PAMA_D double flux_divergence_d(const Params &P, double xlo, double xhi, double dyv, double dzv, double rdzk) {
 #pragma clang fp contract(off)
-  double tend = (xlo - xhi) * P.rdx;
-  if (!P.sim2d) tend = fma(dyv, P.rdy, tend);
-  return fma(dzv, rdzk, tend);
+  if (P.sim2d) return fma(dzv, rdzk, (xlo - xhi) * P.rdx);
+  return flux_divergence_g(P, xlo, xhi, yz_divergence(P, dyv, dzv, rdzk));
 }
 
 // gravity source of the vertical momentum (Dycore.h:562-566): mode A -variable_gravity*rho, mode B -grav*(rho - hy_dens)
@@ -690,9 +706,47 @@ PAMA_D LineLane flat_lane(const Params &P, unsigned q) {
   return ll;
 }
 
-template <int DIR, bool VZ_PER_ENS, bool DIFF>
-PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
-                           int f0, int span, int pair_sel = -1) {
+// Where a z sweep takes the vertical WENO table of a level from (weno5_table; level = cell index + 1, Dycore.h:454-469).  A sweep
+// announces the levels it will use, in ascending order: pass_begin(first, last), then per level trip_begin(level) ... weno(level)
+// ... trip_end(level).
+//   ZTabConst   every member has the same vertical grid (set_grid(..., realConst1d), pam_coupler.h:184-202): ONE table, read through
+//               the constant address space with scalar loads -- the coefficients are scalar operands of the polynomial's instructions
+//   ZTabLane    per-member grids (set_grid(..., realConst2d), pam_coupler.h:163-181; Dycore.h:897-940 builds the matrices per
+//               (k, iens) unconditionally), each lane reads its member's 31 coefficients from global memory: the flat-lane sweeps of
+//               small ensembles, the host emulation
+//   ZTabLds     (awfl_kernels.hip) per-member grids, member lanes: the wavefronts of a workgroup sweep different columns of the SAME
+//               64 members in step, and the level's table of those members is staged in LDS once per workgroup
+struct ZTabConst {
+  const double *vz;
+  // one grid for the ensemble: 1/dz of a level is wave-uniform -- a scalar load (member 0's entry), no vector memory operation
+  PAMA_D double rdz(const Params &P, int k, int) const { return as_constant(P.rdz + (long long)k * P.nens)[0]; }
+  PAMA_D void pass_begin(int, int) {}
+  PAMA_D void trip_begin(int) {}
+  PAMA_D void trip_end(int) {}
+  PAMA_D void weno(const double u[5], int level, const WenoConsts &wc, double &L, double &R) const {
+    weno5_table(u, as_constant(vz + (long long)level * VZ_STRIDE), 1, wc, L, R);
+  }
+};
+struct ZTabLane {
+  const double *vz;
+  long long nens;
+  int e;
+  PAMA_D double rdz(const Params &P, int k, int e_) const { return P.rdz[(long long)k * P.nens + e_]; }
+  PAMA_D void pass_begin(int, int) {}
+  PAMA_D void trip_begin(int) {}
+  PAMA_D void trip_end(int) {}
+  PAMA_D void weno(const double u[5], int level, const WenoConsts &wc, double &L, double &R) const {
+    weno5_table(u, vz + (long long)level * VZ_STRIDE * nens + e, nens, wc, L, R);
+  }
+};
+
+//   FOLD     (DIR == 2, DIFF, 3-D) the y sweep has run in an EARLIER launch: the z sweep loads the y difference of each state variable
+//            of the cell it closes (fold_y: the y flux array) and stores yz_divergence() -- the y+z part of the variable's divergence --
+//            instead of its own difference: the x-sweep then loads one value per variable instead of two (P.yz_fold)
+template <int DIR, bool DIFF, class ZT, bool FOLD = false>
+PAMA_D void flux_line_body_zt(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
+                              int f0, int span, int pair_sel, ZT &zt, const double *__restrict__ fold_y = nullptr) {
+  static_assert(!FOLD || (DIR == 2 && DIFF), "only the z sweep of the fused stage folds the y differences in");
   const unsigned eu = ll.eu;
   const int e = ll.et;
   const LineGeom g = line_geom(P, DIR);
@@ -718,10 +772,12 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   // vertical table of cell c (level index c+1): tab[m] for the ensemble-uniform table, tab[m*nens + e] per member
   auto weno = [&](const double u[5], int c, double &L, double &R) {
     if (DIR != 2) { weno5_const(u, wc, L, R); return; }
-    const double *tab = P.vz + (long long)(c + 1) * VZ_STRIDE * (VZ_PER_ENS ? (long long)P.nens : 1);
-    if (VZ_PER_ENS) weno5_table(u, tab + e, (long long)P.nens, wc, L, R);
-    else weno5_table(u, as_constant(tab), 1, wc, L, R);
+    zt.weno(u, c + 1, wc, L, R);
   };
+  // FOLD: what the store of a closed cell cc needs besides the z difference -- the y difference of the variable and 1/dz of the cell
+  // (requested at the top of the trip that closes the cell, on EVERY trip: see flux_x_update_body on s_waitcnt counts)
+  auto fold_cell = [&](int c) -> int { return c > 0 ? c - 1 : 0; };      // the cell trip c closes (clamped: trip f0 closes none)
+  auto folded = [&](double dzv, double dyv, double rdzv) -> double { return yz_divergence(P, dyv, dzv, rdzv); };
   const int nadv = 4 + P.nt;
   double *fl0 = flux + fbase;                                          // flux field 0 of this line: the face mass flux
 
@@ -742,6 +798,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       wp[s] = uni(pp + o)[eu];
     }
     double prevR_m, prevR_p, prevR_n;
+    if (DIR == 2) { zt.pass_begin(f0, cloop + 1); zt.trip_begin(f0); }     // (levels f0 .. cloop + 1, in this order)
     {                                                      // cell f0-1: only its right-edge values are needed (face f0)
       double Lm, Lp, Ln;
       weno(wm, f0 - 1, Lm, prevR_m);
@@ -753,11 +810,19 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
       wn[4] = nn; wm[4] = mul_rn(uni(pr + on)[eu], nn); wp[4] = uni(pp + on)[eu];
     }
+    if (DIR == 2) zt.trip_end(f0);
     double Fpn = 0.0, Fn0 = 0.0;                           // DIFF: the previous face's normal-momentum flux; face 0's
+    const double *fyn = FOLD ? fold_y + (long long)(1 + ncomp - P_U) * P.ncell + fbase : nullptr;
 #pragma clang loop unroll(disable)
     for (int c = f0; c <= cloop; c++) {                    // window = cells c-2..c+2; face c lies between cells c-1 and c
+      if (DIR == 2) zt.trip_begin(c + 1);
       const long long on = cell_off(c + 3);                // the next cell entering the window
       const double nn = uni(pn + on)[eu], nm = mul_rn(uni(pr + on)[eu], nn), np_ = uni(pp + on)[eu];
+      double dyv = 0.0, rdzv = 0.0;
+      if (FOLD) {
+        dyv = uni(fyn + (long long)fold_cell(c) * g.cs)[eu];
+        rdzv = zt.rdz(P, fold_cell(c), e);
+      }
       double Lm, Rm, Lp, Rp, Ln, Rn;
       weno(wm, c, Lm, Rm);
       weno(wp, c, Lp, Rp);
@@ -770,7 +835,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
       // the mass flux always leaves as FACES: the later passes upwind with it (face n of a periodic line is face 0)
       if (!(DIFF && periodic && c == g.n)) uniw(fl0 + (long long)c * g.cs)[eu] = ruf;
       if (DIFF) {
-        if (c > f0) uniw(fln + (long long)(c - 1) * g.cs)[eu] = Fpn - fn;   // cell c-1 is closed by faces c-1 and c
+        if (c > f0) uniw(fln + (long long)(c - 1) * g.cs)[eu] = FOLD ? folded(Fpn - fn, dyv, rdzv) : Fpn - fn;   // cell c-1 is closed by faces c-1 and c
         else Fn0 = fn;
         Fpn = fn;
       } else {
@@ -780,6 +845,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 #pragma unroll
       for (int s = 0; s < 4; s++) { wm[s] = wm[s + 1]; wp[s] = wp[s + 1]; wn[s] = wn[s + 1]; }
       wm[4] = nm; wp[4] = np_; wn[4] = nn;
+      if (DIR == 2) zt.trip_end(c + 1);
     }
     if (reuse0) uniw(fln + (long long)(g.n - 1) * g.cs)[eu] = Fpn - Fn0;   // the last cell: closed by face n == face 0
   }
@@ -788,7 +854,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   // wavefronts per SIMD a single chain per iteration leaves issue slots empty, several independent chains fill them.
   // NS: the first NS fields of the sweep are state variables whose DIFFERENCE is stored (DIFF only; the sweep order puts the
   // state variables first), the others store faces
-  auto sweep = [&](auto nf_tag, auto ns_tag, const int *fa) {
+  auto sweep = [&](auto nf_tag, auto ns_tag, const int *fa) __attribute__((always_inline)) {
     constexpr int NF = decltype(nf_tag)::value;
     constexpr int NS = decltype(ns_tag)::value;
     const double *q[NF];
@@ -805,6 +871,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 #pragma unroll
       for (int n = 0; n < NF; n++) w[n][s] = uni(q[n] + o)[eu];
     }
+    if (DIR == 2) { zt.pass_begin(f0, cloop + 1); zt.trip_begin(f0); }
     {
       const long long on = cell_off(f0 + 2);
 #pragma unroll
@@ -816,6 +883,10 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         w[n][4] = uni(q[n] + on)[eu];
       }
     }
+    if (DIR == 2) zt.trip_end(f0);
+    const double *fyq[NF];
+#pragma unroll
+    for (int n = 0; n < NF; n++) fyq[n] = (FOLD && n < NS) ? fold_y + (long long)(1 + fa[n]) * P.ncell + fbase : nullptr;
     double Fp[NF], F0[NF];
 #pragma unroll
     for (int n = 0; n < NF; n++) Fp[n] = F0[n] = 0.0;
@@ -827,10 +898,14 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
 #pragma unroll
       for (int r = 0; r < 5; r++) {
         if (c > cloop) break;
+        if (DIR == 2) zt.trip_begin(c + 1);
         const long long on = cell_off(c + 3);
-        double nq[NF], L[NF], R[NF];
+        double nq[NF], L[NF], R[NF], dyv[NF], rdzv = 0.0;
 #pragma unroll
         for (int n = 0; n < NF; n++) nq[n] = uni(q[n] + on)[eu];
+#pragma unroll
+        for (int n = 0; n < NF; n++) dyv[n] = (FOLD && n < NS) ? uni(fyq[n] + (long long)fold_cell(c) * g.cs)[eu] : 0.0;
+        if (FOLD && NS > 0) rdzv = zt.rdz(P, fold_cell(c), e);
         // this lane's own store of pass 1 (the periodic face n is face 0)
         const double ruf = uni(fl0 + (long long)((DIFF && periodic && c == g.n) ? 0 : c) * g.cs)[eu];
 #pragma unroll
@@ -843,7 +918,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
         for (int n = 0; n < NF; n++) {
           const double F = mul_rn(ruf, up ? prevR[n] : L[n]);
           if (n < NS) {
-            if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = Fp[n] - F;
+            if (c > f0) uniw(fl[n] + (long long)(c - 1) * g.cs)[eu] = FOLD ? folded(Fp[n] - F, dyv[n], rdzv) : Fp[n] - F;
             else F0[n] = F;
             Fp[n] = F;
           } else if (c < fend) {
@@ -852,6 +927,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
           prevR[n] = R[n];
           w[n][r % 5] = nq[n];
         }
+        if (DIR == 2) zt.trip_end(c + 1);
         c++;
       }
     }
@@ -861,7 +937,7 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
     }
   };
   // dispatch: NF fields per sweep, of which the leading ns are state variables in difference form
-  auto run = [&](int nf, const int *fa) {
+  auto run = [&](int nf, const int *fa) __attribute__((always_inline)) {
     int ns = 0;
     if (DIFF)
       for (int n = 0; n < nf; n++) ns += (fa[n] < 4) ? 1 : 0;
@@ -892,11 +968,23 @@ PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, dou
   }
 }
 
+// the table of the sweep chosen by VZ_PER_ENS: one for the ensemble / the lane's own member's, straight from global memory
+template <int DIR, bool VZ_PER_ENS, bool DIFF, bool FOLD = false>
+PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, const LineLane &ll,
+                           int f0, int span, int pair_sel = -1, const double *__restrict__ fold_y = nullptr) {
+  if constexpr (VZ_PER_ENS) {
+    ZTabLane zt{P.vz, (long long)P.nens, ll.et};
+    flux_line_body_zt<DIR, DIFF, ZTabLane, FOLD>(P, prim, flux, ll, f0, span, pair_sel, zt, fold_y);
+  } else {
+    ZTabConst zt{P.vz};
+    flux_line_body_zt<DIR, DIFF, ZTabConst, FOLD>(P, prim, flux, ll, f0, span, pair_sel, zt, fold_y);
+  }
+}
 // lanes = members of one line (the layout of large ensembles; also what the host emulation runs)
-template <int DIR, bool VZ_PER_ENS, bool DIFF>
+template <int DIR, bool VZ_PER_ENS, bool DIFF, bool FOLD = false>
 PAMA_D void flux_line_body(const Params &P, const double *__restrict__ prim, double *__restrict__ flux, int line, int e,
-                           int f0, int span, int pair_sel = -1) {
-  flux_line_body<DIR, VZ_PER_ENS, DIFF>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel);
+                           int f0, int span, int pair_sel = -1, const double *__restrict__ fold_y = nullptr) {
+  flux_line_body<DIR, VZ_PER_ENS, DIFF, FOLD>(P, prim, flux, member_lane<DIR>(P, line, e), f0, span, pair_sel, fold_y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1441,7 +1529,9 @@ PAMA_D void update_body(const Params &P, const double *prim_in, const double *pr
   for (int l = 0; l < 5; l++) {
     const double *sx_ = fx + (long long)l * P.ncell, *sy_ = fy + (long long)l * P.ncell, *sz_ = fz + (long long)l * P.fz_fs;
     const double ylo = P.sim2d ? 0.0 : sy_[idx], yhi = P.sim2d ? 0.0 : sy_[jp1];   // no y-flux array in 2-D
-    double tend = flux_divergence(P, sx_[idx], sx_[ip1], ylo, yhi, sz_[idx], sz_[idx + P.sz], rdzk);
+    // (density: (x + y) + z; momentum and rho*theta: x + (y + z) -- see yz_divergence)
+    double tend = (l == 0) ? flux_divergence(P, sx_[idx], sx_[ip1], ylo, yhi, sz_[idx], sz_[idx + P.sz], rdzk)
+                           : flux_divergence_d(P, sx_[idx], sx_[ip1], ylo - yhi, sz_[idx] - sz_[idx + P.sz], rdzk);
     if (l == 3) tend = add_gravity(P, tend, rho_in, gravity_coef(P, ke));
     if (l == 2 && P.sim2d) tend = 0.0;
     const int pf = (l == 0) ? P_RHO : P_U + (l - 1);
@@ -1713,7 +1803,9 @@ PAMA_D void x_tracer_sweep(const Params &P, const double *__restrict__ prim_in, 
 // Bit-for-bit the arithmetic of flux_line_body<0> + update_body (shared helpers above; tests/test_fused_stage.py).
 //   line   wave-uniform index of the x line: k * ny + j          e   ensemble member of this lane
 //   tracers_inline   phase 1 of the further tracers here (else the caller launches awfl_xtr_kernel<., 1>)
-template <int STAGE>
+//   FOLD   the z sweep has folded the y differences of the state variables into the field it stores (flux_line_body_zt<., FOLD>;
+//          P.yz_fold, 3-D only): the z array holds the y+z part of each variable's divergence and the y differences are not loaded
+template <int STAGE, bool FOLD = false>
 PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_in, const double *__restrict__ prim0,
                                double *__restrict__ prim_out, double *__restrict__ fx, const double *__restrict__ fy,
                                const double *__restrict__ fz, double *__restrict__ seed, double *__restrict__ mult,
@@ -1813,7 +1905,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
       ci.z0h = uni(fz + ix + P.sz)[eu];
 #pragma unroll
       for (int l = 1; l <= NQ; l++) {
-        ci.dy[l] = have_y ? uni(fy + (long long)l * P.ncell + ix)[eu] : 0.0;
+        ci.dy[l] = (have_y && !FOLD) ? uni(fy + (long long)l * P.ncell + ix)[eu] : 0.0;
         ci.dz[l] = (l == 2 && !have_y) ? 0.0 : uni(fz + (long long)l * P.fz_fs + ix)[eu];   // 2-D: no v tendency, nothing stored
       }
       ci.tyl = have_y ? uni(fyt + ix)[eu] : 0.0;
@@ -1835,7 +1927,7 @@ PAMA_D void flux_x_update_body(const Params &P, const double *__restrict__ prim_
 #pragma unroll
       for (int n = 0; n < NQ; n++) {
         const int l = 1 + n;                               // 1 rho u, 2 rho v, 3 rho w, 4 rho theta
-        double tend = flux_divergence_d(P, Flo[l], Fhi[l], ci.dy[l], ci.dz[l], rdzk);
+        double tend = FOLD ? flux_divergence_g(P, Flo[l], Fhi[l], ci.dz[l]) : flux_divergence_d(P, Flo[l], Fhi[l], ci.dy[l], ci.dz[l], rdzk);
         if (l == 3) tend = add_gravity(P, tend, ci.rho_in, gcoef);
         if (l == 2 && P.sim2d) tend = 0.0;
         const double m_in = (n == 0) ? m_in_u : mul_rn(q_in[n], ci.rho_in);

@@ -88,12 +88,18 @@ struct FluxGrid {
 // sweep in that mode (the fused x-sweep kernel does it).
 // FLAT (small ensembles, DIFF only): the lanes of a wavefront are 64 consecutive items of the sweep's flat index space
 // ((level, x, member) for y, (y, x, member) for z: flat_lane) instead of 64 members of one line; G.nsy / G.nsz spans per item group.
-template <bool VZ_PER_ENS, bool DIFF, bool FLAT>
-__global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
+// FOLD (DIFF, member lanes, 3-D): this launch is the z sweep of a folded stage -- the y sweep ran in the launch before -- and stores
+// the y+z part of each state variable's divergence instead of its z difference (flux_line_body_zt<., FOLD>).
+// VZ_PER_ENS here means the FLAT lanes of small ensembles with per-member vertical grids (each lane reads its member's table from
+// global memory: 62 registers of coefficients per trip, so two wavefronts per SIMD instead of four -- no scratch); member lanes with
+// per-member grids run awfl_fluxz_pe_kernel below.
+template <bool VZ_PER_ENS, bool DIFF, bool FLAT, bool FOLD = false>
+__global__ void __launch_bounds__(FLUX_THREADS, VZ_PER_ENS ? 2 : 4) awfl_flux_kernel(Params P, FluxGrid G, EnsRange R,
                                                                      const double *__restrict__ prim,
                                                                      double *__restrict__ fx, double *__restrict__ fy,
                                                                      double *__restrict__ fz) {
   static_assert(DIFF || !FLAT, "flat lanes exist for the fused stage's y/z sweeps only");
+  static_assert(!FOLD || (DIFF && !FLAT), "the fold exists for the member-lane z sweep of the fused stage");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nblk = (R.ne + 63) >> 6;          // blocks of 64 members per line
@@ -143,10 +149,91 @@ __global__ void __launch_bounds__(FLUX_THREADS, 4) awfl_flux_kernel(Params P, Fl
       } else {
         const int line = uni_int(grp / nblk), el = (grp - line * nblk) * 64 + lane;
         if (el < R.ne)
-          flux_line_body<2, VZ_PER_ENS, DIFF>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel);
+          flux_line_body<2, VZ_PER_ENS, DIFF, FOLD>(P, prim, fz, line, R.e0 + el, (up - grp * G.nsz) * G.spz, G.spz, psel, fy);
       }
     }
   }
+}
+
+// The z sweep of ensembles whose members have DIFFERENT vertical grids (the coupler's general contract: set_grid(..., realConst2d),
+// pam_coupler.h:163-181; the reference builds and applies the vertical WENO matrices per (k, iens) unconditionally, Dycore.h:897-940,
+// :454-481), member lanes.  A level's table is 31 doubles per member: read by every lane for every polynomial it is 248 B against the
+// 8 B of field data the polynomial consumes.  Here the ZW wavefronts of a workgroup sweep ZW neighbouring columns of the SAME block of
+// 64 members, level by level in step, and the table of the level -- 31 x 64 doubles -- is staged in LDS once per workgroup (double
+// buffered: the next level's rows are requested before the trip's polynomials and stored behind them, one barrier per level); each
+// lane then reads its member's coefficients from LDS.  Workgroups are numbered member block by member block, so at any time the
+// chip works on one or two blocks and their tables (62 levels x 15.9 KB ~ 1 MB) stay in every XCD's L2.
+// Same weno5_table on the same values as ZTabLane: same bits.  Lanes / wavefronts beyond the ensemble range / the last column are
+// clamped to the last valid member / column and redo its work (identical values to identical addresses) -- every lane of the
+// workgroup reaches every barrier and helps staging.
+constexpr int ZPE_WAVES = 4;
+struct ZTabLds {
+  double *buf;              // LDS: two tables of VZ_STRIDE x 64 doubles
+  const double *vz;         // (nz + 2, VZ_STRIDE, nens)
+  long long nens;
+  int eb, emax;             // first member of the block, last valid member
+  int tid, lane, last;
+  double r[(VZ_STRIDE * 64 + 64 * ZPE_WAVES - 1) / (64 * ZPE_WAVES)];
+  static constexpr int NR = (VZ_STRIDE * 64 + 64 * ZPE_WAVES - 1) / (64 * ZPE_WAVES);
+  __device__ __forceinline__ double rdz(const Params &P, int k, int e) const { return P.rdz[(long long)k * P.nens + e]; }
+  __device__ __forceinline__ void load(int level) {
+    const double *src = vz + (long long)level * VZ_STRIDE * nens;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int idx = tid + i * 64 * ZPE_WAVES;            // row m = idx / 64 of the table, member eb + idx % 64
+      const int m = idx >> 6, l = idx & 63, em = (eb + l < emax) ? eb + l : emax;
+      r[i] = (idx < VZ_STRIDE * 64) ? src[(long long)m * nens + em] : 0.0;
+    }
+  }
+  __device__ __forceinline__ void store(int level) {
+    double *dst = buf + (level & 1) * (VZ_STRIDE * 64);
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int idx = tid + i * 64 * ZPE_WAVES;
+      if (idx < VZ_STRIDE * 64) dst[idx] = r[i];
+    }
+  }
+  __device__ __forceinline__ void pass_begin(int first, int last_) {
+    last = last_;
+    load(first);
+    store(first);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void trip_begin(int level) { if (level < last) load(level + 1); }
+  __device__ __forceinline__ void trip_end(int level) {
+    if (level < last) store(level + 1);
+    __syncthreads();
+  }
+  __device__ __forceinline__ void weno(const double u[5], int level, const WenoConsts &wc, double &L, double &R) const {
+    weno5_table(u, buf + (level & 1) * (VZ_STRIDE * 64) + lane, 64, wc, L, R);
+  }
+};
+// grid: blocks of member-block-major units: b -> (member block, [pair of advected fields], span, group of ZW columns)
+// (two wavefronts per SIMD: the 62 registers of a level's coefficients stay live across the two or three polynomials of a trip -- 229-243
+// registers, no scratch; with the budget of three wavefronts per SIMD (168) the compiler spills 336 B per lane)
+template <bool DIFF, bool FOLD>
+__global__ void __launch_bounds__(64 * ZPE_WAVES, 2) awfl_fluxz_pe_kernel(Params P, EnsRange R, int spz, int nsz, int part, int npz,
+                                                                              const double *__restrict__ prim, const double *__restrict__ fy,
+                                                                              double *__restrict__ fz) {
+  __shared__ double ztab[2 * VZ_STRIDE * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ncol = P.ny * P.nx, ncg = (ncol + ZPE_WAVES - 1) / ZPE_WAVES;
+  const int per_blk = ncg * nsz * (part == 1 ? npz : 1);
+  const int b = (int)blockIdx.x;
+  const int blk = uni_int(b / per_blk), r1 = b - blk * per_blk;
+  const int r2 = uni_int(r1 / ncg), cg = r1 - r2 * ncg;
+  const int pp = uni_int(r2 / nsz), sp = r2 - pp * nsz;
+  const int psel = (part == 1) ? 1 + pp : part;
+  int line = cg * ZPE_WAVES + wave;
+  if (line > ncol - 1) line = ncol - 1;
+  const int emax = R.e0 + R.ne - 1;
+  int e = R.e0 + blk * 64 + lane;
+  if (e > emax) e = emax;
+  ZTabLds zt;
+  zt.buf = ztab; zt.vz = P.vz; zt.nens = P.nens; zt.eb = R.e0 + blk * 64; zt.emax = emax;
+  zt.tid = (int)threadIdx.x; zt.lane = lane; zt.last = 0;
+  flux_line_body_zt<2, DIFF, ZTabLds, FOLD>(P, prim, fz, member_lane<2>(P, line, e), sp * spz, spz, psel, zt, fy);
 }
 
 __global__ void __launch_bounds__(256) awfl_fct_kernel(Params P, EnsRange R, const double *__restrict__ fx,
@@ -169,7 +256,7 @@ __global__ void __launch_bounds__(256) awfl_update_kernel(Params P, EnsRange R, 
 }
 // Fused x-sweep + state update (flux_x_update_body): wave unit u -> (x line, member block, span of cells); the 64 lanes are
 // 64 consecutive members of ONE line, so every address is a wave-uniform base + member (scalar addressing).
-template <int STAGE>
+template <int STAGE, bool FOLD>
 __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
                                                                      const double *__restrict__ prim0,
                                                                      double *__restrict__ prim_out, double *__restrict__ fx,
@@ -184,8 +271,8 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
   const int line = uni_int(grp / nblk), blk = grp - line * nblk;
   const int el = blk * 64 + (int)(threadIdx.x & 63);
   if (line < P.nz * P.ny && el < R.ne)
-    flux_x_update_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span,
-                              dt_dyn, dt_stage, tracers_inline != 0);
+    flux_x_update_body<STAGE, FOLD>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span,
+                                    dt_dyn, dt_stage, tracers_inline != 0);
 }
 // x sweeps of tracers 1.. (x_tracer_sweep): wave unit u -> (x line, member block, span, pair of tracers).  PHASE 1 (the cells' FCT
 // multipliers; only for small ensembles -- otherwise it runs inline in awfl_xupd_kernel) and PHASE 2 (the cells' complete update)
@@ -807,6 +894,11 @@ __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *_
   }
 }
 
+// 1 / dz per (level, member) with the reciprocal every kernel forms on the fly (fast_rcp): the z sweep of a folded stage reads it
+__global__ void __launch_bounds__(256) awfl_rdz_kernel(const double *__restrict__ dz, double *__restrict__ rdz, long long n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) rdz[t] = fast_rcp(dz[t]);
+}
 template <bool VZ_PER_ENS>
 __global__ void __launch_bounds__(64) awfl_hydro_kernel(Params P, const double *__restrict__ prim, double *grav_var,
                                                         double *hy_dens, double *hy_pres) {
@@ -914,6 +1006,8 @@ struct pam_amd_awfl {
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
   int xshuf_mode = 0;          // x tile kernels, exchange between neighbouring cells: 0 automatic, 1 through LDS, 2 wavefront shuffles
   bool xshuf = false;          // resolved: wavefront shuffles (a whole periodic line of a tile lies inside one wavefront)
+  int fold_mode = 0;           // y differences of the state folded into the z sweep's output (P.yz_fold): 0 automatic, 1 off, 2 on
+  double *rdz = nullptr;       // (nz, nens) fast_rcp(dz)
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
   int tile_pressure_mode = 0;  // 0 automatic, 1 separate pressure pass, 2 inside the x tile kernel
   bool tile_pressure = true;   // x tile kernels: the next stage's pressure inside awfl_xupd_tile_kernel (no awfl_ptail_kernel launch)
@@ -1107,12 +1201,23 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
   // the kernel uses no LDS; a dynamic LDS request only caps its residency per CU when other kernels should co-reside
   size_t lds_bytes = 0;
   if (h->chunks.size() > 1) lds_bytes = h->flux_lds_floor;
+  // The z sweep in a launch of its own, BEHIND the x / y sweeps, in two cases:
+  //   fold   (fused stage, 3-D, member lanes: P.yz_fold) it reads the y sweep's differences of the state variables and stores the y+z part
+  //          of their divergence, one field per variable, which is all the x-sweep then loads (yz_divergence in awfl_device.h);
+  //   pe     per-member vertical grids with member lanes: awfl_fluxz_pe_kernel (the levels' tables staged in LDS per workgroup)
+  const bool fold = diff && P.yz_fold && !flat && (sweeps & 6) == 6;
+  const bool pe = P.vz_per_ens && !flat && (sweeps & 4);
+  const int nsub = ((fold || pe) && (sweeps & 3)) ? 2 : 1;
   ScopedTimer st(h, "flux", s);
+  for (int sub = 0; sub < nsub; sub++) {
+  const int mask = nsub == 1 ? sweeps : (sub == 0 ? (sweeps & 3) : (sweeps & 4));
+  const bool zonly = (mask == 4);
+  ScopedTimer st2(h, nsub == 1 ? "flux_all" : (sub == 0 ? "flux_xy" : "flux_z"), s);
   for (int phase = 0; phase < nphase; phase++) {
   G.part = two_phase ? phase : -1;
   G.npx = G.npy = G.npz = npairs;
   const long long mult = (G.part == 1) ? npairs : 1;
-  G.nux = (int)(ux0 * nblk * mult); G.nuy = (int)(uy0 * nblk * mult); G.nuz = (int)(uz0 * nblk * mult);
+  G.nux = (mask & 1) ? (int)(ux0 * nblk * mult) : 0; G.nuy = (mask & 2) ? (int)(uy0 * nblk * mult) : 0; G.nuz = (mask & 4) ? (int)(uz0 * nblk * mult) : 0;
   G.nbx = (G.nux + FLUX_WAVES - 1) / FLUX_WAVES; G.nby = (G.nuy + FLUX_WAVES - 1) / FLUX_WAVES;
   G.nbz = (G.nuz + FLUX_WAVES - 1) / FLUX_WAVES;
   G.nbx_l = G.nby_l = 0;
@@ -1120,15 +1225,31 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     G.nbx_l = G.nbx / P.nz;
     G.nby_l = G.nby / P.nz;
   }
-  if (G.nbx + G.nby + G.nbz == 0) return PAM_AMD_OK;
+  if (G.nbx + G.nby + G.nbz == 0) continue;
+  if (pe && zonly) {
+    // member-block-major workgroups of ZPE_WAVES columns each (awfl_fluxz_pe_kernel)
+    const long long ncg = ((long long)P.ny * P.nx + ZPE_WAVES - 1) / ZPE_WAVES;
+    const long long nwg = nblk * ncg * G.nsz * mult;
+    if (nwg > 0x3fffffffll) return fail(PAM_AMD_EINVAL, "flux launch: more than 2^30 workgroups in one launch");
+    const dim3 zgrid((unsigned)nwg), zblock(64 * ZPE_WAVES);
+    const bool f = fold && zonly;
+#define PAMA_LAUNCH_ZPE(DF, FO)                                                                                         \
+  hipLaunchKernelGGL((awfl_fluxz_pe_kernel<DF, FO>), zgrid, zblock, 0, s, P, r, G.spz, G.nsz, G.part, npairs, prim, h->flux_y, h->flux_z)
+    if (!diff) PAMA_LAUNCH_ZPE(false, false); else if (f) PAMA_LAUNCH_ZPE(true, true); else PAMA_LAUNCH_ZPE(true, false);
+#undef PAMA_LAUNCH_ZPE
+    HIP_TRY(hipGetLastError());
+    continue;
+  }
   const dim3 grid(G.nbx + G.nby + G.nbz), block(FLUX_THREADS);
-#define PAMA_LAUNCH_FLUX(VZ, DF, FL)                                                                                    \
-  hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF, FL>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
-  if (flat) { if (P.vz_per_ens) PAMA_LAUNCH_FLUX(true, true, true); else PAMA_LAUNCH_FLUX(false, true, true); }
-  else if (P.vz_per_ens) { if (diff) PAMA_LAUNCH_FLUX(true, true, false); else PAMA_LAUNCH_FLUX(true, false, false); }
-  else { if (diff) PAMA_LAUNCH_FLUX(false, true, false); else PAMA_LAUNCH_FLUX(false, false, false); }
+#define PAMA_LAUNCH_FLUX(VZ, DF, FL, FO)                                                                                \
+  hipLaunchKernelGGL((awfl_flux_kernel<VZ, DF, FL, FO>), grid, block, lds_bytes, s, P, G, r, prim, h->flux_x, h->flux_y, h->flux_z)
+  if (flat) { if (P.vz_per_ens) PAMA_LAUNCH_FLUX(true, true, true, false); else PAMA_LAUNCH_FLUX(false, true, true, false); }
+  else if (fold && zonly) PAMA_LAUNCH_FLUX(false, true, false, true);
+  else if (diff) PAMA_LAUNCH_FLUX(false, true, false, false);      // (per-member grids: only the z sweep reads tables, and it is not in this launch)
+  else PAMA_LAUNCH_FLUX(false, false, false, false);
 #undef PAMA_LAUNCH_FLUX
   HIP_TRY(hipGetLastError());
+  }
   }
   return PAM_AMD_OK;
 }
@@ -1264,9 +1385,14 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   if (r.e0 % 64) return fail(PAM_AMD_EINVAL, "x-sweep launch: member ranges of the fused stage start at multiples of 64 (a wavefront is one row of FCT flags)");
   {
     ScopedTimer st(h, "xupd", s);
-    hipLaunchKernelGGL(awfl_xupd_kernel<STAGE>, dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
-                       prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn,
-                       dt_stage, split ? 0 : 1, span, nspan);
+    if (P.yz_fold)      // (the z sweep has left the y+z part of the state's divergence in flux_z: no y differences to load)
+      hipLaunchKernelGGL((awfl_xupd_kernel<STAGE, true>), dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
+                         prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn,
+                         dt_stage, split ? 0 : 1, span, nspan);
+    else
+      hipLaunchKernelGGL((awfl_xupd_kernel<STAGE, false>), dim3(nblocks(nunits, FLUX_WAVES)), dim3(FLUX_THREADS), 0, s, P, r,
+                         prim_in, prim0, prim_out, h->flux_x, h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), dt_dyn,
+                         dt_stage, split ? 0 : 1, span, nspan);
     HIP_TRY(hipGetLastError());
   }
   // the tracer launches have npairs wavefronts per (line, member block, span): their lines are cut less (or not at all)
@@ -1441,6 +1567,13 @@ void choose_flux_tiles(pam_amd_awfl *h) {
   }
 }
 
+// The fold (P.yz_fold) is OFF unless asked for: measured on MI355X (round 6, profiles/r06_ab_experiments.txt, A/B on one box) it moves
+// four loads per cell from the HBM-bound x-sweep (3.59 -> 3.31 ms at C2) into the FP64-issue-bound flux kernel, which pays the same
+// back (4.36 -> 4.59 ms for the y and z launches together): C2 2.555 -> 2.564 G, 256 members 2.548 -> 2.537, 128 members 2.466 ->
+// 2.445, the 3-D four-tracer grid at 256 members 1.416 -> 1.381.
+#ifndef PAMA_FOLD_DEFAULT
+#define PAMA_FOLD_DEFAULT 0
+#endif
 // Lane mapping of the fused stage (decided from the WHOLE ensemble; results never depend on it):
 //   flat   the y/z sweeps take 64 consecutive (x, member) items per wavefront (flat_lane) instead of 64 members of one line
 //   xtile  the x direction runs as tile kernels (a lane per cell) instead of sweeps (a wavefront per line span)
@@ -1463,6 +1596,9 @@ void resolve_lane_mapping(pam_amd_awfl *h) {
   // neighbours by wavefront shuffles instead of an LDS image + barriers wherever a line lies inside one wavefront
   h->xshuf = h->xtile && h->xshuf_mode != 1 && xtile_line_in_wavefront(P, h->xg);
   P.flat_cells = (h->lane_mode != 1 && (long long)P.nx * P.nens < 256 && P.ncell < (1ll << 31)) ? 1 : 0;
+  // the y differences of the state folded into what the z sweep stores (3-D, member-lane sweeps in y, z AND x: the tile kernels form
+  // the y+z part of the divergence themselves, with the same yz_divergence -- same bits either way)
+  P.yz_fold = (!P.sim2d && !h->flat && !h->xtile && (h->fold_mode == 2 || (h->fold_mode == 0 && PAMA_FOLD_DEFAULT))) ? 1 : 0;
   // the y/z fluxes of a flat-lane stage: ONE tile kernel (a lane per cell) while the whole ensemble is below ~2.6e5 cells -- a flat-lane
   // sweep is then a handful of wavefronts walking their lines serially -- and flat-lane sweeps above (they read every input once and
   // build no halo rows; measured on MI355X, 32x32x60: 1 member 67 -> 20 us per stage, 8 members 85 -> 82, 32 members 184 -> 320)
@@ -1588,7 +1724,7 @@ void free_all(pam_amd_awfl *h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   h->ev_fork = nullptr;
   double **bufs[] = {&h->prim0, &h->prim1, &h->prim2, &h->flux_x, &h->flux_y, &h->flux_z, &h->seed, &h->mult, &h->dz,
-                     &h->grav_var, &h->hy_dens, &h->hy_pres, &h->vz, &h->vert_s2c, &h->vert_wrl};
+                     &h->grav_var, &h->hy_dens, &h->hy_pres, &h->vz, &h->vert_s2c, &h->vert_wrl, &h->rdz};
   for (auto b : bufs) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
@@ -1721,6 +1857,10 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
     P.pw = h->pow_tab;
   }
   INIT_TRY(hipMemcpy(h->dz, dz_host.data(), nzn * 8, hipMemcpyHostToDevice));
+  INIT_TRY(hipMalloc(&h->rdz, nzn * 8));
+  hipLaunchKernelGGL(awfl_rdz_kernel, dim3((unsigned)((nzn + 255) / 256)), dim3(256), 0, h->stream, h->dz, h->rdz, (long long)nzn);
+  INIT_TRY(hipGetLastError());
+  P.rdz = h->rdz;
   INIT_TRY(hipMemcpy(h->vz, vt.table.data(), vt.table.size() * 8, hipMemcpyHostToDevice));
   INIT_TRY(hipMemcpy(h->vert_s2c, vt.s2c.data(), vt.s2c.size() * 8, hipMemcpyHostToDevice));
   INIT_TRY(hipMemcpy(h->vert_wrl, vt.wrl.data(), vt.wrl.size() * 8, hipMemcpyHostToDevice));
@@ -1736,13 +1876,9 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   // (the graph-replay stream, its events and the stage-number word are created when the replay is switched on)
   // the flux kernel may request more than the default 64 KiB of dynamic LDS (residency cap)
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INIT_TRY(hipFuncSetAttribute((const void *)awfl_flux_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // the tile kernels stage their tiles in LDS: up to 14 doubles per lane of a 1024-lane workgroup
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INIT_TRY(hipFuncSetAttribute((const void *)awfl_xupd_tile_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2361,6 +2497,21 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
   if (flat_cells) *flat_cells = h->P.flat_cells;
   if (x_tiles && h->xtile && h->xshuf) *x_tiles = 2;
   if (geom) { geom[0] = h->xg.W; geom[1] = h->xg.nmb; geom[2] = h->xg.tc; geom[3] = h->xg.halo; geom[4] = h->xg.ntl; geom[5] = h->xg.lpb; }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_yz_fold(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_yz_fold: 0 = automatic, 1 = off (the x-sweep loads the y and the z differences), 2 = on");
+  USE_DEVICE(h);
+  const int old = h->fold_mode;
+  h->fold_mode = mode;
+  resolve_lane_mapping(h);
+  if (mode == 2 && !h->P.yz_fold) {
+    h->fold_mode = old;
+    resolve_lane_mapping(h);
+    return fail(PAM_AMD_EINVAL, "set_yz_fold: the fold exists for 3-D grids swept with member lanes (y, z and x sweep kernels)");
+  }
   return PAM_AMD_OK;
 }
 

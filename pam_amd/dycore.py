@@ -242,6 +242,13 @@ class Dycore:
     def set_range_schedule(self, independent):
         check(self._lib.pam_amd_awfl_set_range_schedule(self._h, int(bool(independent))))
 
+    FOLD = {"auto": 0, "off": 1, "on": 2}
+
+    def set_yz_fold(self, mode="auto"):
+        """3-D member-lane stage: the z sweep stores the y+z part of the state's divergence ("on" / "auto") or its own differences
+        ("off": the x-sweep loads both); same bits (include/pam_amd_awfl.h)"""
+        check(self._lib.pam_amd_awfl_set_yz_fold(self._h, self.FOLD[mode]))
+
     def set_launch_tuning(self, want_units=0, two_phase_below=-1, split_below=-1):
         """launch-shape thresholds of THIS handle's sweep kernels, in wavefronts (0 / -1 = leave as it is); same results"""
         check(self._lib.pam_amd_awfl_set_handle_launch_tuning(self._h, int(want_units), int(two_phase_below), int(split_below)))

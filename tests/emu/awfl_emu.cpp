@@ -19,7 +19,7 @@ using namespace pama;
 
 struct Emu {
   Params P;
-  std::vector<double> prim0, prim1, prim2, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz;
+  std::vector<double> prim0, prim1, prim2, fx, fy, fz, seed, mult, dz, grav_var, hy_dens, hy_pres, vz, rdz;
   VerticalTables vt;
   PowTab pow_tab;
   int span = 0;   // faces per thread in the flux sweep (0 = whole line)
@@ -154,6 +154,9 @@ static void flux_launch(Emu *h, const double *prim, int sweeps = 7, bool diff = 
           } else if (dir == 1) {
             if (P.vz_per_ens) { if (diff) flux_line_body<1, true, true>(P, prim, fl, line, e, f0, span); else flux_line_body<1, true, false>(P, prim, fl, line, e, f0, span); }
             else { if (diff) flux_line_body<1, false, true>(P, prim, fl, line, e, f0, span); else flux_line_body<1, false, false>(P, prim, fl, line, e, f0, span); }
+          } else if (diff && P.yz_fold) {      // the z sweep of a folded stage (the y sweep has run: dir 1 comes first)
+            if (P.vz_per_ens) flux_line_body<2, true, true, true>(P, prim, fl, line, e, f0, span, -1, h->fy.data());
+            else flux_line_body<2, false, true, true>(P, prim, fl, line, e, f0, span, -1, h->fy.data());
           } else {
             if (P.vz_per_ens) { if (diff) flux_line_body<2, true, true>(P, prim, fl, line, e, f0, span); else flux_line_body<2, true, false>(P, prim, fl, line, e, f0, span); }
             else { if (diff) flux_line_body<2, false, true>(P, prim, fl, line, e, f0, span); else flux_line_body<2, false, false>(P, prim, fl, line, e, f0, span); }
@@ -312,9 +315,14 @@ static void xupd_launch(Emu *h, const double *in, const double *p0, double *out,
   const int span = h->span > 0 ? h->span : P.nx, nspan = (P.nx + span - 1) / span;   // emu_set_span cuts the x lines too
   for (int line = 0; line < P.nz * P.ny; line++)
     for (int sp = 0; sp < nspan; sp++)
-      for (int e = 0; e < P.nens; e++)
-        flux_x_update_body<STAGE>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(),
-                                  fct_rows(h), line, e, sp * span, span, dt, dt_stage, h->xtr_split == 0);
+      for (int e = 0; e < P.nens; e++) {
+        if (P.yz_fold)
+          flux_x_update_body<STAGE, true>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(),
+                                          fct_rows(h), line, e, sp * span, span, dt, dt_stage, h->xtr_split == 0);
+        else
+          flux_x_update_body<STAGE, false>(P, in, p0, out, h->fx.data(), h->fy.data(), h->fz.data(), h->seed.data(), h->mult.data(),
+                                           fct_rows(h), line, e, sp * span, span, dt, dt_stage, h->xtr_split == 0);
+      }
   // awfl_xtr_kernel: phase 1 of the further tracers in a launch of its own (one wavefront per (span, pair)) unless it ran inline;
   // then -- always a launch of its own -- phase 2 (the multipliers of unflagged rows are poisoned in between: the device does not
   // store them)
@@ -402,6 +410,9 @@ Emu *emu_init(int nens, int nx, int ny, int nz, int nt, double xlen, double ylen
   h->grav_var.assign((size_t)nz * nens, nan); h->hy_dens.assign((size_t)nz * nens, nan); h->hy_pres.assign((size_t)nz * nens, nan);
   P.dz = h->dz.data(); P.grav_var = h->grav_var.data(); P.hy_dens = h->hy_dens.data(); P.hy_pres = h->hy_pres.data();
   P.vz = h->vz.data();
+  h->rdz.resize((size_t)nz * nens);
+  for (size_t i = 0; i < h->rdz.size(); i++) h->rdz[i] = fast_rcp(h->dz[i]);
+  P.rdz = h->rdz.data();
   build_pow_tab(h->pow_tab);
   P.pw = &h->pow_tab;
   return h;
@@ -418,6 +429,8 @@ void emu_set_grav_balance(Emu *h, int v) { h->P.grav_balance = v ? 1 : 0; }
 void emu_set_seg(Emu *h, int seg) { h->P.seg = seg; }
 void emu_set_span(Emu *h, int span) { h->span = span; }
 void emu_set_fused(Emu *h, int fused) { h->fused = fused; }
+// the y differences of the state folded into the z sweep's output (3-D, member lanes + sweep kernels; resolve_lane_mapping)
+void emu_set_yz_fold(Emu *h, int on) { h->P.yz_fold = (on && !h->P.sim2d && !h->flat && !h->xtile) ? 1 : 0; }
 void emu_set_xtr_split(Emu *h, int split) { h->xtr_split = split; }
 void emu_set_lane_mapping(Emu *h, int flat, int xtile) { h->flat = flat; h->xtile = xtile; }
 void emu_set_x_tile(Emu *h, int w, int tc, int lpb) { h->xt_w = w; h->xt_tc = tc; h->xt_lpb = lpb; }

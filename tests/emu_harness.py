@@ -33,6 +33,7 @@ def load():
         lib.emu_set_span.argtypes = [C.c_void_p, C.c_int]
         lib.emu_pow.argtypes = [_DP, C.c_int, C.c_double, _DP]
         lib.emu_set_fused.argtypes = [C.c_void_p, C.c_int]
+        lib.emu_set_yz_fold.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_xtr_split.argtypes = [C.c_void_p, C.c_int]
         lib.emu_set_lane_mapping.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.emu_set_x_tile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -90,6 +91,9 @@ class EmuDycore:
 
     def set_fused(self, on):
         self.lib.emu_set_fused(self.h, int(bool(on)))
+
+    def set_yz_fold(self, on):
+        self.lib.emu_set_yz_fold(self.h, int(bool(on)))
 
     def set_xtr_split(self, on):
         self.lib.emu_set_xtr_split(self.h, int(bool(on)))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/pam_amd_awfl.h but not exported"
     assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
-    assert lib.pam_amd_awfl_abi_version() == 4
+    assert lib.pam_amd_awfl_abi_version() == 5
     mods = _header_symbols("pam_amd_modules.h", "pam_amd_")
     assert mods == set(capi.MODULE_SYMBOLS) and all(hasattr(lib, n) for n in mods)
 

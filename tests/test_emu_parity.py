@@ -101,7 +101,9 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span, split):
     if kw.get("per_ens"):
         dz = dz * (1 + 0.01 * np.arange(nens))[None, :]
     out = []
-    for fused in (False, True):
+    # three-kernel stage; fused stage; fused stage with the y differences of the state folded into the z sweep's output (3-D: the z
+    # sweep stores yz_divergence(), the x-sweep loads that one field -- the schedule of large 3-D ensembles on the device)
+    for fused, fold in ((False, False), (True, False), (True, True)):
         ff = copy.deepcopy(f)
         g = eh.EmuDycore(nens, nx, ny, nz, xlen, ylen, dz, pos, mass, idwv, consts=consts, seg=seg)
         g.set_grav_balance(mode_a)
@@ -109,12 +111,14 @@ def test_fused_stage_equals_three_kernel_stage_bit_for_bit(case, span, split):
         if fused:
             g.set_span(span)      # the fused x-sweep cut into spans (each recomputes its closing face) vs whole-line three-kernel stage
             g.set_xtr_split(split)  # tracers 1.. finished inline after the state pass, or in a launch of their own (awfl_xtr_kernel)
+            g.set_yz_fold(fold)
         g.declare_current_profile_as_hydrostatic(ff)
         ncyc = [g.time_step(ff, dt)[0] for dt in (2.0, 0.7, 2.0)]
         out.append((ncyc, ff))
-    assert out[0][0] == out[1][0] and any(n % 2 for n in out[0][0]) and any(n % 2 == 0 for n in out[0][0]), out[0][0]
+    assert out[0][0] == out[1][0] == out[2][0] and any(n % 2 for n in out[0][0]) and any(n % 2 == 0 for n in out[0][0]), out[0][0]
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+        assert np.array_equal(out[0][1][k], out[2][1][k]), k + " (folded)"
 
 
 def test_vertical_tables_match_oracle_matrices():

@@ -29,10 +29,16 @@ CASES = {
     "3d_nt1_vapour_limited_rows": (128, 6, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, True, idz.CONSTS_DEFAULT),
     "3d_nt1_vapour_limited_ragged_B": (70, 6, 5, 9, idz.TRACERS_NONE, idz.stretched_interfaces(9, 12000.0), False, False, idz.CONSTS_DEFAULT),
     "2d_nt10_whole_flag_rows": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), False, False, idz.CONSTS_P3),
+    # per-member vertical grids with MEMBER lanes (awfl_fluxz_pe_kernel: the levels' tables staged in LDS per workgroup of four
+    # columns): whole blocks of 64 members + two ranges; a ragged last block and a column count that is not a multiple of four
+    # (clamped lanes / wavefronts redo the last member / column); 2-D with many tracers (the pairs in a launch of their own)
+    "3d_nt4_perens_member_lanes": (128, 6, 5, 9, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(9, 12000.0), "mod16", True, idz.CONSTS_DEFAULT),
+    "3d_nt1_perens_ragged_130_B": (130, 5, 3, 7, idz.TRACERS_NONE, idz.stretched_interfaces(7, 9000.0), "mod16", False, idz.CONSTS_DEFAULT),
+    "2d_nt10_perens_member_lanes": (192, 32, 1, 12, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(12, 12000.0), "mod16", True, idz.CONSTS_P3),
 }
 
 
-def _run(case, fused, chunks=0, want_mult=False):
+def _run(case, fused, chunks=0, want_mult=False, fold=None, lanes=None):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts = CASES[case]
@@ -52,7 +58,9 @@ def _run(case, fused, chunks=0, want_mult=False):
             q[..., 1::3] = q[..., 1::3] + 2.0e-4 * f["density_dry"][..., 1::3]
             q[..., 2::5] = 0.0
     zi = np.asarray(zint)[:, None] * np.ones((1, nens))
-    if per_ens:
+    if per_ens == "mod16":
+        zi = zi * (1 + 0.01 * (np.arange(nens) % 16) + 1.0e-4 * (np.arange(nens) // 16))[None, :]
+    elif per_ens:
         zi = zi * (1 + 0.01 * np.arange(nens))[None, :]
     coupler = PamCoupler("cuda:0")
     coupler.set_option("crm_dt", 2.0)
@@ -67,6 +75,10 @@ def _run(case, fused, chunks=0, want_mult=False):
     dycore.set_fused_stage(fused)
     if chunks:
         dycore.set_ensemble_chunks(chunks)
+    if lanes is not None:
+        dycore.set_lane_mapping(*lanes)
+    if fold is not None:
+        dycore.set_yz_fold(fold)
     coupler.load_fields(f)
     if not mode_a:
         coupler.set_option("balance_hydrostasis_with_gravity", False)
@@ -104,6 +116,51 @@ def test_flag_row_cases_exercise_the_limiter(case):
     lim = (rows < 1.0).sum(axis=-1)
     assert ((lim > 0) & (lim < 64)).any(), "no row holds limited and unlimited members side by side"
     assert (lim == 0).any(), "rows without any limited member must exist too (they are the ones that are skipped)"
+
+
+@pytest.mark.parametrize("case", ["3d_nt4_whole_flag_rows", "3d_nt1_vapour_limited_rows", "3d_nt4_perens_member_lanes", "3d_nt1_perens_ragged_130_B",
+                                  "3d_nt4_many_lines_inline_tracers"])
+def test_yz_fold_is_a_schedule_not_an_arithmetic(case):
+    """3-D member lanes: the z sweep storing the y+z part of the state's divergence (one field per variable for the x-sweep; the
+    default) == the z sweep storing its own differences and the x-sweep loading both (pam_amd_awfl_set_yz_fold), bit for bit"""
+    n0, a = _run(case, fused=True, fold="off")
+    n1, b = _run(case, fused=True, fold="on")
+    assert n0 == n1
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
+def test_yz_fold_is_refused_where_it_does_not_exist():
+    """2-D grids have no y part; flat lanes / tile kernels form the sum themselves"""
+    import torch  # noqa: F401
+    from pam_amd import Dycore, PamCoupler
+    from pam_amd.capi import PamAmdError
+    for nens, ny in ((128, 1), (3, 6)):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 2.0)
+        coupler.allocate_coupler_state(8, ny, 6, nens)
+        coupler.set_grid(3000.0, 3000.0, idz.stretched_interfaces(8, 12000.0))
+        coupler.add_tracer("water_vapor", "", True, True)
+        dycore = Dycore()
+        dycore.init(coupler)
+        with pytest.raises(PamAmdError):
+            dycore.set_yz_fold("on")
+        dycore.set_yz_fold("off")
+        dycore.set_yz_fold("auto")
+        dycore.finalize(coupler)
+
+
+@pytest.mark.parametrize("case", ["3d_nt4_perens_member_lanes", "3d_nt1_perens_ragged_130_B", "2d_nt10_perens_member_lanes"])
+def test_per_member_grids_member_lanes_equal_flat_lanes_bit_for_bit(case):
+    """per-member vertical grids: the LDS-staged tables of the member-lane z sweep (awfl_fluxz_pe_kernel) against flat lanes, where
+    every lane reads its member's table from global memory (ZTabLane) -- the same weno5_table on the same 31 values"""
+    n0, a = _run(case, fused=True, lanes=("flat", "sweep"))
+    n1, b = _run(case, fused=True, lanes=("member", "sweep"))
+    assert n0 == n1
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
 
 
 def test_fct_flag_rows_are_chunking_invariant():

@@ -43,7 +43,9 @@ def _setup(nens, nx, ny, nz, tr, zint, consts=idz.CONSTS_DEFAULT, supercell=True
     else:
         f = idz.dry_bubble_fields(nens, nx, ny, nz, xlen, ylen, zint, consts=consts, tracers=tr)
     zi = np.asarray(zint)[:, None] * np.ones((1, nens))
-    if per_ens:
+    if per_ens == "mod16":
+        zi = zi * (1 + 0.01 * (np.arange(nens) % 16) + 1.0e-4 * (np.arange(nens) // 16))[None, :]
+    elif per_ens:
         zi = zi * (1 + 0.01 * np.arange(nens))[None, :]
     dz = np.diff(zi, axis=0)
     coupler = PamCoupler("cuda:0")
@@ -82,6 +84,11 @@ CASES = {
     "2d_nt1_vapour_limited": (66, 9, 1, 10, idz.TRACERS_NONE, idz.stretched_interfaces(10, 12000.0), dict(dry_air=True), True, 2),
     "3d_nt10_perens_A_p3": (3, 6, 4, 8, idz.TRACERS_P3_SHOC, idz.stretched_interfaces(8, 12000.0),
                             dict(per_ens=True, consts=idz.CONSTS_P3), True, 2),
+    # per-member vertical grids with MEMBER lanes (64+ members: awfl_fluxz_pe_kernel, tables staged in LDS): whole blocks; a ragged
+    # block (130 = 2 x 64 + 2) with 15 columns (not a multiple of the workgroup's four)
+    "3d_nt4_perens_nens64_member_lanes": (64, 6, 4, 8, idz.TRACERS_KESSLER_SHOC, idz.stretched_interfaces(8, 12000.0),
+                                          dict(per_ens="mod16"), True, 2),
+    "3d_nt1_perens_nens130_ragged_B": (130, 5, 3, 7, idz.TRACERS_NONE, idz.stretched_interfaces(7, 9000.0), dict(per_ens="mod16"), False, 1),
     "2d_bubble_A": (2, 16, 1, 20, idz.TRACERS_NONE, idz.uniform_interfaces(20, 10000.0),
                     dict(supercell=False, crm_dt=1.0), True, 3),
     # ragged sizes: nens not a multiple of 64 but > 64, line lengths not multiples of the segment

@@ -52,6 +52,11 @@ def main():
         v = [x for x in res[name] if x == x]
         ks = " ".join("%s=%.4f" % (k["kernel"].replace("awfl_", "").replace("_kernel", ""), k["ms_per_stage"])
                       for k in (last.get(name, {}).get("kernel_rooflines") or []))
+        kk = last.get(name, {}).get("kernels") or {}
+        nst = max(1, (kk.get("xupd") or kk.get("update") or {}).get("launches", 1))
+        for extra in ("flux_xy", "flux_z"):      # the y and z sweeps as launches of their own (folded stage / per-member grids): shipped schedule
+            if extra in kk:
+                ks += " %s=%.4f" % (extra, kk[extra]["total_ms"] / nst)
         st = (last.get(name, {}).get("roofline") or {}).get("stage_ms_back_to_back")
         lines.append("%-28s median %.4f G  [%s]  stage %s ms | %s" % (name, statistics.median(v) if v else float("nan"),
                                                                      " ".join("%.4f" % x for x in res[name]),
