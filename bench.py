@@ -646,8 +646,11 @@ def modules_timing(torch, dev):
                                 "note": "prep kernel 6 reads + 5 writes, column kernel 11 reads + 4 writes per cell (1 sub-cycle)"}
     t = timeit(lambda: modules.sponge_layer(c))
     nsp = 5                   # sponge_layer.h:8-95: the top 5 of 60 levels
-    out["sponge_layer"] = {"ms": t, "bytes": nens * nx * ny * nsp * 4 * 3 * 8.0, "GBps": nens * nx * ny * nsp * 4 * 3 * 8.0 / t / 1e6,
-                           "note": "u, v, w, T of the top 5 levels: read for the mean, read + written for the relaxation"}
+    nfld = 5 + len(c.get_tracer_names())          # rho_d, u, v, w, T + every tracer (sponge_layer.h:54-62); w's mean is zero: not read
+    sp_bytes = nens * nx * ny * nsp * (3 * nfld - 1) * 8.0
+    out["sponge_layer"] = {"ms": t, "bytes": sp_bytes, "GBps": sp_bytes / t / 1e6, "hbm_frac": sp_bytes / t / 1e6 / HBM_PEAK_GBS,
+                           "note": "%d fields, top 5 levels: read for the mean (not w), read + written for the relaxation; the second read "
+                                   "comes out of the caches, so the compulsory HBM traffic is 2/3 of this" % nfld}
     del micro, dm, c
     torch.cuda.empty_cache()
     c = PamCoupler(dev)
@@ -666,11 +669,15 @@ def modules_timing(torch, dev):
         dm.get(k).copy_(dm.get(src).mean(dim=(1, 2)) * 1.01)
     modules.compute_gcm_forcing_tendencies(c)
     t = timeit(lambda: modules.compute_gcm_forcing_tendencies(c), 3)
-    out["compute_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 5 * 8.0, "GBps": cells * 5 * 8.0 / t / 1e6,
-                                             "note": "column means of rho_d, u, v, T, rho_v: 5 fields read"}
+    out["compute_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 10 * 8.0, "GBps": cells * 10 * 8.0 / t / 1e6,
+                                             "hbm_frac": cells * 10 * 8.0 / t / 1e6 / HBM_PEAK_GBS,
+                                             "note": "column means of rho_d, u, v, T, rho_v, rho_l, rho_i, nc, ni, nr (gcm_forcing.h:149-174): "
+                                                     "10 fields read (rounds 1-5 counted 5 of them)"}
     t = timeit(lambda: modules.apply_gcm_forcing_tendencies(c), 3)
-    out["apply_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 10 * 8.0, "GBps": cells * 10 * 8.0 / t / 1e6,
-                                           "note": "5 fields read and written (hole filling included)"}
+    out["apply_gcm_forcing_tendencies"] = {"ms": t, "bytes": cells * 20 * 8.0, "GBps": cells * 20 * 8.0 / t / 1e6,
+                                           "hbm_frac": cells * 20 * 8.0 / t / 1e6 / HBM_PEAK_GBS,
+                                           "note": "the same 10 fields read and written in place (gcm_forcing.h:361-429; the hole-filling sums "
+                                                   "ride along; rounds 1-5 counted 5 + 5)"}
     del dm, c
     torch.cuda.empty_cache()
     return out
@@ -734,6 +741,7 @@ def compact_line(full):
         for k, v in o.items():
             if k == "modules":
                 oo["modules_ms"] = {kk: vv["ms"] for kk, vv in v.items() if isinstance(vv, dict) and "ms" in vv}
+                oo["modules_hbm_frac"] = {kk: vv["hbm_frac"] for kk, vv in v.items() if isinstance(vv, dict) and "hbm_frac" in vv}
             elif isinstance(v, dict):
                 oo[k] = v.get("value")
                 rf = v.get("roofline") or {}

@@ -141,6 +141,19 @@ int pam_amd_awfl_set_kernel_timing(pam_amd_awfl_t *h, int enable);
  * "finalize","cfl","hydro","xupd","xtr1","xtr2","ptail","trfix") since the last reset; synchronises the stream. */
 int pam_amd_awfl_get_kernel_timing(pam_amd_awfl_t *h, const char *name, double *total_ms, long long *launches);
 int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
+/* The reference's runtime self-check (Dycore.h:36-58 compute_mass; under -DPAM_DEBUG: :136-138 before, :224-251 after the sub-steps of a
+ * timeStep) as an opt-in: with enable = 1 every timeStep forms, per variable (tracer densities in registration order, then rho, then
+ * rho*theta) and per member, the mean of q * dz over the member's cells before and after, by a device reduction, and synchronises the
+ * handle's stream at its end.  A (variable, member) pair whose mass changed by more than 1e-10 relative AND 1e-10 absolute -- the
+ * reference's WARNING condition -- counts as a violation; get_conservation returns their number, the largest relative change and where
+ * it was; conservation_report the reference's WARNING lines (the first 32).  Off by default: nothing is launched, nothing synchronised.
+ * (ABI 5) */
+int pam_amd_awfl_set_debug_conservation(pam_amd_awfl_t *h, int enable);
+int pam_amd_awfl_get_conservation(pam_amd_awfl_t *h, int *violations, double *max_rel_diff, int *worst_variable, int *worst_member);
+const char *pam_amd_awfl_conservation_report(const pam_amd_awfl_t *h);
+/* Test hook of the check: in the NEXT timeStep, between the last stage and the final masses, one cell of `variable` of `member` is
+ * multiplied by `factor` (rho: at constant rho*theta). */
+int pam_amd_awfl_debug_inject_mass_fault(pam_amd_awfl_t *h, int variable, int k, int j, int i, int member, double factor);
 /* Sweep-kernel tuning knobs; results do not depend on them (bit for bit).
  *   segment: shortest span (faces) a line may be cut into when the ensemble alone does not fill the chip (default 8; 1..64)
  *   span:    faces swept by one wavefront (0 = automatic: the whole line, cut only for small ensembles; at most 64 per span) */

@@ -18,7 +18,8 @@ extern "C" {
  *               then the tracers in registration order (sponge_layer.h:54-62)
  *   zint, zmid  DEVICE "vertical_interface_height" (nz+1,nens), "vertical_midpoint_height" (nz,nens)
  *   num_layers  option "sponge_num_layers" (default 5), time_scale option "sponge_time_scale" (default 60 s)
- *   workspace   DEVICE scratch of num_fields*num_layers*nens doubles (the horizontal means)
+ *   workspace   unused since ABI 5 (the horizontal means live in the kernel's workgroups); may be NULL.  ABI <= 4: DEVICE scratch
+ *               of num_fields*num_layers*nens doubles
  *   stream      hipStream_t (NULL = default stream) */
 int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fields, double *const *fields, const double *zint,
                          const double *zmid, double crm_dt, int num_layers, double time_scale, double *workspace,

@@ -64,6 +64,10 @@ SYMBOLS = {
     "pam_amd_awfl_set_fused_stage": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_range_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_yz_fold": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_set_debug_conservation": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_get_conservation": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pam_amd_awfl_conservation_report": (C.c_char_p, [C.c_void_p]),
+    "pam_amd_awfl_debug_inject_mass_fault": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pam_amd_awfl_set_lane_mapping": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pam_amd_awfl_set_x_tile": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pam_amd_awfl_set_x_exchange": (C.c_int, [C.c_void_p, C.c_int]),

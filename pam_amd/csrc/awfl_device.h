@@ -2580,8 +2580,12 @@ struct FTileGeom {
 };
 PAMA_HD int ftile_rows(const FTileGeom &G) { return G.tc + 2 * G.halo; }
 PAMA_HD int ftile_threads(const FTileGeom &G) { return G.W * ftile_rows(G) * G.lpb; }
+// (per-member vertical grids: a lane of a z tile holds its member's 31 coefficients of the level across the polynomials of a group --
+// the tile kernel then runs with workgroups of at most 512 lanes, i.e. a register budget of 256: no scratch)
+PAMA_HD int ftile_max_threads(const Params &P) { return P.vz_per_ens ? 512 : 1024; }
 PAMA_HD FTileGeom ftile_geometry(const Params &P, int dir, int tc_req) {
   FTileGeom G;
+  const int maxT = ftile_max_threads(P);
   const long long plane = (dir == 1) ? (long long)P.nx * P.nens : P.sz;     // contiguous lanes across the sweep direction
   const int n = (dir == 1) ? P.ny : P.nz;
   if (dir == 1) {
@@ -2598,7 +2602,7 @@ PAMA_HD FTileGeom ftile_geometry(const Params &P, int dir, int tc_req) {
       int tc = tc_req > 0 ? tc_req : (G.W >= 32 ? 512 : 256) / G.W - 2;
       if (tc < 2) tc = 2;
       if (tc > n) tc = n;
-      while (tc > 1 && (tc + 2) * G.W > 1024) tc--;
+      while (tc > 1 && (tc + 2) * G.W > maxT) tc--;
       G.ntl = (n + tc - 1) / tc;
       G.tc = tc_req > 0 ? tc : (n + G.ntl - 1) / G.ntl;
     }
@@ -2607,7 +2611,7 @@ PAMA_HD FTileGeom ftile_geometry(const Params &P, int dir, int tc_req) {
     G.halo = 1; G.lpb = 1;
     int tc = tc_req > 0 ? tc_req : 6;
     if (tc > n) tc = n;
-    if (tc > 14) tc = 14;
+    if (tc > maxT / 64 - 2) tc = maxT / 64 - 2;
     G.ntl = (n + tc - 1) / tc;
     G.tc = tc_req > 0 ? tc : (n + G.ntl - 1) / G.ntl;
   }

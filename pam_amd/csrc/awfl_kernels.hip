@@ -783,7 +783,7 @@ __device__ __forceinline__ void flux_tile_part(const Params &P, const FTileGeom 
 }
 // parts: 0 = every part of a tile in one workgroup, one behind the other; 1 = grid.y indexes the part (flux_tile_part)
 template <bool VZ_PER_ENS>
-__global__ void __launch_bounds__(1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
+__global__ void __launch_bounds__(VZ_PER_ENS ? 512 : 1024) awfl_flux_tile_kernel(Params P, FTileGeom Gy, FTileGeom Gz, FTileGroups Q, int nby, int gyx,
                                                               const double *__restrict__ prim, double *__restrict__ fy,
                                                               double *__restrict__ fz, int parts) {
   extern __shared__ double ft_lds[];
@@ -892,6 +892,44 @@ __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *_
     if (!(m > 0.0)) m = 0.0;   // NaN or non-positive anywhere in the wavefront's cells: reported as 0 (the host refuses it)
     atomicMin(result, (unsigned long long)__double_as_longlong(m));
   }
+}
+
+// The reference's runtime self-check (Dycore.h:36-58 compute_mass, used under PAM_DEBUG at :136-138, :224-251): per variable -- every
+// tracer density, rho, rho*theta -- and per member the mean of q * dz over the member's cells, taken from the resident state (prim: rho,
+// theta; seed: the conserved tracer densities).  grid (blocks of 64 members of the range, variables); lanes = members; the four
+// wavefronts of a workgroup take every fourth column of each level and their partial sums are added in a fixed order: deterministic.
+__global__ void __launch_bounds__(256) awfl_mass_kernel(Params P, EnsRange R, const double *__restrict__ prim,
+                                                        const double *__restrict__ seed, double *__restrict__ mass) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int el = (int)blockIdx.x * 64 + lane;
+  const bool ok = el < R.ne;
+  const int e = R.e0 + (ok ? el : R.ne - 1);
+  const int ivar = (int)blockIdx.y;
+  const long long ncol = (long long)P.ny * P.nx;
+  double s = 0.0;
+  for (int k = 0; k < P.nz; k++) {
+    const double dzk = P.dz[(long long)k * P.nens + e];
+    for (long long c = wave; c < ncol; c += 4) {
+      const long long o = (long long)(k + HS) * P.sz + c * P.nens + e;
+      double q;
+      if (ivar < P.nt) q = seed[(long long)ivar * P.ncell + ((long long)k * ncol + c) * P.nens + e];
+      else if (ivar == P.nt) q = prim[P_RHO * P.prim_fs + o];
+      else q = prim[P_RHO * P.prim_fs + o] * prim[P_THETA * P.prim_fs + o];
+      s = fma(q, dzk, s);
+    }
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && ok)
+    mass[(long long)ivar * P.nens + e] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (double)((long long)P.nz * ncol);
+}
+// test hook of the check above: one cell of one variable scaled between the last stage and the final mass (pam_amd_awfl_debug_inject_mass_fault)
+__global__ void awfl_poke_kernel(Params P, const double *prim, double *prim_w, double *seed, int ivar, int k, int j, int i, int e, double factor) {
+  const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
+  if (ivar < P.nt) seed[(long long)ivar * P.ncell + (((long long)k * P.ny + j) * P.nx + i) * P.nens + e] *= factor;
+  else if (ivar == P.nt) { prim_w[P_RHO * P.prim_fs + o] *= factor; prim_w[P_THETA * P.prim_fs + o] /= factor; }   // rho alone: rho*theta unchanged
+  else prim_w[P_THETA * P.prim_fs + o] *= factor;
 }
 
 // 1 / dz per (level, member) with the reciprocal every kernel forms on the fly (fast_rcp): the z sweep of a folded stage reads it
@@ -1006,6 +1044,13 @@ struct pam_amd_awfl {
   int xt_w = 0, xt_tc = 0, xt_lpb = 0;   // tile geometry overrides (0 = automatic)
   int xshuf_mode = 0;          // x tile kernels, exchange between neighbouring cells: 0 automatic, 1 through LDS, 2 wavefront shuffles
   bool xshuf = false;          // resolved: wavefront shuffles (a whole periodic line of a tile lies inside one wavefront)
+  // the reference's PAM_DEBUG conservation check as an opt-in (pam_amd_awfl_set_debug_conservation): masses before / after a timeStep
+  bool debug_mass = false;
+  double *mass_dev = nullptr;  // (2, nt + 2, nens): before, after
+  int mass_violations = 0, mass_worst_var = -1, mass_worst_member = -1;
+  double mass_max_rel = 0.0;
+  std::string mass_report;
+  struct { bool armed = false; int ivar, k, j, i, e; double factor; } fault;   // one-shot test hook
   int fold_mode = 0;           // y differences of the state folded into the z sweep's output (P.yz_fold): 0 automatic, 1 off, 2 on
   double *rdz = nullptr;       // (nz, nens) fast_rcp(dz)
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
@@ -1161,7 +1206,7 @@ int launch_flux(pam_amd_awfl *h, const double *prim, EnsRange r, hipStream_t s, 
     int T = ftile_threads(Gz);
     if (!P.sim2d && ftile_threads(Gy) > T) T = ftile_threads(Gy);
     T = ((T + 63) / 64) * 64;
-    if (T > 1024) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes");
+    if (T > ftile_max_threads(P)) return fail(PAM_AMD_EINVAL, "flux tile launch: a tile must fit a workgroup of 1024 lanes (512 with per-member vertical grids)");
     const size_t lds = (size_t)(2 * FT_NG + 4) * T * sizeof(double);
     ScopedTimer st(h, "flux", s);
     // the parts of a tile (acoustic triple, groups of advected quantities) beside each other in workgroups of their own -- grid.y --
@@ -1488,6 +1533,41 @@ int launch_tail(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
   return PAM_AMD_OK;
 }
 
+// Dycore.h:36-58 on the resident state of one member range: slot 0 = before the sub-steps, 1 = after
+int launch_mass(pam_amd_awfl *h, int slot, EnsRange r, hipStream_t s) {
+  const Params &P = h->P;
+  hipLaunchKernelGGL(awfl_mass_kernel, dim3((unsigned)((r.ne + 63) / 64), (unsigned)(P.nt + 2)), dim3(256), 0, s, P, r, h->prim0, h->seed,
+                     h->mass_dev + (size_t)slot * (P.nt + 2) * P.nens);
+  HIP_TRY(hipGetLastError());
+  return PAM_AMD_OK;
+}
+// Dycore.h:224-251: a (variable, member) pair is reported when its mass changed by more than 1e-10 relative AND absolute
+int evaluate_mass(pam_amd_awfl *h) {
+  const Params &P = h->P;
+  const size_t n = (size_t)(P.nt + 2) * P.nens;
+  std::vector<double> m(2 * n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(m.data(), h->mass_dev, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+  h->mass_violations = 0; h->mass_max_rel = 0.0; h->mass_worst_var = h->mass_worst_member = -1;
+  h->mass_report.clear();
+  for (int ivar = 0; ivar < P.nt + 2; ivar++)
+    for (int e = 0; e < P.nens; e++) {
+      const double a = m[(size_t)ivar * P.nens + e], b = m[n + (size_t)ivar * P.nens + e];
+      const double ad = std::fabs(b - a), rd = ad / (std::fabs(a) + 1.e-20);
+      const bool bad = !(rd <= 1.e-10) && !(ad <= 1.e-10);      // (a NaN mass is a violation)
+      if (rd > h->mass_max_rel || (rd != rd && h->mass_worst_var < 0)) { h->mass_max_rel = rd; h->mass_worst_var = ivar; h->mass_worst_member = e; }
+      if (!bad) continue;
+      h->mass_violations++;
+      if (h->mass_violations <= 32) {
+        char line[256];
+        std::snprintf(line, sizeof(line), "WARNING: conservation violated variable,ensemble,rel_diff,mass_diff,init,final: %d , %d , %.6e , %.6e , %.6e , %.6e\n",
+                      ivar, e, rd, b - a, a, b);
+        h->mass_report += line;
+      }
+    }
+  return PAM_AMD_OK;
+}
+
 int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, double *dt) {
   if (!f || !f->tracers) return fail(PAM_AMD_EINVAL, "fields: null pointer");
   const unsigned long long init = 0x7FF0000000000000ull;   // +inf
@@ -1555,7 +1635,7 @@ void choose_flux_tiles(pam_amd_awfl *h) {
       int T = ftile_threads(Gz);
       if (!P.sim2d && ftile_threads(Gy) > T) T = ftile_threads(Gy);
       T = ((T + 63) / 64) * 64;
-      if (T > 1024) continue;
+      if (T > ftile_max_threads(P)) continue;
       const long long launched = (nby + nbz) * T;
       const long long active = (P.sim2d ? 0 : nby * ftile_threads(Gy)) + nbz * ftile_threads(Gz);
       if (active * 5 < launched * 4) continue;
@@ -1731,6 +1811,8 @@ void free_all(pam_amd_awfl *h) {
   }
   if (h->dt_bits) (void)hipFree(h->dt_bits);
   h->dt_bits = nullptr;
+  if (h->mass_dev) (void)hipFree(h->mass_dev);
+  h->mass_dev = nullptr;
   if (h->pow_tab) (void)hipFree(h->pow_tab);
   h->pow_tab = nullptr;
   if (h->fct_flags) (void)hipFree(h->fct_flags);
@@ -2092,6 +2174,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     // Dycore.h:128-134 (per chunk)
     for (auto &c : h->chunks) {
       if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
+      if (h->debug_mass && (rc = launch_mass(h, 0, c.r, c.stream))) return rc;      // Dycore.h:136-138 (after the clipping of :130-134)
       if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
     }
     // Launches are issued stage by stage, round-robin over the chunks.  With several chunks:
@@ -2175,9 +2258,19 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
           if ((rc = stage(c, 3, B, A, A, (2.0 / 3.0) * dt_dyn))) return rc;
       }
     }
-    // Dycore.h:254 (per chunk)
-    for (auto &c : h->chunks)
+    // Dycore.h:224-251 (PAM_DEBUG), then :254 (per chunk)
+    for (auto &c : h->chunks) {
+      if (h->debug_mass) {
+        if (h->fault.armed && h->fault.e >= c.r.e0 && h->fault.e < c.r.e0 + c.r.ne) {
+          hipLaunchKernelGGL(awfl_poke_kernel, dim3(1), dim3(1), 0, c.stream, h->P, h->prim0, h->prim0, h->seed, h->fault.ivar, h->fault.k,
+                             h->fault.j, h->fault.i, h->fault.e, h->fault.factor);
+          HIP_TRY(hipGetLastError());
+          h->fault.armed = false;
+        }
+        if ((rc = launch_mass(h, 1, c.r, c.stream))) return rc;
+      }
       if ((rc = launch_finalize(h, fields, c.r, c.stream))) return rc;
+    }
     return PAM_AMD_OK;
   };
   // Launch-bound ensembles: the whole step (coupler -> dycore, 3 x ncycles stages, dycore -> coupler) is captured ONCE into a HIP
@@ -2188,7 +2281,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   // 0.425 ms: the gaps between DEPENDENT kernels (~2.3 us each) are the same inside a graph, and the fork / join events cost more
   // than the host-side launch calls they replace (the host is not the bottleneck: launches are issued well ahead of the device).
   const bool graph_on = h->graph_mode == 2;
-  if (graph_on && h->fused && !forked && !h->timing && h->gstream) {
+  if (graph_on && h->fused && !forked && !h->timing && !h->debug_mass && h->gstream) {
     const int nstages = 3 * ncycles;
     if (h->fct_seq > 0x7fffffff - nstages - 4) {      // the wrap of the stage number cannot happen inside a graph
       HIP_TRY(hipDeviceSynchronize());
@@ -2268,6 +2361,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
     }
     if (rc == PAM_AMD_OK) rc = jrc;
   }
+  if (rc == PAM_AMD_OK && h->debug_mass) rc = evaluate_mass(h);
   return rc;
 }
 
@@ -2497,6 +2591,38 @@ int pam_amd_awfl_get_lane_mapping(const pam_amd_awfl_t *h, int *yz_flat, int *x_
   if (flat_cells) *flat_cells = h->P.flat_cells;
   if (x_tiles && h->xtile && h->xshuf) *x_tiles = 2;
   if (geom) { geom[0] = h->xg.W; geom[1] = h->xg.nmb; geom[2] = h->xg.tc; geom[3] = h->xg.halo; geom[4] = h->xg.ntl; geom[5] = h->xg.lpb; }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_set_debug_conservation(pam_amd_awfl_t *h, int enable) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  USE_DEVICE(h);
+  drop_graphs(h);
+  if (enable && !h->mass_dev) HIP_TRY(hipMalloc(&h->mass_dev, (size_t)2 * (h->P.nt + 2) * h->P.nens * sizeof(double)));
+  h->debug_mass = enable != 0;
+  h->mass_violations = 0; h->mass_max_rel = 0.0; h->mass_worst_var = h->mass_worst_member = -1;
+  h->mass_report.clear();
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_get_conservation(pam_amd_awfl_t *h, int *violations, double *max_rel_diff, int *worst_variable, int *worst_member) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (!h->debug_mass) return fail(PAM_AMD_ESTATE, "get_conservation: the check is off (pam_amd_awfl_set_debug_conservation)");
+  if (violations) *violations = h->mass_violations;
+  if (max_rel_diff) *max_rel_diff = h->mass_max_rel;
+  if (worst_variable) *worst_variable = h->mass_worst_var;
+  if (worst_member) *worst_member = h->mass_worst_member;
+  return PAM_AMD_OK;
+}
+
+const char *pam_amd_awfl_conservation_report(const pam_amd_awfl_t *h) { return h ? h->mass_report.c_str() : ""; }
+
+int pam_amd_awfl_debug_inject_mass_fault(pam_amd_awfl_t *h, int variable, int k, int j, int i, int member, double factor) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  const Params &P = h->P;
+  if (variable < 0 || variable > P.nt + 1 || k < 0 || k >= P.nz || j < 0 || j >= P.ny || i < 0 || i >= P.nx || member < 0 || member >= P.nens)
+    return fail(PAM_AMD_EINVAL, "debug_inject_mass_fault: index out of range");
+  h->fault.armed = true; h->fault.ivar = variable; h->fault.k = k; h->fault.j = j; h->fault.i = i; h->fault.e = member; h->fault.factor = factor;
   return PAM_AMD_OK;
 }
 

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <fstream>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -25,6 +27,30 @@ class Dycore {
   int ncycles_ = 0;
 
   static void chk(int rc) { if (rc) endrun(pam_amd_awfl_last_error()); }          // pam_const.h:249-252
+
+#ifdef PAM_STANDALONE
+  // The reference reads `initData` from the standalone driver's YAML file with yaml-cpp (awfl/Dycore.h:991-1004).  Its input files
+  // are flat `key : value  # comment` lists (the .yaml files under standalone/mmf_simplified/inputs), which is all this reads; inside PAM, where
+  // yaml-cpp is linked, YAML::LoadFile(inFile)["initData"].as<std::string>() is the same value.
+  static std::string yaml_flat_value(std::string const &file, std::string const &key) {
+    std::ifstream in(file);
+    if (!in) endrun("ERROR: cannot open standalone_input_file " + file);
+    std::string line;
+    while (std::getline(in, line)) {
+      auto hash = line.find('#');
+      if (hash != std::string::npos) line.erase(hash);
+      auto colon = line.find(':');
+      if (colon == std::string::npos) continue;
+      auto trim = [](std::string v) {
+        auto a = v.find_first_not_of(" \t\r\""), b = v.find_last_not_of(" \t\r\"");
+        return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+      };
+      if (trim(line.substr(0, colon)) == key) return trim(line.substr(colon + 1));
+    }
+    endrun("ERROR: key " + key + " not found in " + file);
+    return "";
+  }
+#endif
 
   // read-write views of the coupler fields (awfl/Dycore.h:1301-1310): marks the entries dirty like the reference
   pam_amd_awfl_fields_t fields(pam::PamCoupler &coupler) const {
@@ -116,6 +142,22 @@ class Dycore {
     dm.register_and_allocate<bool>("tracer_positive", "", {num_tracers});
     if (hipMemcpy(dm.get<bool, 1>("tracer_positive").data(), pos_b.data(), num_tracers, hipMemcpyHostToDevice) != hipSuccess)
       endrun("ERROR: copying tracer_positive to the device failed");
+#ifdef PAM_DEBUG
+    chk(pam_amd_awfl_set_debug_conservation(h, 1));                                // awfl/Dycore.h:136-138,224-251
+#endif
+    // idealised initial data of the standalone driver (awfl/Dycore.h:986-1090: "thermal" :1021-1088, "supercell" :1096-1276),
+    // filled on the device; "external" (the MMF case, and what the absence of the option means): nothing to do (:1005-1011)
+    if (coupler.option_exists("standalone_input_file")) {
+#ifdef PAM_STANDALONE
+      std::string inFile = coupler.get_option<std::string>("standalone_input_file");
+      std::string dataStr = yaml_flat_value(inFile, "initData");
+      if (dataStr != "thermal" && dataStr != "supercell" && dataStr != "external") endrun("ERROR: Invalid data_spec");   // :1002
+      auto f = fields(coupler);
+      chk(pam_amd_awfl_init_idealized(h, &f, dataStr.c_str(), dm.get<real const, 2>("vertical_midpoint_height").data(),
+                                      dm.get<real const, 2>("vertical_interface_height").data()));
+#endif
+    }
+    (void)verbose;
   }
 
   // awfl/Dycore.h:107
@@ -123,6 +165,7 @@ class Dycore {
     chk(sync_balance_option(coupler));
     auto f = fields(coupler);
     chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), /*dt_dyn_hint=*/0., &ncycles_, nullptr));
+    report_conservation();
   }
 
   // Not in the reference (one process, one device): the ensemble sharded by member index over several devices, one coupler and
@@ -133,8 +176,22 @@ class Dycore {
     chk(sync_balance_option(coupler));
     auto f = fields(coupler);
     chk(pam_amd_awfl_time_step(h, &f, coupler.get_option<real>("crm_dt"), dt_dyn_all_members, &ncycles_, nullptr));
+    report_conservation();
   }
   int last_ncycles() const { return ncycles_; }        // sub-cycles of the most recent timeStep (awfl/Dycore.h:144)
+  // The reference's PAM_DEBUG self-check (awfl/Dycore.h:36-58,136-138,224-251) at run time: the mass of every variable and member
+  // before / after each timeStep; violations (> 1e-10 relative and absolute) are printed as the reference prints them
+  void set_debug_conservation(bool on) { chk(pam_amd_awfl_set_debug_conservation(h, on ? 1 : 0)); debug_mass_ = on; }
+  int conservation_violations() const {
+    int n = 0;
+    if (debug_mass_) chk(pam_amd_awfl_get_conservation(h, &n, nullptr, nullptr, nullptr));
+    return n;
+  }
+  real conservation_max_rel_diff() const {
+    double r = 0;
+    if (debug_mass_) chk(pam_amd_awfl_get_conservation(h, nullptr, &r, nullptr, nullptr));
+    return r;
+  }
 
   // awfl/Dycore.h:65
   real compute_time_step(pam::PamCoupler const &coupler, real cfl = 0.8) const {
@@ -191,6 +248,17 @@ class Dycore {
   }
 
  private:
+#ifdef PAM_DEBUG
+  bool debug_mass_ = true;
+#else
+  bool debug_mass_ = false;
+#endif
+  void report_conservation() const {
+    if (!debug_mass_) return;
+    int n = 0;
+    chk(pam_amd_awfl_get_conservation(h, &n, nullptr, nullptr, nullptr));
+    if (n > 0) std::cout << pam_amd_awfl_conservation_report(h);                  // awfl/Dycore.h:240-247
+  }
   // the reference re-reads the option on every call (awfl/Dycore.h:284,624,1410)
   int sync_balance_option(pam::PamCoupler const &coupler) const {
     double cur;

@@ -17,17 +17,10 @@ inline void sponge_layer(pam::PamCoupler &coupler) {
   std::vector<double *> f;
   for (char const *n : {"density_dry", "uvel", "vvel", "wvel", "temp"}) f.push_back(dm.get<real, 4>(n).data());
   for (auto &n : coupler.get_tracer_names()) f.push_back(dm.get<real, 4>(n).data());
-  // scratch (per field, layer and member: horizontal means) lives in a DataManager entry registered on first use, like the
-  // reference's own module-owned entries (gcm_forcing_tend_*, gcm_forcing.h:132-147): no allocation -- and no device-wide
-  // synchronisation -- per CRM step
-  int nwork = (int)f.size() * num_layers * nens;
-  if (dm.entry_exists("sponge_layer_scratch") && (int)dm.get<real, 1>("sponge_layer_scratch").size() != nwork)
-    dm.unregister_and_deallocate("sponge_layer_scratch");
-  if (!dm.entry_exists("sponge_layer_scratch"))
-    dm.register_and_allocate<real>("sponge_layer_scratch", "sponge layer horizontal means", {nwork});
+  // (no scratch: the horizontal means live in the kernel's workgroups)
   int rc = pam_amd_sponge_layer(nens, nx, ny, nz, (int)f.size(), f.data(), dm.get<real const, 2>("vertical_interface_height").data(),
                                 dm.get<real const, 2>("vertical_midpoint_height").data(), coupler.get_option<real>("crm_dt"), num_layers,
-                                time_scale, dm.get<real, 1>("sponge_layer_scratch").data(), nullptr);
+                                time_scale, nullptr, nullptr);
   if (rc) endrun(pam_amd_awfl_last_error());
 }
 

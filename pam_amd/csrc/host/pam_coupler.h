@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <iostream>
 #include <map>
 #include <string>
@@ -43,6 +44,8 @@ class DeviceView {
 // pam_const.h:30-55: YAKL device arrays by rank; here every rank is the same non-owning view
 typedef pam::DeviceView<real> real5d;
 typedef pam::DeviceView<real const> realConst5d;
+typedef pam::DeviceView<int> int1d;
+typedef pam::DeviceView<int const> intConst1d;
 namespace pam {
 
 class Options {
@@ -143,6 +146,23 @@ class DataManager {
   }
 };
 
+// what yakl::timer_start / yakl::timer_stop are to the reference's run_module under -DPAM_FUNCTION_TIMERS (pam_coupler.h:144-150; YAKL
+// prints its timers in yakl::finalize()): wall time per module name, the device drained on both sides
+namespace function_timers {
+struct Entry { double seconds = 0; long calls = 0; std::chrono::steady_clock::time_point t0; };
+inline std::map<std::string, Entry> &table() { static std::map<std::string, Entry> t; return t; }
+inline void start(std::string const &name) { (void)hipDeviceSynchronize(); table()[name].t0 = std::chrono::steady_clock::now(); }
+inline void stop(std::string const &name) {
+  (void)hipDeviceSynchronize();
+  auto &e = table()[name];
+  e.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - e.t0).count();
+  e.calls++;
+}
+inline void print(std::ostream &os = std::cout) {
+  for (auto &t : table()) os << "timer " << t.first << ": " << t.second.seconds << " s in " << t.second.calls << " calls\n";
+}
+}  // namespace function_timers
+
 class PamCoupler {
   Options options;
   real xlen = -1, ylen = -1;
@@ -170,7 +190,24 @@ class PamCoupler {
   template <class T> T get_option(std::string key) const { return options.get_option<T>(key); }
   bool option_exists(std::string key) const { return options.option_exists(key); }
 
-  template <class F> void run_module(std::string name, F const &f) { dm.clean_all_entries(); f(*this); }
+  // pam_coupler.h:139-160: the module runs between the dirty-flag reset / report (-DPAM_FUNCTION_TRACE there; the flags are always
+  // kept here) and, with -DPAM_FUNCTION_TIMERS, inside a named timer (yakl::timer_start / timer_stop there: function_timers above)
+  template <class F> void run_module(std::string name, F const &f) {
+    dm.clean_all_entries();
+#ifdef PAM_FUNCTION_TIMERS
+    function_timers::start(name);
+#endif
+    f(*this);
+#ifdef PAM_FUNCTION_TIMERS
+    function_timers::stop(name);
+#endif
+#ifdef PAM_FUNCTION_TRACE
+    auto dirty = dm.get_dirty_entries();
+    std::cout << "MMF Module " << name << " wrote to the following coupler entries: ";
+    for (size_t e = 0; e < dirty.size(); e++) std::cout << dirty[e] << (e + 1 < dirty.size() ? ", " : "");
+    std::cout << "\n\n";
+#endif
+  }
 
   void allocate_coupler_state(int nz, int ny, int nx, int nens) {      // pam_coupler.h:255-293 (the entries the dycore uses)
     for (auto n : {"density_dry", "uvel", "vvel", "wvel", "temp"})
@@ -179,7 +216,8 @@ class PamCoupler {
     dm.register_and_allocate<real>("vertical_cell_dz", "", {nz, nens}, {"z", "nens"});
     dm.register_and_allocate<real>("vertical_midpoint_height", "", {nz, nens}, {"z", "nens"});
     for (auto n : {"gcm_density_dry", "gcm_uvel", "gcm_vvel", "gcm_wvel", "gcm_temp", "gcm_water_vapor", "gcm_cloud_water",
-                   "gcm_cloud_ice", "gcm_num_liq", "gcm_num_ice", "gcm_num_rain"})   // pam_coupler.h:270-281
+                   "gcm_cloud_ice", "gcm_num_liq", "gcm_num_ice", "gcm_num_rain",     // pam_coupler.h:270-281
+                   "ref_density_dry", "ref_density_vapor", "ref_density_liq", "ref_density_ice", "ref_temp"})
       dm.register_and_allocate<real>(n, "", {nz, nens}, {"z", "nens"});
   }
 

@@ -18,65 +18,65 @@ namespace {
 constexpr int MAX_FIELDS = 55;   // 5 state fields + pam_const.h:24 max_fields tracers
 struct FieldPtrs { double *p[MAX_FIELDS]; };
 
-// horizontal mean of level k = nz-1-kloc for (field, member), accumulated in the reference's serial atomicAdd order
-// (j outer, i inner: sponge_layer.h:73-76) -> deterministic.  wvel (field 3) keeps a zero mean (:34,:75).
-// Strips: the walk of a (field, layer, member) triple over its ny*nx cells is cut into `nstrip` strips of `cpt` consecutive cells,
-// one thread each, when one thread per triple would leave the chip mostly empty (fields*layers*nens threads: 480 wavefronts at
-// nens = 1024, ONE at nens = 1); every strip sums its cells in the reference's serial order (j outer, i inner) and a second, tiny
-// kernel adds the strips in ascending order.  With one strip the sums are the serial reference's bit for bit; with more they differ
-// by re-association only.  part: (triple, nstrip) partial sums, e fastest inside the triple index.
-__global__ void __launch_bounds__(64) sponge_mean_kernel(FieldPtrs F, int nens, int nx, int ny, int nz, int num_fields,
-                                                         int num_layers, double *__restrict__ havg, int cpt, int nstrip,
-                                                         double *__restrict__ part) {
-  const long long tt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long ntrip = (long long)num_fields * num_layers * nens;
-  if (tt >= ntrip * nstrip) return;
-  const int e = (int)(tt % nens);
-  const long long r = tt / nens;
-  const int sidx = (int)(r % nstrip);
-  const long long fl = r / nstrip;                       // field * num_layers + layer
-  const int kloc = (int)(fl % num_layers), ifld = (int)(fl / num_layers);
-  const long long t = fl * nens + e;                     // the triple's slot in havg
-  const int k = nz - 1 - kloc;
-  double s = 0.0;
-  if (ifld != 3) {
-    const double r_nx_ny = 1.0 / (nx * ny);
-    const double *f = F.p[ifld] + (long long)k * ny * nx * nens + e;
-    const int c_end = (sidx + 1) * cpt < ny * nx ? (sidx + 1) * cpt : ny * nx;
-    for (int c = sidx * cpt; c < c_end; c++) s += f[(long long)c * nens] * r_nx_ny;
+// Horizontal sums of the modules (sponge_layer, gcm_forcing): the reference accumulates them with atomicAdd, in no particular order.
+// Here every sum is deterministic and does not depend on how many members the call holds (a CRM must be bit-reproducible between a
+// 1-GPU run and a run sharded by members over N GPUs): the ny*nx cells of a level are dealt to MOD_NS = 16 SLOTS -- cell c belongs to
+// slot c % 16 --, a thread sums the cells of ONE slot of ONE member in ascending order, and the 16 slot sums of a member are added in
+// ascending order through LDS (slot_reduce).  A workgroup = (level, block of up to 64 members) x 16 slots: lanes are consecutive
+// members, so every step of a walk is one coalesced row per field, and the 16 wavefronts of a workgroup keep 16 rows of every field in
+// flight.  No scratch arrays: round 5's strip sums lived in stream-ordered allocations (hipMallocAsync / hipFreeAsync per call), which
+// on this runtime made the C++ driver's CRM loop irreproducible from run to run (tools/ci_variants.sh: the sponge layer relaxing
+// towards garbage means whenever the host synchronised between modules).
+constexpr int MOD_NS = 16;     // sponge_layer
+constexpr int GCM_NS = 8;      // gcm_forcing: ten fields per cell and three divisions -- workgroups of 512 lanes (a budget of 256 registers)
+// v[0..NQ) of every thread -> the member's totals (all NS threads of a member get them); red: NQ * NS * blockDim.x doubles of LDS
+template <int NQ, int NS = MOD_NS>
+__device__ __forceinline__ void slot_reduce(double (&v)[NQ], double *red) {
+  constexpr int MOD_NS = NS;
+  const int ME = blockDim.x, m = threadIdx.x, slot = threadIdx.y;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) red[(q * MOD_NS + slot) * ME + m] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    double a = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < MOD_NS; sl++) a += red[(q * MOD_NS + sl) * ME + m];
+    v[q] = a;
   }
-  if (nstrip > 1) part[(fl * nstrip + sidx) * nens + e] = s;
-  else havg[t] = s;
+  __syncthreads();
 }
-__global__ void __launch_bounds__(64) sponge_mean_finish_kernel(long long ntrip, int nens, int nstrip, const double *__restrict__ part,
-                                                                double *__restrict__ havg) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntrip) return;
-  const int e = (int)(t % nens);
-  const long long fl = t / nens;
-  double a = 0.0;
-  for (int q = 0; q < nstrip; q++) a += part[(fl * nstrip + q) * nens + e];
-  havg[t] = a;
-}
-__global__ void __launch_bounds__(256) sponge_relax_kernel(FieldPtrs F, int nens, int nx, int ny, int nz, int num_fields,
-                                                           int num_layers, const double *__restrict__ havg,
-                                                           const double *__restrict__ zint, const double *__restrict__ zmid,
-                                                           double time_factor) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long per_layer = (long long)ny * nx * nens;
-  if (t >= (long long)num_fields * num_layers * per_layer) return;
-  const long long c = t % per_layer;
-  const int e = (int)(c % nens);
-  const int kloc = (int)((t / per_layer) % num_layers);
-  const int ifld = (int)(t / (per_layer * num_layers));
-  const int k = nz - 1 - kloc;
+
+// modules::sponge_layer (pam_core/modules/sponge_layer.h:8-95), mean and relaxation in ONE kernel: grid (member blocks, layers, fields).
+// A workgroup sums its level of its field (wvel, field 3, keeps a zero mean: :34,:75), then relaxes the same cells -- their second
+// read comes out of the caches (the top five levels of every field: 0.25 GB at 1024 x 32x32x60).
+__global__ void __launch_bounds__(1024) sponge_kernel(FieldPtrs F, int nens, int ncol, int nz, int num_layers,
+                                                      const double *__restrict__ zint, const double *__restrict__ zmid,
+                                                      double time_factor) {
+  __shared__ double red[MOD_NS * 64];
+  const int ME = blockDim.x, slot = threadIdx.y;
+  const int e0 = (int)blockIdx.x * ME + (int)threadIdx.x;
+  const bool ok = e0 < nens;
+  const int e = ok ? e0 : nens - 1;
+  const int kloc = (int)blockIdx.y, ifld = (int)blockIdx.z, k = nz - 1 - kloc;
+  double *f = F.p[ifld] + (long long)k * ncol * nens + e;
+  double h[1] = {0.0};
+  if (ifld != 3) {
+    const double r_nx_ny = 1.0 / ncol;
+#pragma unroll 8
+    for (int c = slot; c < ncol; c += MOD_NS) h[0] += f[(long long)c * nens] * r_nx_ny;
+  }
+  slot_reduce<1>(h, red);
   const double ztop = zint[(long long)nz * nens + e];
   const double rel_dist = (ztop - zmid[(long long)k * nens + e]) / (ztop - zmid[(long long)(nz - 1 - (num_layers - 1)) * nens + e]);
   const double space_factor = (cos(M_PI * rel_dist) + 1) / 2;
   const double factor = space_factor * time_factor;
-  double *f = F.p[ifld] + (long long)k * per_layer + c;
-  const double h = havg[((long long)ifld * num_layers + kloc) * nens + e];
-  *f += (h - *f) * factor;
+  if (!ok) return;
+#pragma unroll 8
+  for (int c = slot; c < ncol; c += MOD_NS) {
+    const double v = f[(long long)c * nens];
+    f[(long long)c * nens] = v + (h[0] - v) * factor;
+  }
 }
 
 
@@ -230,10 +230,8 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
 
 // ---------------------------------------------------------------------------------------------------------------
 // GCM forcing of the CRM mean state (pam_core/modules/gcm_forcing.h).  The reference accumulates its horizontal means
-// and hole-filling masses with atomicAdd, in no particular order; here every sum is deterministic: a thread walks a strip of
-// consecutive cells of one (level, member) pair in the reference's serial order (j outer, i inner), and the strips of a pair
-// are added in ascending order (GcmStrips below; with one strip the sums equal the serial reference's bit for bit).
-// Consecutive lanes are consecutive members: each step of the walk is one coalesced row per field.
+// and hole-filling masses with atomicAdd, in no particular order; here every sum is deterministic (slots: slot_reduce above).
+// Consecutive lanes are consecutive members: each step of a walk is one coalesced row per field.
 struct Gcm10 { double *p[10]; };
 struct Gcm14 { double *p[14]; };
 enum { GF_RHOD, GF_U, GF_V, GF_T, GF_RV, GF_RL, GF_RI, GF_NC, GF_NI, GF_NR };
@@ -259,36 +257,22 @@ __device__ __forceinline__ void gcm_forcing_compute_finish(const Gcm10 &gcm, con
   tend.p[GT_QTOT][t] = tqv + tql + tqi;
 }
 
-// Strips.  A (level, member) pair's walk over its ny*nx cells is cut into `nstrip` strips of `cpt` consecutive cells, one thread
-// each, when one thread per pair would leave the chip mostly empty (nz*nens threads: 960 wavefronts at 1024 x 60, 1 at nens = 1);
-// every strip sums its cells in the reference's serial order and a second, tiny kernel adds the strips in ascending order.
-// With one strip the sums are those of the serial reference bit for bit; with more they differ by re-association only (the
-// reference itself accumulates with atomicAdd in no particular order).
-//   thread t -> (level k, strip s, member e), e fastest: consecutive lanes are consecutive members of the same cell.
-//   part     (nsum, nz, nstrip, nens) partial sums (only when nstrip > 1)
-struct GcmStrips { int cpt, nstrip; };
-__device__ __forceinline__ bool gcm_strip_of(long long t, int nens, int nz, GcmStrips S, int &k, int &sidx, int &e) {
-  if (t >= (long long)nz * S.nstrip * nens) return false;
-  e = (int)(t % nens);
-  const long long r = t / nens;
-  sidx = (int)(r % S.nstrip);
-  k = (int)(r / S.nstrip);
-  return true;
-}
-
-// compute_gcm_forcing_tendencies (gcm_forcing.h:17-210): column averages
-__global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
-                                                                 double r_dt_gcm, GcmStrips S, double *__restrict__ part) {
-  int k, sidx, e;
-  if (!gcm_strip_of((long long)blockIdx.x * blockDim.x + threadIdx.x, nens, nz, S, k, sidx, e)) return;
+// compute_gcm_forcing_tendencies (gcm_forcing.h:17-210): column averages; grid (member blocks, levels), block (members, GCM_NS slots)
+__global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_compute_kernel(int nens, int ncol, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+                                                                   double r_dt_gcm) {
+  __shared__ double red[5 * GCM_NS * 64];
+  const int ME = blockDim.x, slot = threadIdx.y;
+  const int e0 = (int)blockIdx.x * ME + (int)threadIdx.x;
+  const bool ok = e0 < nens;
+  const int e = ok ? e0 : nens - 1, k = (int)blockIdx.y;
   const long long t = (long long)k * nens + e;
-  const double r_nx_ny = 1.0 / (nx * ny);
+  const double r_nx_ny = 1.0 / ncol;
   double ca[10];
 #pragma unroll
   for (int f = 0; f < 10; f++) ca[f] = 0;
-  const long long base = (long long)k * ny * nx * nens + e;
-  const int c_end = (sidx + 1) * S.cpt < ny * nx ? (sidx + 1) * S.cpt : ny * nx;
-  for (int c = sidx * S.cpt; c < c_end; c++) {
+  const long long base = (long long)k * ncol * nens + e;
+#pragma unroll 2
+  for (int c = slot; c < ncol; c += GCM_NS) {
     const long long o = base + (long long)c * nens;
     const double rd = crm.p[GF_RHOD][o], rv = crm.p[GF_RV][o];
     ca[GF_RHOD] += rd * r_nx_ny;
@@ -302,26 +286,13 @@ __global__ void __launch_bounds__(64) gcm_forcing_compute_kernel(int nens, int n
     ca[GF_NI] += crm.p[GF_NI][o] * r_nx_ny;
     ca[GF_NR] += crm.p[GF_NR][o] * r_nx_ny;
   }
-  if (S.nstrip > 1) {
-#pragma unroll
-    for (int f = 0; f < 10; f++) part[(((long long)f * nz + k) * S.nstrip + sidx) * nens + e] = ca[f];
-    return;
+  double lo[5] = {ca[0], ca[1], ca[2], ca[3], ca[4]}, hi[5] = {ca[5], ca[6], ca[7], ca[8], ca[9]};
+  slot_reduce<5, GCM_NS>(lo, red);
+  slot_reduce<5, GCM_NS>(hi, red);
+  if (slot == 0 && ok) {
+    const double tot[10] = {lo[0], lo[1], lo[2], lo[3], lo[4], hi[0], hi[1], hi[2], hi[3], hi[4]};
+    gcm_forcing_compute_finish(gcm, tend, tot, t, r_dt_gcm);
   }
-  gcm_forcing_compute_finish(gcm, tend, ca, t, r_dt_gcm);
-}
-__global__ void __launch_bounds__(64) gcm_forcing_compute_finish_kernel(int nens, int nz, Gcm10 gcm, Gcm14 tend, double r_dt_gcm,
-                                                                        GcmStrips S, const double *__restrict__ part) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)nz * nens) return;
-  const int e = (int)(t % nens), k = (int)(t / nens);
-  double ca[10];
-#pragma unroll
-  for (int f = 0; f < 10; f++) {
-    double a = 0;
-    for (int q = 0; q < S.nstrip; q++) a += part[(((long long)f * nz + k) * S.nstrip + q) * nens + e];
-    ca[f] = a;
-  }
-  gcm_forcing_compute_finish(gcm, tend, ca, t, r_dt_gcm);
 }
 
 // apply_gcm_forcing_tendencies, main kernel + diagnostics (gcm_forcing.h:361-429) fused with the first two kernels of
@@ -339,79 +310,64 @@ __device__ __forceinline__ void gcm_forcing_apply_finish(const Gcm10 &gcm, const
     if (neg[s] > pos[s]) atomicOr(&flags[3 + s], 1);
   }
 }
-// strips as in gcm_forcing_compute_kernel; part: (9, nz, nstrip, nens) = colavg[3], neg[3], pos[3]
-__global__ void __launch_bounds__(64) gcm_forcing_apply_kernel(int nens, int nx, int ny, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
-                                                               const double *__restrict__ dz, double dt, double r_dt_gcm,
-                                                               double *__restrict__ work, int *__restrict__ flags, GcmStrips S,
-                                                               double *__restrict__ part) {
-  int k, sidx, e;
-  if (!gcm_strip_of((long long)blockIdx.x * blockDim.x + threadIdx.x, nens, nz, S, k, sidx, e)) return;
+// grid (member blocks, levels), block (members, GCM_NS slots): every cell is read and written once, the nine sums of a
+// (level, member) pair -- colavg[3], neg[3], pos[3] -- go through slot_reduce
+__global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_apply_kernel(int nens, int ncol, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+                                                                 const double *__restrict__ dz, double dt, double r_dt_gcm,
+                                                                 double *__restrict__ work, int *__restrict__ flags) {
+  __shared__ double red[5 * GCM_NS * 64];
+  const int ME = blockDim.x, slot = threadIdx.y;
+  const int e0 = (int)blockIdx.x * ME + (int)threadIdx.x;
+  const bool ok = e0 < nens;
+  const int e = ok ? e0 : nens - 1, k = (int)blockIdx.y;
   const long long t = (long long)k * nens + e;
   const long long n2 = (long long)nz * nens;
-  const double r_nx_ny = 1.0 / (nx * ny);
+  const double r_nx_ny = 1.0 / ncol;
   const double dzk = dz[t];
   const double t_rd = tend.p[GT_RHOD][t] * dt, t_u = tend.p[GT_U][t] * dt, t_v = tend.p[GT_V][t] * dt, t_t = tend.p[GT_T][t] * dt;
   const double t_qv = tend.p[GT_QV][t] * dt, t_ql = tend.p[GT_QL][t] * dt, t_qi = tend.p[GT_QI][t] * dt;
   const double t_nc = tend.p[GT_NC][t] * dt, t_ni = tend.p[GT_NI][t] * dt, t_nr = tend.p[GT_NR][t] * dt;
   double colavg[3] = {0, 0, 0}, neg[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
-  const long long base = (long long)k * ny * nx * nens + e;
-  const int c_end = (sidx + 1) * S.cpt < ny * nx ? (sidx + 1) * S.cpt : ny * nx;
-  for (int c = sidx * S.cpt; c < c_end; c++) {
-    const long long o = base + (long long)c * nens;
-    const double rho_d_old = crm.p[GF_RHOD][o];
-    const double rho_d = rho_d_old + t_rd;
-    crm.p[GF_RHOD][o] = rho_d;
-    crm.p[GF_U][o] += t_u;
-    crm.p[GF_V][o] += t_v;
-    crm.p[GF_T][o] += t_t;
-    const double rv_old = crm.p[GF_RV][o];
-    const double qv_new = rv_old / (rho_d_old + rv_old) + t_qv;
-    const double ql_new = crm.p[GF_RL][o] / (rho_d_old + rv_old) + t_ql;
-    const double qi_new = crm.p[GF_RI][o] / (rho_d_old + rv_old) + t_qi;
-    double w[3];
-    w[0] = qv_new * rho_d / (1 - qv_new);
-    w[1] = ql_new * (rho_d + w[0]);
-    w[2] = qi_new * (rho_d + w[0]);
-    double nc = crm.p[GF_NC][o] + t_nc, ni = crm.p[GF_NI][o] + t_ni, nr = crm.p[GF_NR][o] + t_nr;   // :388-393
-    if (nc < 0) nc = 0;
-    if (ni < 0) ni = 0;
-    if (nr < 0) nr = 0;
-    crm.p[GF_NC][o] = nc; crm.p[GF_NI][o] = ni; crm.p[GF_NR][o] = nr;
+  const long long base = (long long)k * ncol * nens + e;
+  if (ok) {
+#pragma unroll 2
+    for (int c = slot; c < ncol; c += GCM_NS) {
+      const long long o = base + (long long)c * nens;
+      const double rho_d_old = crm.p[GF_RHOD][o];
+      const double rho_d = rho_d_old + t_rd;
+      crm.p[GF_RHOD][o] = rho_d;
+      crm.p[GF_U][o] += t_u;
+      crm.p[GF_V][o] += t_v;
+      crm.p[GF_T][o] += t_t;
+      const double rv_old = crm.p[GF_RV][o];
+      const double qv_new = rv_old / (rho_d_old + rv_old) + t_qv;
+      const double ql_new = crm.p[GF_RL][o] / (rho_d_old + rv_old) + t_ql;
+      const double qi_new = crm.p[GF_RI][o] / (rho_d_old + rv_old) + t_qi;
+      double w[3];
+      w[0] = qv_new * rho_d / (1 - qv_new);
+      w[1] = ql_new * (rho_d + w[0]);
+      w[2] = qi_new * (rho_d + w[0]);
+      double nc = crm.p[GF_NC][o] + t_nc, ni = crm.p[GF_NI][o] + t_ni, nr = crm.p[GF_NR][o] + t_nr;   // :388-393
+      if (nc < 0) nc = 0;
+      if (ni < 0) ni = 0;
+      if (nr < 0) nr = 0;
+      crm.p[GF_NC][o] = nc; crm.p[GF_NI][o] = ni; crm.p[GF_NR][o] = nr;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-      colavg[s] += w[s] * r_nx_ny;
-      if (w[s] < 0) { neg[s] += -w[s] * dzk; w[s] = 0; }
-      if (w[s] > 0) pos[s] += w[s] * dzk;
-      crm.p[GF_RV + s][o] = w[s];
+      for (int s = 0; s < 3; s++) {
+        colavg[s] += w[s] * r_nx_ny;
+        if (w[s] < 0) { neg[s] += -w[s] * dzk; w[s] = 0; }
+        if (w[s] > 0) pos[s] += w[s] * dzk;
+        crm.p[GF_RV + s][o] = w[s];
+      }
     }
   }
-  if (S.nstrip > 1) {
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-      part[(((long long)s * nz + k) * S.nstrip + sidx) * nens + e] = colavg[s];
-      part[(((long long)(3 + s) * nz + k) * S.nstrip + sidx) * nens + e] = neg[s];
-      part[(((long long)(6 + s) * nz + k) * S.nstrip + sidx) * nens + e] = pos[s];
-    }
-    return;
+  double a5[5] = {colavg[0], colavg[1], colavg[2], neg[0], neg[1]}, b4[4] = {neg[2], pos[0], pos[1], pos[2]};
+  slot_reduce<5, GCM_NS>(a5, red);
+  slot_reduce<4, GCM_NS>(b4, red);
+  if (slot == 0 && ok) {
+    const double ca[3] = {a5[0], a5[1], a5[2]}, ng[3] = {a5[3], a5[4], b4[0]}, ps[3] = {b4[1], b4[2], b4[3]};
+    gcm_forcing_apply_finish(gcm, tend, ca, ng, ps, t, n2, r_dt_gcm, work, flags);
   }
-  gcm_forcing_apply_finish(gcm, tend, colavg, neg, pos, t, n2, r_dt_gcm, work, flags);
-}
-__global__ void __launch_bounds__(64) gcm_forcing_apply_finish_kernel(int nens, int nz, Gcm10 gcm, Gcm14 tend, double r_dt_gcm,
-                                                                      double *__restrict__ work, int *__restrict__ flags,
-                                                                      GcmStrips S, const double *__restrict__ part) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long n2 = (long long)nz * nens;
-  if (t >= n2) return;
-  const int e = (int)(t % nens), k = (int)(t / nens);
-  double a[9];
-#pragma unroll
-  for (int f = 0; f < 9; f++) {
-    double x = 0;
-    for (int q = 0; q < S.nstrip; q++) x += part[(((long long)f * nz + k) * S.nstrip + q) * nens + e];
-    a[f] = x;
-  }
-  const double colavg[3] = {a[0], a[1], a[2]}, neg[3] = {a[3], a[4], a[5]}, pos[3] = {a[6], a[7], a[8]};
-  gcm_forcing_apply_finish(gcm, tend, colavg, neg, pos, t, n2, r_dt_gcm, work, flags);
 }
 
 // fill_holes, level pass (:243-250)
@@ -511,7 +467,7 @@ extern "C" int pam_amd_set_last_error_(int code, const char *msg);   // defined 
 extern "C" int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fields, double *const *fields,
                                     const double *zint, const double *zmid, double crm_dt, int num_layers, double time_scale,
                                     double *workspace, void *stream) {
-  if (nens < 1 || nx < 1 || ny < 1 || nz < 1 || !fields || !zint || !zmid || !workspace)
+  if (nens < 1 || nx < 1 || ny < 1 || nz < 1 || !fields || !zint || !zmid)
     return pam_amd_set_last_error_(PAM_AMD_EINVAL, "sponge_layer: bad dimensions or null pointer");
   if (num_fields < 5 || num_fields > MAX_FIELDS)
     return pam_amd_set_last_error_(PAM_AMD_EINVAL, "sponge_layer: num_fields must be 5 + number of tracers (<= 55)");
@@ -528,27 +484,10 @@ extern "C" int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fi
     F.p[i] = fields[i];
   }
   hipStream_t s = (hipStream_t)stream;
-  const long long n1 = (long long)num_fields * num_layers * nens;
-  // strips of the horizontal walks: at most 64 per (field, layer, member), never fewer than 8 cells each.  The count follows from
-  // (nx, ny) ALONE: the order in which a member's mean is summed must not depend on how many members this call holds, or a CRM
-  // would not be bit-reproducible between a 1-GPU run and a run sharded by members over N GPUs
-  const long long cells = (long long)ny * nx;
-  long long want = cells / 8;
-  if (want > 64) want = 64;
-  if (want < 1) want = 1;
-  const int cpt = (int)((cells + want - 1) / want), nstrip = (int)((cells + cpt - 1) / cpt);
-  double *part = nullptr;     // partial sums of the strips: stream-ordered scratch
-  if (nstrip > 1 && hipMallocAsync((void **)&part, (size_t)n1 * nstrip * sizeof(double), s) != hipSuccess)
-    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "sponge_layer: no memory for the partial sums");
-  hipLaunchKernelGGL(sponge_mean_kernel, dim3((unsigned)((n1 * nstrip + 63) / 64)), dim3(64), 0, s, F, nens, nx, ny, nz, num_fields,
-                     num_layers, workspace, cpt, nstrip, part);
-  if (nstrip > 1) {
-    hipLaunchKernelGGL(sponge_mean_finish_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, n1, nens, nstrip, part, workspace);
-    (void)hipFreeAsync(part, s);
-  }
-  const long long n2 = n1 * ny * nx;
-  hipLaunchKernelGGL(sponge_relax_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, F, nens, nx, ny, nz, num_fields,
-                     num_layers, workspace, zint, zmid, crm_dt / time_scale);
+  (void)workspace;      // (the horizontal means live in the workgroups since ABI 5; the argument is kept for callers of ABI <= 4)
+  const int ME = nens < 64 ? nens : 64;
+  const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)num_layers, (unsigned)num_fields), block((unsigned)ME, (unsigned)MOD_NS);
+  hipLaunchKernelGGL(sponge_kernel, grid, block, 0, s, F, nens, nx * ny, nz, num_layers, zint, zmid, crm_dt / time_scale);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
@@ -664,20 +603,6 @@ int gcm_check(const char *who, int nens, int nx, int ny, int nz, const void *con
 }
 }  // namespace
 
-namespace {
-// strips of the per-(level, member) walks (GcmStrips): enough threads for ~4 wavefronts per SIMD, never fewer than 8 cells each
-GcmStrips gcm_strips(int nens, int nx, int ny, int nz) {
-  const long long pairs = (long long)nz * nens, cells = (long long)ny * nx;
-  long long want = (262144 + pairs - 1) / pairs;
-  if (want > cells / 8) want = cells / 8;
-  if (want < 1) want = 1;
-  GcmStrips S;
-  S.cpt = (int)((cells + want - 1) / want);
-  S.nstrip = (int)((cells + S.cpt - 1) / S.cpt);
-  return S;
-}
-}  // namespace
-
 extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, const double *const *crm, const double *const *gcm,
                                            double *const *tend, double gcm_physics_dt, void *stream) {
   if (int rc = gcm_check("compute_gcm_forcing_tendencies", nens, nx, ny, nz, (const void *const *)crm, 10,
@@ -686,19 +611,10 @@ extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, con
   Gcm10 C, G; Gcm14 T;
   for (int i = 0; i < 10; i++) { C.p[i] = const_cast<double *>(crm[i]); G.p[i] = const_cast<double *>(gcm[i]); }
   for (int i = 0; i < 14; i++) T.p[i] = tend[i];
-  const long long n2 = (long long)nz * nens;
   hipStream_t s = (hipStream_t)stream;
-  const GcmStrips S = gcm_strips(nens, nx, ny, nz);
-  double *part = nullptr;     // partial sums of the strips: stream-ordered scratch, gone when the kernels are
-  if (S.nstrip > 1 && hipMallocAsync((void **)&part, (size_t)10 * n2 * S.nstrip * sizeof(double), s) != hipSuccess)
-    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "compute_gcm_forcing_tendencies: no memory for the partial sums");
-  hipLaunchKernelGGL(gcm_forcing_compute_kernel, dim3((unsigned)((n2 * S.nstrip + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz,
-                     C, G, T, 1.0 / gcm_physics_dt, S, part);
-  if (S.nstrip > 1) {
-    hipLaunchKernelGGL(gcm_forcing_compute_finish_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nz, G, T,
-                       1.0 / gcm_physics_dt, S, part);
-    (void)hipFreeAsync(part, s);
-  }
+  const int ME = nens < 64 ? nens : 64;
+  const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)nz), block((unsigned)ME, (unsigned)GCM_NS);
+  hipLaunchKernelGGL(gcm_forcing_compute_kernel, grid, block, 0, s, nens, nx * ny, nz, C, G, T, 1.0 / gcm_physics_dt);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
@@ -719,17 +635,10 @@ extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, doubl
   double *glob = workspace + 6 * n2;
   int *flags = (int *)(glob + 2 * (long long)nens);
   if (hipMemsetAsync(flags, 0, 8 * sizeof(int), s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
-  const GcmStrips S = gcm_strips(nens, nx, ny, nz);
-  double *part = nullptr;
-  if (S.nstrip > 1 && hipMallocAsync((void **)&part, (size_t)9 * n2 * S.nstrip * sizeof(double), s) != hipSuccess)
-    return pam_amd_set_last_error_(PAM_AMD_ENOGPU, "apply_gcm_forcing_tendencies: no memory for the partial sums");
-  hipLaunchKernelGGL(gcm_forcing_apply_kernel, dim3((unsigned)((n2 * S.nstrip + 63) / 64)), dim3(64), 0, s, nens, nx, ny, nz, C, G, T,
-                     dz, crm_dt, 1.0 / gcm_physics_dt, workspace, flags, S, part);
-  if (S.nstrip > 1) {
-    hipLaunchKernelGGL(gcm_forcing_apply_finish_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, nens, nz, G, T,
-                       1.0 / gcm_physics_dt, workspace, flags, S, part);
-    (void)hipFreeAsync(part, s);
-  }
+  const int ME = nens < 64 ? nens : 64;
+  const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)nz), block((unsigned)ME, (unsigned)GCM_NS);
+  hipLaunchKernelGGL(gcm_forcing_apply_kernel, grid, block, 0, s, nens, nx * ny, nz, C, G, T, dz, crm_dt, 1.0 / gcm_physics_dt, workspace,
+                     flags);
   // "Only do the hole filling if there's negative mass" (:432-436) and ScalarLiveOut neg_too_large (:241,:252): one read-back
   int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)

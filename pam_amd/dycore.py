@@ -242,6 +242,21 @@ class Dycore:
     def set_range_schedule(self, independent):
         check(self._lib.pam_amd_awfl_set_range_schedule(self._h, int(bool(independent))))
 
+    def set_debug_conservation(self, enable=True):
+        """the reference's PAM_DEBUG mass check (Dycore.h:36-58, :136-138, :224-251) as an opt-in: masses of every variable and member
+        before / after each timeStep by a device reduction"""
+        check(self._lib.pam_amd_awfl_set_debug_conservation(self._h, int(bool(enable))))
+
+    def conservation(self):
+        """(violations, max_rel_diff, worst_variable, worst_member, report) of the most recent timeStep; variables: tracers in
+        registration order, then rho, then rho*theta"""
+        n, wv, wm, mr = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(self._lib.pam_amd_awfl_get_conservation(self._h, C.byref(n), C.byref(mr), C.byref(wv), C.byref(wm)))
+        return n.value, mr.value, wv.value, wm.value, (self._lib.pam_amd_awfl_conservation_report(self._h) or b"").decode()
+
+    def debug_inject_mass_fault(self, variable, k, j, i, member, factor):
+        check(self._lib.pam_amd_awfl_debug_inject_mass_fault(self._h, int(variable), int(k), int(j), int(i), int(member), float(factor)))
+
     FOLD = {"auto": 0, "off": 1, "on": 2}
 
     def set_yz_fold(self, mode="auto"):

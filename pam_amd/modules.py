@@ -20,13 +20,11 @@ def sponge_layer(coupler):
     tens = [dm.get(n) for n in names]
     zint = dm.get("vertical_interface_height", readonly=True)
     zmid = dm.get("vertical_midpoint_height", readonly=True)
-    work = torch.empty(len(tens) * int(num_layers) * nens, dtype=torch.float64, device=coupler.device)
     ptrs = (C.c_void_p * len(tens))(*[t.data_ptr() for t in tens])
     with torch.cuda.device(coupler.device):
         check(lib.pam_amd_sponge_layer(nens, nx, ny, nz, len(tens), ptrs, zint.data_ptr(), zmid.data_ptr(),
                                        float(coupler.get_option("crm_dt")), int(num_layers), float(time_scale),
-                                       work.data_ptr(), torch.cuda.current_stream(coupler.device).cuda_stream))
-    return work   # keeps the scratch alive until the caller drops it (the launch is asynchronous)
+                                       None, torch.cuda.current_stream(coupler.device).cuda_stream))
 
 
 GCM_FORCING_CRM = ("density_dry", "uvel", "vvel", "temp", "water_vapor", "cloud_water", "ice", "cloud_water_num", "ice_num",

@@ -32,6 +32,7 @@ REF_DM = {"add_dimension", "clean_all_entries", "clean_entry", "entry_exists", "
 
 SOURCES = [os.path.join(HOST, "dynamics", "awfl_amd", "Dycore.h"), os.path.join(HOST, "dynamics", "spam_surface", "Dycore.h"),
            os.path.join(HOST, "modules", "sponge_layer.h"), os.path.join(HOST, "modules", "gcm_forcing.h"),
+           os.path.join(HOST, "modules", "broadcast_initial_gcm_column.h"), os.path.join(HOST, "modules", "perturb_temperature.h"),
            os.path.join(HOST, "physics", "micro", "kessler_amd", "Microphysics.h"), os.path.join(ROOT, "examples", "driver.cpp")]
 
 

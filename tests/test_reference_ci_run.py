@@ -1,0 +1,105 @@
+"""The reference's one and only automated run of the AWFL path, as a test of THIS path.
+
+`.github/workflows/mmf-simplified-ubuntu.yml:27-39` builds the standalone driver and runs
+`./driver ../inputs/ci/input_pama.yaml` -- 65 x 1 x 50 cells, nens = 1, xlen 128 km, 50 equal levels to 20 km, dt_crm_phys 20 s,
+1800 s = 2 GCM steps x 45 CRM steps -- and passes when the run does not crash.  `examples/driver --yaml` (examples/driver.cpp:
+run_yaml) is that driver's flow over the C++ plug-in surface: allocate_coupler_state -> set_grid -> micro.init -> dycore.init ->
+initialize_from_supercell_column (driver.cpp:19-77: the supercell column, broadcast, temperature perturbation -- all on the
+device) -> per GCM step { declare_current_profile_as_hydrostatic; per CRM step { dycore -> sponge_layer -> micro } }.  P3 and
+SHOC (the CI build's micro / sgs) and the GCM forcing that works on P3's tracer set are outside this repository's scope; Kessler
+is the microphysics.  What is asserted goes beyond "no crash": bounds on the final state, the reference's own runtime invariant
+(Dycore.h:224-251: the mass of every variable, per member and timeStep, within 1e-10) through the opt-in check of the C ABI, the
+first CRM steps against the oracle, and the member-lane mapping (64 members) reproducing the one-member run bit for bit."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from parity_gate import compare
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "examples", "driver")
+YAML = os.path.join(ROOT, "tests", "golden", "ci_input_pama.yaml")
+NX, NY, NZ = 65, 1, 50
+XLEN, YLEN, CRM_DT = 128000.0, 64000.0, 20.0
+CONSTS = dict(R_d=287.0, cp_d=1003.0, R_v=461.0, cp_v=1859.0, p0=1.0e5, grav=9.81)     # kessler/Microphysics.h:66-71
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tmp_path, tag, *opts):
+    assert os.path.exists(DRIVER), "examples/driver missing: run __graft_entry__.build()"
+    outp = str(tmp_path / ("out_%s.bin" % tag))
+    r = subprocess.run([DRIVER, "--yaml", YAML] + list(opts) + [outp], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    stats = json.loads(r.stdout.strip().split("\n")[-1])
+    nens = stats["nens"]
+    raw = np.fromfile(outp, dtype="<f8")
+    ncell = NZ * NY * NX * nens
+    fields = raw[:8 * ncell].reshape(8, NZ, NY, NX, nens)
+    return stats, fields, r.stdout
+
+
+def test_reference_ci_run_1800_seconds(tmp_path):
+    stats, f, out = _run(tmp_path, "full", "--check")
+    assert "SSPRK3+WENO+FV A-grid" in out and "Simulation Time: 1800" in out
+    assert stats["crm_steps"] == 90 and stats["etime"] == 1800.0 and stats["dt_crm_phys"] == 20.0
+    assert out.count("Etime , dtphys, maxw:") == 9                 # out_freq 200 s (driver.cpp:257-271)
+    # ~2 000 sub-steps: dz = 400 m, c ~ 350 m/s -> dt_dyn ~ 0.8-0.9 s
+    assert 1800 <= stats["substeps"] <= 2700, stats["substeps"]
+    assert stats["finite"] and np.isfinite(f).all()
+    assert stats["rho_d_min"] > 0.05 and f[0].min() > 0.05        # the density at 20 km is ~0.09 kg/m3
+    assert 190.0 < stats["temp_min"] and stats["temp_max"] < 320.0   # the sounding: 300 K at the ground, 213 K above 12 km
+    assert f[5].min() >= 0.0 and f[6].min() >= 0.0 and f[7].min() >= 0.0   # positive-definite tracers stay non-negative
+    # the perturbed sounding (0.1 K in the lowest quarter) has not blown up and is not dead either
+    # (measured on MI355X: 0.027 ... 0.048 m/s at the nine outputs)
+    assert 5.0e-3 < stats["maxw_any_output"] < 0.5 and 5.0e-3 < stats["maxw_final"] < 0.5, stats["maxw_series"]
+    # the reference's own runtime invariant, every one of the 90 timeSteps, every variable (Dycore.h:224-251)
+    assert stats["conservation_checked"] and stats["conservation_violations"] == 0, stats
+    assert stats["conservation_max_rel_diff"] <= 1.0e-10, stats["conservation_max_rel_diff"]
+
+
+def test_first_crm_steps_of_the_ci_run_match_the_oracle(tmp_path):
+    from oracle import awfl_oracle as ao
+    nsteps, nens = 5, 1
+    stats, got, _ = _run(tmp_path, "five", "--steps", str(nsteps))
+    assert stats["crm_steps"] == nsteps
+    zint = np.linspace(0.0, 20000.0, NZ + 1)
+    zi = np.ascontiguousarray(np.broadcast_to(zint[:, None], (NZ + 1, nens)))
+    zm = 0.5 * (zi[:-1] + zi[1:])
+    # initialize_from_supercell_column (driver.cpp:19-77) with the oracle's restatements
+    cols = ao.supercell_init(zint, CONSTS)
+    gcm = {n: np.ascontiguousarray(np.broadcast_to(c[:, None], (NZ, nens))) for n, c in zip(ao.BROADCAST_GCM, cols)}
+    crm = {n: np.zeros((NZ, NY, NX, nens)) for n in ao.BROADCAST_CRM}
+    ao.broadcast_initial_gcm_column(crm, gcm)
+    ao.perturb_temperature(crm["temp"], np.zeros(nens, dtype=np.int32), 0.1)
+    f = {k: crm[k] for k in ("density_dry", "uvel", "vvel", "wvel", "temp")}
+    f["tracers"] = np.zeros((3, NZ, NY, NX, nens))
+    f["tracers"][0] = crm["water_vapor"]
+    o = ao.OracleDycore(nens, NX, NY, NZ, XLEN, YLEN, np.diff(zint), [True] * 3, [True] * 3, 0, consts=CONSTS)
+    o.declare_current_profile_as_hydrostatic(f)
+    nsub = 0
+    for _ in range(nsteps):
+        nsub += o.time_step(f, CRM_DT)[0]
+        ao.sponge_layer(f, zi, zm, CRM_DT)
+        trc = [np.ascontiguousarray(f["tracers"][t]) for t in range(3)]
+        ao.kessler(trc[0], trc[1], trc[2], f["density_dry"], f["temp"], zm, CRM_DT, CONSTS)
+        for t in range(3):
+            f["tracers"][t] = trc[t]
+    assert nsub == stats["substeps"], (nsub, stats["substeps"])
+    g = {"density_dry": got[0], "uvel": got[1], "vvel": got[2], "wvel": got[3], "temp": got[4], "tracers": got[5:]}
+    compare(g, f, ["water_vapor", "cloud_liquid", "precip_liquid"], nsub)      # tests/parity_gate.py
+
+
+def test_member_lanes_reproduce_the_one_member_ci_run_bit_for_bit(tmp_path):
+    """65 x 1 x 50 with ONE member runs as tile kernels with flat lanes, with 64 members as member-lane sweeps: every member of the
+    ensemble (the driver seeds every member's perturbation alike, driver.cpp:74-76) is the one-member run"""
+    s1, a, _ = _run(tmp_path, "n1", "--steps", "10")
+    s64, b, _ = _run(tmp_path, "n64", "--steps", "10", "--nens", "64")
+    assert s1["substeps"] == s64["substeps"], "the CFL minimum over the ensemble changed the sub-cycle count: not comparable"
+    assert np.isfinite(b).all()
+    for i in range(8):
+        for e in (0, 1, 37, 63):
+            assert np.array_equal(a[i][..., 0], b[i][..., e]), (i, e)
