@@ -511,7 +511,7 @@ def stage_rooflines(job, alone):
     return out
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def load_profile(cfg_name):
@@ -523,6 +523,15 @@ def load_profile(cfg_name):
     prof = json.load(open(path))
     if prof.get("csrc_hash") != csrc_hash():
         return None, "%s was measured on another build of pam_amd/csrc: not reported" % os.path.basename(path)
+    # the launch shapes of the tile kernels follow the device's CU count (xtile_geometry, choose_flux_tiles): a profile taken on a part
+    # with another CU count describes other launches
+    try:
+        import torch
+        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    except Exception:
+        ncu = None
+    if prof.get("compute_units") and ncu and prof["compute_units"] != ncu:
+        return None, "%s was measured on a part with %d compute units (this one: %d): not reported" % (os.path.basename(path), prof["compute_units"], ncu)
     return prof, "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE, separate passes, this build (%s)" % prof["csrc_hash"]
 
 
@@ -551,7 +560,7 @@ def measure_roofline(job, args, profile_key=None):
         kname = "awfl_xtr_kernel<%s>" % dom[3:]
     mine = [k for k in kernel_rooflines if k["kernel"] == kname]
     prof, tnote = (load_profile(profile_key) if profile_key else (None, "not a profiled workload"))
-    traffic, stage_traffic, valu = None, None, None
+    traffic, stage_traffic, valu, stage_valu_insts = None, None, None, 0.0
     if prof is not None:
         pk = prof["kernels"]
 
@@ -563,15 +572,25 @@ def measure_roofline(job, args, profile_key=None):
             if name.startswith("awfl_trfix") and "awfl_trfix_flat_kernel" in pk:
                 return "awfl_trfix_flat_kernel"
             return name
-        if pkey(kname) in pk:
-            traffic = pk[pkey(kname)]["hbm_bytes_per_stage"]
+        def pkeys(name):     # every kernel family of the profile that bench.py's `name` stands for: with per-member vertical grids
+            ks = [pkey(name)]    # the "flux" launches are awfl_flux_kernel (y) + awfl_fluxz_pe_kernel (z)
+            if name == "awfl_flux_kernel" and "awfl_fluxz_pe_kernel" in pk:
+                ks.append("awfl_fluxz_pe_kernel")
+            return [k for k in ks if k in pk]
+
+        def psum(name, field):
+            vals = [pk[k][field] for k in pkeys(name) if field in pk[k]]
+            return sum(vals) if vals else None
+        traffic = psum(kname, "hbm_bytes_per_stage")
         for kr in kernel_rooflines:
-            k = pkey(kr["kernel"])
-            if k in pk:
-                kr["traffic"] = pk[k]["hbm_bytes_per_stage"]
-        names = set(pkey(kr["kernel"]) for kr in kernel_rooflines)
-        stage_traffic = sum(pk[k]["hbm_bytes_per_stage"] for k in names if k in pk)
-        c = pk.get(pkey(kname), {})
+            tr_ = psum(kr["kernel"], "hbm_bytes_per_stage")
+            if tr_ is not None:
+                kr["traffic"] = tr_
+        names = set(k for kr in kernel_rooflines for k in pkeys(kr["kernel"]))
+        stage_traffic = sum(pk[k]["hbm_bytes_per_stage"] for k in names)
+        stage_valu_insts = sum(pk[k].get("valu_insts_per_stage", 0.0) for k in names)
+        c = {"valu_insts_per_stage": psum(kname, "valu_insts_per_stage"), "busy_cycles_per_xcd_per_stage": psum(kname, "busy_cycles_per_xcd_per_stage")}
+        c = {k: v for k, v in c.items() if v}
         if "valu_insts_per_stage" in c and "busy_cycles_per_xcd_per_stage" in c:
             # counter-based VALU figures of the dominant kernel: a wave-level fp64 VALU instruction occupies its SIMD for 4
             # cycles; 1024 SIMDs.  issue_frac: of the cycles the chip was busy (at the clock it actually held, ~1.9 GHz under this
@@ -586,6 +605,11 @@ def measure_roofline(job, args, profile_key=None):
         valu = {"bound": "fp64-valu", "achieved": mine[0]["fp64_TFLOPs"], "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": mine[0]["valu_frac"], "source": "instruction-count model (no counter profile of this build)"}
     stage_ms = sum(alone[k]["total_ms"] for k in stage) / nstage
+    # the whole stage against its FP64-issue floor at the clock the chip held (every wave-level VALU instruction of every stage kernel
+    # occupies its SIMD for 4 cycles; 1024 SIMDs): the roofline that binds this path
+    stage_valu_frac = None
+    if prof is not None and valu and "sustained_clock_GHz_approx" in valu and stage_valu_insts:
+        stage_valu_frac = stage_valu_insts * 4.0 / 1024.0 / (valu["sustained_clock_GHz_approx"] * 1e9) / (stage_ms * 1e-3)
     # which roofline binds the dominant kernel: FP64 vector issue when its VALU fraction exceeds its HBM fraction
     hbm_frac = achieved / HBM_PEAK_GBS
     bound = "fp64-valu" if (valu and valu["frac"] > hbm_frac) else "hbm"
@@ -605,7 +629,12 @@ def measure_roofline(job, args, profile_key=None):
                 "stage_frac": alg_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "stage_traffic": stage_traffic,
                 "stage_traffic_ratio": (stage_traffic / alg_bytes) if stage_traffic else None,
-                "valu": valu}
+                "valu": valu,
+                # flat copies of the figures that bind
+                "valu_frac_spec_clock": valu.get("frac") if valu else None,
+                "valu_issue_frac": valu.get("issue_frac_at_sustained_clock") if valu else None,
+                "sustained_clock_GHz": valu.get("sustained_clock_GHz_approx") if valu else None,
+                "stage_valu_frac": stage_valu_frac}
     return roofline, kernels, kernel_rooflines
 
 
@@ -716,7 +745,8 @@ def compact_line(full):
     r = full.get("roofline")
     if r:
         rr = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "ms_per_stage", "alg_bytes_per_launch",
-                                    "stage_ms_back_to_back", "stage_frac", "stage_traffic", "stage_traffic_ratio")}
+                                    "stage_ms_back_to_back", "stage_frac", "stage_traffic", "stage_traffic_ratio", "valu_frac_spec_clock",
+                                    "valu_issue_frac", "sustained_clock_GHz", "stage_valu_frac")}
         v = r.get("valu")
         if v:
             rr["valu"] = {k: v[k] for k in ("frac", "issue_frac_at_sustained_clock", "sustained_clock_GHz_approx") if k in v}

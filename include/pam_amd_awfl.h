@@ -151,6 +151,10 @@ int pam_amd_awfl_reset_kernel_timing(pam_amd_awfl_t *h);
 int pam_amd_awfl_set_debug_conservation(pam_amd_awfl_t *h, int enable);
 int pam_amd_awfl_get_conservation(pam_amd_awfl_t *h, int *violations, double *max_rel_diff, int *worst_variable, int *worst_member);
 const char *pam_amd_awfl_conservation_report(const pam_amd_awfl_t *h);
+/* Test hook of the graph replay's error path: the NEXT capture reports a failure of hipStreamBeginCapture (1), hipStreamEndCapture (2) or
+ * hipGraphInstantiate (3); the step must then run eagerly, switch the replay off for the handle and leave a "warning: ..." text in
+ * pam_amd_awfl_last_error() while returning PAM_AMD_OK. */
+int pam_amd_awfl_debug_fail_next_capture(pam_amd_awfl_t *h, int which);
 /* Test hook of the check: in the NEXT timeStep, between the last stage and the final masses, one cell of `variable` of `member` is
  * multiplied by `factor` (rho: at constant rho*theta). */
 int pam_amd_awfl_debug_inject_mass_fault(pam_amd_awfl_t *h, int variable, int k, int j, int i, int member, double factor);

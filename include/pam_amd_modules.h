@@ -25,6 +25,10 @@ int pam_amd_sponge_layer(int nens, int nx, int ny, int nz, int num_fields, doubl
                          const double *zmid, double crm_dt, int num_layers, double time_scale, double *workspace,
                          void *stream);
 
+/* Frees what the module entry points keep per device and process (the 3.5 KB of pow tables the Kessler kernels read, built on the first
+ * call on a device: that call allocates and copies synchronously).  Optional; the entry points rebuild them on demand. */
+int pam_amd_modules_finalize(void);
+
 /* Microphysics::timeStep(coupler) of the Kessler scheme  (physics/micro/kessler/Microphysics.h:120-268, kessler():346-457;
  * called after the SGS module, standalone/mmf_simplified/driver.cpp:253).  Works in place on the coupler's DEVICE arrays:
  *   rho_v, rho_c, rho_r   tracers "water_vapor", "cloud_liquid", "precip_liquid" (nz,ny,nx,nens)     in/out

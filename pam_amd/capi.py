@@ -64,6 +64,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_fused_stage": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_range_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_yz_fold": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_debug_fail_next_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_debug_conservation": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_get_conservation": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pam_amd_awfl_conservation_report": (C.c_char_p, [C.c_void_p]),
@@ -90,6 +91,7 @@ SYMBOLS = {
 
 # include/pam_amd_modules.h
 MODULE_SYMBOLS = {
+    "pam_amd_modules_finalize": (C.c_int, []),
     "pam_amd_sponge_layer": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                                        C.c_double, C.c_void_p, C.c_void_p]),
     "pam_amd_kessler_time_step": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_double] * 5 + [C.c_void_p, C.c_void_p,

@@ -1032,6 +1032,7 @@ struct pam_amd_awfl {
   int graph_mode = 0;          // 0 automatic, 1 off, 2 on
   long graph_gen = 0;          // bumped by every setter that changes what a step launches: older graphs are dropped
   bool capturing = false;
+  int fail_next_capture = 0;   // test hook: 1 BeginCapture, 2 EndCapture, 3 Instantiate of the NEXT capture reports a failure
   int capture_seq0 = 0;
   int *seq_dev = nullptr;      // device word: fct_seq at the start of the replayed step
   hipStream_t gstream = nullptr;
@@ -2313,23 +2314,36 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       // kernel has run then, and the next step must start from the same buffers
       const int seq_keep = h->fct_seq;
       double *const p0_keep = h->prim0, *const p1_keep = h->prim1;
-      hipError_t cerr = hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
+      // (test hook: pam_amd_awfl_debug_fail_next_capture makes one of the three capture calls "fail")
+      const int inject = h->fail_next_capture;
+      h->fail_next_capture = 0;
+      hipError_t cerr = (inject == 1) ? hipErrorUnknown : hipStreamBeginCapture(h->gstream, hipStreamCaptureModeThreadLocal);
       if (cerr == hipSuccess) rc = enqueue();
       hipGraph_t graph = nullptr;
-      const hipError_t eerr = (cerr == hipSuccess) ? hipStreamEndCapture(h->gstream, &graph) : cerr;
+      hipError_t eerr = (cerr == hipSuccess) ? hipStreamEndCapture(h->gstream, &graph) : cerr;
+      if (inject == 2 && eerr == hipSuccess) eerr = hipErrorUnknown;
       h->capturing = false;
       c0.stream = s_keep; c0.fstream = f_keep;
-      if (rc == PAM_AMD_OK && eerr != hipSuccess) rc = fail(PAM_AMD_ENOGPU, std::string("time_step: graph capture: ") + hipGetErrorString(eerr));
-      if (rc == PAM_AMD_OK && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) != hipSuccess)
-        rc = fail(PAM_AMD_ENOGPU, "time_step: hipGraphInstantiate failed");
+      // what failed: the launches themselves (rc: a bad argument, a HIP error of a launch -- the same call would fail eagerly too) or
+      // the capture machinery (BeginCapture / EndCapture / Instantiate: the step itself is fine)
+      const int enqueue_rc = rc;
+      std::string why;
+      if (enqueue_rc == PAM_AMD_OK && eerr != hipSuccess) why = std::string("graph capture: ") + hipGetErrorString(eerr);
+      if (enqueue_rc == PAM_AMD_OK && why.empty() &&
+          (inject == 3 || hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) != hipSuccess)) why = "hipGraphInstantiate failed";
       if (graph) (void)hipGraphDestroy(graph);
-      if (rc) {
+      if (enqueue_rc != PAM_AMD_OK || !why.empty()) {
         h->fct_seq = seq_keep; h->prim0 = p0_keep; h->prim1 = p1_keep;
-        // the caller's stream was forked into gstream above: join it again, then run the step eagerly instead of failing it
+        // the caller's stream was forked into gstream above: join it again
         (void)hipEventRecord(h->g_join, h->gstream);
         (void)hipStreamWaitEvent(h->stream, h->g_join, 0);
-        h->graph_mode = 1;                              // (no further capture attempts on this handle)
-        return enqueue();
+        if (enqueue_rc != PAM_AMD_OK) return enqueue_rc;         // (its message is in last_error; nothing ran: the launches were only recorded)
+        // the capture machinery failed: drop the runtime's sticky error, run the step eagerly, say so, and stop capturing on this handle
+        (void)hipGetLastError();
+        h->graph_mode = 1;
+        const int erc = enqueue();
+        if (erc == PAM_AMD_OK) g_last_error = "warning: time_step: " + why + "; the step ran eagerly and graph replay is switched off for this handle";
+        return erc;
       }
       e.prim0_after = h->prim0; e.prim1_after = h->prim1;       // (the capture has walked the buffer rotation on the host side)
       h->graphs.push_back(e);
@@ -2483,11 +2497,17 @@ int pam_amd_awfl_set_x_tile(pam_amd_awfl_t *h, int row_lanes, int cells_per_tile
   if (row_lanes < 0 || cells_per_tile < 0 || lines_per_group < 0) return fail(PAM_AMD_EINVAL, "set_x_tile: arguments must be >= 0 (0 = automatic)");
   const XTileGeom g = xtile_geometry(h->P, row_lanes, cells_per_tile, lines_per_group, h->ncu);
   if (xtile_threads(g) > 1024 || xtile_threads(g) < 1) return fail(PAM_AMD_EINVAL, "set_x_tile: a tile must fit a workgroup of 1024 lanes");
-  if ((size_t)XT_NS * (xtile_threads(g) + xtile_stage_elems(g)) * sizeof(double) > 160 * 1024)
-    return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");
   USE_DEVICE(h);
+  // the LDS bound is that of the launch (launch_xupd): it applies when the x tile kernels run AND exchange through LDS -- the shuffle
+  // form stages nothing -- so the candidate geometry is resolved first and rolled back if the launch would refuse it
+  const int old_w = h->xt_w, old_tc = h->xt_tc, old_lpb = h->xt_lpb;
   h->xt_w = row_lanes; h->xt_tc = cells_per_tile; h->xt_lpb = lines_per_group;
   resolve_lane_mapping(h);       // (may switch the x kernels: the ranges are rebuilt like set_lane_mapping does)
+  if (h->xtile && !h->xshuf && (size_t)XT_NS * (xtile_threads(h->xg) + xtile_stage_elems(h->xg)) * sizeof(double) > 160 * 1024) {
+    h->xt_w = old_w; h->xt_tc = old_tc; h->xt_lpb = old_lpb;
+    resolve_lane_mapping(h);
+    return fail(PAM_AMD_EINVAL, "set_x_tile: the staged tile does not fit the 160 KB of LDS");
+  }
   return build_chunks(h);
 }
 
@@ -2554,6 +2574,13 @@ int pam_amd_awfl_set_graph_replay(pam_amd_awfl_t *h, int mode) {
     HIP_TRY(hipEventCreateWithFlags(&h->g_join, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&h->seq_dev, sizeof(int)));
   }
+  return PAM_AMD_OK;
+}
+
+int pam_amd_awfl_debug_fail_next_capture(pam_amd_awfl_t *h, int which) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (which < 0 || which > 3) return fail(PAM_AMD_EINVAL, "debug_fail_next_capture: 0 none, 1 BeginCapture, 2 EndCapture, 3 Instantiate");
+  h->fail_next_capture = which;
   return PAM_AMD_OK;
 }
 

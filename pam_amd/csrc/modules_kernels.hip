@@ -506,23 +506,32 @@ int kessler_check(int nens, int nx, int ny, int nz, const void *a, const void *b
   return PAM_AMD_OK;
 }
 
-// the tables of pow_pos_fast on the current device (built once per device and process; 4 KB)
-const PowTab *kessler_pow_tab() {
-  static std::mutex m;
-  static std::vector<PowTab *> tabs;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
-  std::lock_guard<std::mutex> lk(m);
-  if ((int)tabs.size() <= dev) tabs.resize(dev + 1, nullptr);
-  if (!tabs[dev]) {
+// the tables of pow_pos_fast on the device that holds the caller's arrays (`ref`: any of them; built once per device and process, 3.5 KB;
+// the FIRST call on a device allocates and copies synchronously -- pam_amd_modules_finalize() frees them).  The launches go to the
+// caller's stream, which must belong to that device, as for any kernel launch.
+std::mutex g_tab_mutex;
+std::vector<PowTab *> g_tabs;
+const PowTab *kessler_pow_tab(const void *ref) {
+  int dev = -1, cur = -1;
+  hipPointerAttribute_t attr;
+  if (ref && hipPointerGetAttributes(&attr, ref) == hipSuccess) dev = attr.device;
+  else (void)hipGetLastError();
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  if (dev < 0) dev = cur;
+  std::lock_guard<std::mutex> lk(g_tab_mutex);
+  if ((int)g_tabs.size() <= dev) g_tabs.resize(dev + 1, nullptr);
+  if (!g_tabs[dev]) {
     PowTab host;
     pama::build_pow_tab(host);
     PowTab *d = nullptr;
-    if (hipMalloc((void **)&d, sizeof(PowTab)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, &host, sizeof(PowTab), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    tabs[dev] = d;
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) return nullptr;
+    const bool ok = hipMalloc((void **)&d, sizeof(PowTab)) == hipSuccess && hipMemcpy(d, &host, sizeof(PowTab), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok && d) (void)hipFree(d);
+    if (dev != cur) (void)hipSetDevice(cur);
+    if (!ok) return nullptr;
+    g_tabs[dev] = d;
   }
-  return tabs[dev];
+  return g_tabs[dev];
 }
 
 int kessler_read_dt_max(const double *slot, hipStream_t s, double *out) {
@@ -535,11 +544,25 @@ int kessler_read_dt_max(const double *slot, hipStream_t s, double *out) {
 }
 }  // namespace
 
+extern "C" int pam_amd_modules_finalize(void) {
+  std::lock_guard<std::mutex> lk(g_tab_mutex);
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  for (size_t d = 0; d < g_tabs.size(); d++)
+    if (g_tabs[d]) {
+      if ((int)d != cur) (void)hipSetDevice((int)d);
+      (void)hipFree(g_tabs[d]);
+      g_tabs[d] = nullptr;
+    }
+  if (cur >= 0) (void)hipSetDevice(cur);
+  return PAM_AMD_OK;
+}
+
 extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, const double *rho_r, const double *rho_dry,
                                              const double *zmid, double dt, double *workspace, void *stream, double *dt_max) {
   if (!dt_max) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null dt_max");
   if (int rc = kessler_check(nens, nx, ny, nz, rho_r, rho_r, rho_r, rho_dry, rho_dry, zmid, workspace, dt, 1, 1, 1, 1)) return rc;
-  const PowTab *tab = kessler_pow_tab();
+  const PowTab *tab = kessler_pow_tab(workspace);
   if (!tab) return pam_amd_set_last_error_(PAM_AMD_ENOMEM, "kessler: cannot allocate the pow tables");
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;
@@ -557,7 +580,7 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
                                          int rainsplit_hint, int *rainsplit) {
   if (!precl) return pam_amd_set_last_error_(PAM_AMD_EINVAL, "kessler: null precl");
   if (int rc = kessler_check(nens, nx, ny, nz, rho_v, rho_c, rho_r, rho_dry, temp, zmid, workspace, dt, R_d, R_v, cp_d, p0)) return rc;
-  const PowTab *tab = kessler_pow_tab();
+  const PowTab *tab = kessler_pow_tab(workspace);
   if (!tab) return pam_amd_set_last_error_(PAM_AMD_ENOMEM, "kessler: cannot allocate the pow tables");
   hipStream_t s = (hipStream_t)stream;
   const long long ncol = (long long)ny * nx * nens;

@@ -257,6 +257,9 @@ class Dycore:
     def debug_inject_mass_fault(self, variable, k, j, i, member, factor):
         check(self._lib.pam_amd_awfl_debug_inject_mass_fault(self._h, int(variable), int(k), int(j), int(i), int(member), float(factor)))
 
+    def debug_fail_next_capture(self, which):
+        check(self._lib.pam_amd_awfl_debug_fail_next_capture(self._h, int(which)))
+
     FOLD = {"auto": 0, "off": 1, "on": 2}
 
     def set_yz_fold(self, mode="auto"):

@@ -15,8 +15,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMITTED = "r05_c2_bench_default.json"
-COMMITTED_DETAIL = "r05_c2_bench_detail.json"
+COMMITTED = "r06_c2_bench_default.json"
+COMMITTED_DETAIL = "r06_c2_bench_detail.json"
 LIMIT = 4096
 
 
@@ -93,10 +93,19 @@ def test_bench_py_the_drivers_command_prints_a_parseable_line():
     assert c is not None and c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == d["unit"] and c["value"] > 0 and c["sample"]
     assert c["one_core"]["value"] > 0 and c["processes_x_1_core"]["value"] >= c["one_core"]["value"]
     o = d["other"]
-    for k in ("c3", "c4", "c4_full", "c2_shard128", "c2_limiter1", "c2_limiter2", "ref_nens1", "c2grid_nens1"):
+    for k in ("c3", "c4", "c2_perens", "c4_perens", "c4_full", "c2_shard128", "c2_limiter1", "c2_limiter2", "ref_nens1", "c2grid_nens1"):
         assert o[k] > 0, k
+    assert o["c3_ms_per_step"] > 0 and o["c4_ms_per_step"] > 0
+    # per-member vertical grids (the coupler's general contract) within 15 % of the shared-table configurations
+    assert o["c2_perens"] >= 0.80 * d["value"] and o["c4_perens"] >= 0.80 * o["c4"], (o["c2_perens"], d["value"], o["c4_perens"], o["c4"])
     for k in ("kessler_time_step", "sponge_layer", "compute_gcm_forcing_tendencies", "apply_gcm_forcing_tendencies"):
         assert o["modules_ms"][k] > 0
+    for k in ("sponge_layer", "compute_gcm_forcing_tendencies", "apply_gcm_forcing_tendencies"):
+        assert 0 < o["modules_hbm_frac"][k] < 1
+    # the roofline that binds, as flat keys (null when no PMC profile of this build is committed)
+    r = d["roofline"]
+    for k in ("valu_frac_spec_clock", "valu_issue_frac", "sustained_clock_GHz", "stage_valu_frac"):
+        assert k in r and (r[k] is None or r[k] > 0), k
     # the detail object holds what the line summarises
     assert abs(full["value"] - d["value"]) <= 1e-9 * d["value"]
     assert abs(full["other_configs"]["c3"]["value"] - o["c3"]) <= 1e-3 * o["c3"]

@@ -372,3 +372,66 @@ def test_more_lines_than_the_tile_launch_grid_falls_back_to_sweeps():
         d.finalize(coupler)
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("which", [1, 2, 3], ids=["begin_capture", "end_capture", "instantiate"])
+def test_a_failed_graph_capture_runs_the_step_eagerly_and_says_so(which):
+    """when the capture machinery fails (hipStreamBeginCapture / hipStreamEndCapture / hipGraphInstantiate; injected through
+    pam_amd_awfl_debug_fail_next_capture) the step runs eagerly with the runtime's sticky error cleared, the replay is switched off for
+    the handle, pam_amd_awfl_last_error() carries a warning, and the results are those of eager launches bit for bit"""
+    import torch
+    from pam_amd import Dycore, PamCoupler, capi
+    nens, nx, ny, nz = 2, 8, 4, 10
+    tr = idz.TRACERS_KESSLER_SHOC
+    zint = idz.stretched_interfaces(nz, 12000.0)
+    xlen, ylen = nx * 500.0, ny * 500.0
+    f = idz.supercell_fields(nens, nx, ny, nz, zint, tracers=tr, magnitude=0.5)
+    idz.add_tracer_blobs(f, tr, xlen, ylen, zint)
+    res = []
+    for graph in ("off", "on"):
+        coupler = PamCoupler("cuda:0")
+        coupler.set_option("crm_dt", 2.0)
+        coupler.allocate_coupler_state(nz, ny, nx, nens)
+        coupler.set_grid(xlen, ylen, zint)
+        for n, p, m in tr:
+            coupler.add_tracer(n, "", p, m)
+        d = Dycore()
+        d.init(coupler)
+        d.set_graph_replay(graph)
+        coupler.load_fields(f)
+        d.declare_current_profile_as_hydrostatic(coupler)
+        if graph == "on":
+            d.debug_fail_next_capture(which)
+        ncyc = [d.timeStep(coupler)]
+        if graph == "on":
+            msg = capi.load().pam_amd_awfl_last_error().decode()
+            assert msg.startswith("warning: time_step:") and "eagerly" in msg, msg
+        ncyc += [d.timeStep(coupler) for _ in range(2)]      # the handle keeps working (eagerly) afterwards
+        torch.cuda.synchronize()
+        res.append((ncyc, coupler.dump_fields()))
+        d.finalize(coupler)
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert np.isfinite(res[0][1][k]).all()
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_set_x_tile_is_accepted_whatever_kernels_the_handle_runs():
+    """the setter applies the LDS bound of the launch (x tile kernels exchanging through LDS) to the RESOLVED mapping and
+    rolls back on refusal; with sweep kernels, or a geometry the launch accepts, it must simply take the geometry"""
+    from pam_amd import Dycore, PamCoupler
+    coupler = PamCoupler("cuda:0")
+    coupler.set_option("crm_dt", 2.0)
+    coupler.allocate_coupler_state(6, 3, 64, 16)              # 64-cell lines of 16 members
+    coupler.set_grid(32000.0, 1500.0, idz.uniform_interfaces(6, 6000.0))
+    coupler.add_tracer("water_vapor", "", True, True)
+    d = Dycore()
+    d.init(coupler)
+    d.set_lane_mapping("member", "sweep")
+    d.set_x_tile(16, 62, 0)                                    # sweep kernels: the tile geometry is not in use
+    assert not d.get_lane_mapping()["x_tiles"]
+    d.set_lane_mapping("flat", "tile")
+    d.set_x_tile(16, 62, 0)                                    # (62 + 2) rows x 16 lanes: 1024 lanes, 7 x 2 x 1024 doubles of LDS
+    m = d.get_lane_mapping()
+    assert m["x_tiles"] and m["tile"]["W"] == 16 and m["tile"]["tc"] == 62 and m["tile"]["halo"] == 1, m
+    d.finalize(coupler)

@@ -32,7 +32,8 @@ done
 tools/profile.sh ref_nens1 --config ref --steps 20 --warmup 2;    take ref_nens1 ref_nens1
 # the default schedule of the plain bench command (two independent member ranges): kernel trace only
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ks_default
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_default -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --detail $DST/unused.json > /dev/null 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_default -o t -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --detail $DST/unused.json > $DST/default_schedule.log 2>&1 || { echo "default-schedule pass failed:"; tail -20 $DST/default_schedule.log; exit 1; }
+rm -f $DST/default_schedule.log
 cp $(find /tmp/ks_default -name '*kernel_stats.csv') $DST/${round}_c2_kernel_stats_default_schedule.csv
 rm -f $DST/unused.json
 cd $R

@@ -104,7 +104,7 @@ def main():
                 res[base]["valu_insts_per_stage"] = inst / nstage
                 res[base]["busy_cycles_per_xcd_per_stage"] = busy / 8.0 / nstage
         i = sys.argv.index("--traffic-json")
-        print(json.dumps({"csrc_hash": sys.argv[i + 1], "kernels": res,
+        print(json.dumps({"csrc_hash": sys.argv[i + 1], "compute_units": int(os.environ.get("PMC_COMPUTE_UNITS", "0")) or None, "kernels": res,
                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py, config %s" % os.environ.get("PMC_SOURCE_CONFIG", "c2")}))
 
 

@@ -18,10 +18,13 @@ if [ "$1" = "--quick" ]; then quick=1; shift; fi
 OUT=$R/gpurun_out/prof_$tag
 rm -rf $OUT && mkdir -p $OUT
 HASH=$(python3 -c "import sys; sys.path.insert(0,'$R'); import bench; print(bench.csrc_hash())")
+# the launch shapes of the small-ensemble kernels follow the device's CU count: the profile is valid for this build ON this kind of part
+export PMC_COMPUTE_UNITS=$(python3 -c "import torch; print(torch.cuda.get_device_properties(0).multi_processor_count)")
 common="--no-cpu-baseline --no-other-configs"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks_$tag
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o t -- python3 $R/bench.py "$@" $common --detail $OUT/bench_detail_under_rocprof.json > $OUT/bench.log 2>/dev/null || { tail -20 $OUT/bench.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$tag -o t -- python3 $R/bench.py "$@" $common --detail $OUT/bench_detail_under_rocprof.json > $OUT/bench.log 2> $OUT/bench.err || { echo "kernel-trace pass failed:"; tail -20 $OUT/bench.err; tail -5 $OUT/bench.log; exit 1; }
+rm -f $OUT/bench.err
 grep '^{"metric"' $OUT/bench.log > $OUT/bench_under_rocprof.json
 cp $(find /tmp/ks_$tag -name '*kernel_stats.csv') $OUT/kernel_stats.csv
 rm -f $OUT/bench.log
