@@ -166,7 +166,10 @@ __global__ void __launch_bounds__(FLUX_THREADS, VZ_PER_ENS ? 2 : 4) awfl_flux_ke
 // Same weno5_table on the same values as ZTabLane: same bits.  Lanes / wavefronts beyond the ensemble range / the last column are
 // clamped to the last valid member / column and redo its work (identical values to identical addresses) -- every lane of the
 // workgroup reaches every barrier and helps staging.
-constexpr int ZPE_WAVES = 4;
+#ifndef PAMA_ZPE_WAVES
+#define PAMA_ZPE_WAVES 4
+#endif
+constexpr int ZPE_WAVES = PAMA_ZPE_WAVES;
 struct ZTabLds {
   double *buf;              // LDS: two tables of VZ_STRIDE x 64 doubles
   const double *vz;         // (nz + 2, VZ_STRIDE, nens)
