@@ -339,6 +339,8 @@ class Job:
         dycore.init(coupler)
         if getattr(args, "fold", "auto") != "auto":
             dycore.set_yz_fold(args.fold)
+        if getattr(args, "tailfusion", "auto") != "auto":
+            dycore.set_tail_fusion(args.tailfusion)
         if args.seg > 0:
             dycore.set_flux_segment(args.seg)
         if args.span >= 0:
@@ -1018,6 +1020,8 @@ def build_parser():
                     help="member ranges of the fused stage: 1 every range runs its whole stage on its own stream, 0 the polynomial kernels of "
                          "all ranges share one compute stream (round 2's schedule); -1 (default): the library's default (1)")
     ap.add_argument("--perens", type=int, default=0, choices=(0, 1), help="1: every member on its own vertical grid (per-member WENO tables)")
+    ap.add_argument("--tailfusion", default="auto", choices=("auto", "on", "off"),
+                    help="NT > 1, member lanes: tracer phase 2 + pressure pass + vapour fix-up as one launch (on) or three (off)")
     ap.add_argument("--fold", default="auto", choices=("auto", "on", "off"),
                     help="3-D member-lane stage: the z sweep stores the y+z part of the state's divergence (on) or its own differences (off)")
     ap.add_argument("--detail", default="bench_detail.json", help="file (beside bench.py) that receives the full measurement object")

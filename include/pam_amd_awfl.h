@@ -175,6 +175,11 @@ int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds
  * phases with another range's kernels; 0: the polynomial kernels of all ranges back to back on one stream (round 2's schedule).
  * Same results.  The automatic range count (set_ensemble_chunks(0)) of the fused stage is 2 from 128 members on. */
 int pam_amd_awfl_set_range_schedule(pam_amd_awfl_t *h, int independent);
+/* Member-lane sweeps with further tracers (NT > 1): the last three launches of a stage -- phase 2 of the further tracers' x sweeps, the
+ * pressure pass, water vapour's fix-up; they read what earlier launches wrote and write disjoint things -- as ONE launch (mode 2;
+ * automatic: while the phase-2 launch is less than about two rounds of wavefronts, e.g. one GPU's shard of C4) or three (mode 1).
+ * Same bits (ABI 5). */
+int pam_amd_awfl_set_tail_fusion(pam_amd_awfl_t *h, int mode);
 /* Fused stage, 3-D grids swept with member lanes: the momentum components and rho*theta take their divergence as x + (y + z)
  * (Dycore.h:553-571 sums the three directions; the density and the tracers keep (x + y) + z).  mode 2: the z sweep runs in a launch
  * of its own behind the y sweep, reads the y sweep's flux differences and stores the y+z part, ONE field per variable, which is all

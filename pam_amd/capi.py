@@ -64,6 +64,7 @@ SYMBOLS = {
     "pam_amd_awfl_set_fused_stage": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_range_schedule": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_yz_fold": (C.c_int, [C.c_void_p, C.c_int]),
+    "pam_amd_awfl_set_tail_fusion": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_debug_fail_next_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_set_debug_conservation": (C.c_int, [C.c_void_p, C.c_int]),
     "pam_amd_awfl_get_conservation": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

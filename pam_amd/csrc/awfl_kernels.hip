@@ -281,14 +281,13 @@ __global__ void __launch_bounds__(FLUX_THREADS, 2) awfl_xupd_kernel(Params P, En
 // multipliers; only for small ensembles -- otherwise it runs inline in awfl_xupd_kernel) and PHASE 2 (the cells' complete update)
 // both follow awfl_xupd_kernel (they need the face mass flux; phase 2 also the new density and every line's multipliers).
 template <int STAGE, int PHASE, bool AHEAD = false>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                               const double *__restrict__ prim0, double *__restrict__ prim_out,
-                                                               const double *__restrict__ fx, const double *__restrict__ fy,
-                                                               const double *__restrict__ fz, double *__restrict__ seed,
-                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
-                                                               double dt_stage, int npairs, int span, int nspan) {
-  fct_rows_resolve(rows);
-  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
+__device__ __forceinline__ void xtr_pairs_block(const Params &P, EnsRange R, const double *__restrict__ prim_in,
+                                                const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                const double *__restrict__ fx, const double *__restrict__ fy,
+                                                const double *__restrict__ fz, double *__restrict__ seed,
+                                                double *__restrict__ mult, const FctRows &rows, double dt_dyn,
+                                                double dt_stage, int npairs, int span, int nspan, int block) {
+  const int u = __builtin_amdgcn_readfirstlane((int)(block * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int g2 = uni_int(u / npairs), pair = u - g2 * npairs;
   const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
@@ -302,21 +301,31 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRan
       x_tracer_sweep<1, STAGE, PHASE, AHEAD>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
+template <int STAGE, int PHASE, bool AHEAD = false>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                               const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                               const double *__restrict__ fx, const double *__restrict__ fy,
+                                                               const double *__restrict__ fz, double *__restrict__ seed,
+                                                               double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                               double dt_stage, int npairs, int span, int nspan) {
+  fct_rows_resolve(rows);
+  xtr_pairs_block<STAGE, PHASE, AHEAD>(P, R, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, npairs, span, nspan,
+                                       (int)blockIdx.x);
+}
 // The same sweeps with G = 4 or G = 1 further tracers per wavefront (pam_amd_awfl_set_tracer_grouping; experiment (a) of VERDICT r3 / r4
 // and its opposite).  Four: half the wavefronts, the per-wavefront loads a pair shares (face mass flux, the three densities) shared by
 // four tracers -- and twice the windows in registers.  One: twice the wavefronts, each with half the registers (more wavefronts per
 // SIMD), the shared loads repeated per tracer.  Kernels of their own so that the pair form keeps its register count.  Same arithmetic
 // per tracer: same bits.
 template <int STAGE, int PHASE, int G>
-__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtrn_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                                const double *__restrict__ prim0, double *__restrict__ prim_out,
-                                                                const double *__restrict__ fx, const double *__restrict__ fy,
-                                                                const double *__restrict__ fz, double *__restrict__ seed,
-                                                                double *__restrict__ mult, FctRows rows, double dt_dyn,
-                                                                double dt_stage, int ngroups, int span, int nspan) {
+__device__ __forceinline__ void xtr_groups_block(const Params &P, EnsRange R, const double *__restrict__ prim_in,
+                                                 const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                 const double *__restrict__ fx, const double *__restrict__ fy,
+                                                 const double *__restrict__ fz, double *__restrict__ seed,
+                                                 double *__restrict__ mult, const FctRows &rows, double dt_dyn,
+                                                 double dt_stage, int ngroups, int span, int nspan, int block) {
   static_assert(G == 1 || G == 4, "groups of one or four tracers");
-  fct_rows_resolve(rows);
-  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * FLUX_WAVES + (threadIdx.x >> 6)));
+  const int u = __builtin_amdgcn_readfirstlane((int)(block * FLUX_WAVES + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int g2 = uni_int(u / ngroups), grpn = u - g2 * ngroups;
   const int grp = uni_int(g2 / nspan), sp = g2 - grp * nspan;
@@ -334,25 +343,52 @@ __global__ void __launch_bounds__(FLUX_THREADS) awfl_xtrn_kernel(Params P, EnsRa
       x_tracer_sweep<1, STAGE, PHASE>(P, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, line, R.e0 + el, sp * span, span, fa, dt_dyn, dt_stage, false, 0.0);
   }
 }
+template <int STAGE, int PHASE, int G>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtrn_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                                const double *__restrict__ prim0, double *__restrict__ prim_out,
+                                                                const double *__restrict__ fx, const double *__restrict__ fy,
+                                                                const double *__restrict__ fz, double *__restrict__ seed,
+                                                                double *__restrict__ mult, FctRows rows, double dt_dyn,
+                                                                double dt_stage, int ngroups, int span, int nspan) {
+  fct_rows_resolve(rows);
+  xtr_groups_block<STAGE, PHASE, G>(P, R, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, ngroups, span, nspan,
+                                    (int)blockIdx.x);
+}
 // Pointwise tail of the fused stage, (1): next stage's pressure + density/pressure ghosts: a pow per cell and nothing else, so few
 // registers and full occupancy; TAIL_LEVELS levels per thread (a sixth of the wavefronts, the (i, member) split once).
 constexpr int TAIL_LEVELS = 6;
-__global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *__restrict__ prim_out) {
-  // the tables of pow_pos_fast (3.5 KB) staged in LDS: five per-lane lookups per pow, which are what this kernel waits for when
-  // they go to global memory (0.39 -> 0.26 ms on C2)
-  __shared__ PowTab sh_tab;
-  {
-    const double *src = reinterpret_cast<const double *>(P.pw);
-    double *dst = reinterpret_cast<double *>(&sh_tab);
-    for (int i = threadIdx.x; i < (int)(sizeof(PowTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
-  }
+// the tables of pow_pos_fast (3.5 KB) staged in LDS: five per-lane lookups per pow, which are what the pressure pass waits for when
+// they go to global memory (0.39 -> 0.26 ms on C2)
+__device__ __forceinline__ void stage_pow_tab(Params &P, PowTab *sh_tab) {
+  const double *src = reinterpret_cast<const double *>(P.pw);
+  double *dst = reinterpret_cast<double *>(sh_tab);
+  for (int i = threadIdx.x; i < (int)(sizeof(PowTab) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
   __syncthreads();
-  P.pw = &sh_tab;
+  P.pw = sh_tab;
+}
+// member-lane grid (ceil(nx*ne/256), ny, level groups): the block (bx, by, bz) of that grid
+__device__ __forceinline__ void ptail_block(const Params &P, EnsRange R, double *__restrict__ prim_out, unsigned bx, int by, int bz) {
+  const unsigned t = bx * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)P.nx * (unsigned)R.ne) return;
+  CellId c;
+  const unsigned i = t / (unsigned)R.ne;
+  c.j = by; c.i = (int)i; c.e = R.e0 + (int)(t - i * (unsigned)R.ne);
+#pragma unroll
+  for (int kk = 0; kk < TAIL_LEVELS; kk++) {
+    c.k = bz * TAIL_LEVELS + kk;
+    if (c.k >= P.nz) return;
+    c.idx = (((long long)c.k * P.ny + c.j) * P.nx + c.i) * P.nens + c.e;
+    pressure_tail_body(P, prim_out, c);
+  }
+}
+__global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, double *__restrict__ prim_out) {
+  __shared__ PowTab sh_tab;
+  stage_pow_tab(P, &sh_tab);
+  if (!P.flat_cells) { ptail_block(P, R, prim_out, blockIdx.x, (int)blockIdx.y, (int)blockIdx.z); return; }
   CellId c;
   const int ngrp = (P.nz + TAIL_LEVELS - 1) / TAIL_LEVELS;       // groups of levels
-  if (P.flat_cells) { if (!flat_cell(P, ngrp, c)) return; }
-  else if (!grid_cell(P, R, c)) return;
-  const int kg = P.flat_cells ? c.k : (int)blockIdx.z;
+  if (!flat_cell(P, ngrp, c)) return;
+  const int kg = c.k;
 #pragma unroll
   for (int kk = 0; kk < TAIL_LEVELS; kk++) {
     c.k = kg * TAIL_LEVELS + kk;
@@ -365,19 +401,59 @@ __global__ void __launch_bounds__(256) awfl_ptail_kernel(Params P, EnsRange R, d
 // wavefront leaves after ONE scalar load unless some row (of any tracer) was flagged in this stage, and after its five line flags
 // unless a row of its own or of a neighbouring line was.
 template <int STAGE>
-__global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
-                                                         const double *__restrict__ prim0, double *prim_out,
-                                                         const double *__restrict__ fx, const double *__restrict__ fy,
-                                                         const double *__restrict__ fz, const double *__restrict__ mult,
-                                                         FctRows rows, double *__restrict__ seed, double dt_dyn) {
-  fct_rows_resolve(rows);
-  const int u = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+__device__ __forceinline__ void trfix_block(const Params &P, EnsRange R, const double *__restrict__ prim_in,
+                                            const double *__restrict__ prim0, double *prim_out,
+                                            const double *__restrict__ fx, const double *__restrict__ fy,
+                                            const double *__restrict__ fz, const double *__restrict__ mult,
+                                            const FctRows &rows, double *__restrict__ seed, double dt_dyn, int block) {
+  const int u = __builtin_amdgcn_readfirstlane((int)(block * 4 + (threadIdx.x >> 6)));
   const int nblk = (R.ne + 63) >> 6;
   const int line = uni_int(u / nblk), el = (u - line * nblk) * 64 + (int)(threadIdx.x & 63);
   if (line >= P.nz * P.ny || el >= R.ne) return;
   if (rows.any[(R.e0 + el) >> 6] != rows.seq) return;     // no row of this member block was flagged in this stage
   const int k = uni_int(line / P.ny), j = line - k * P.ny;
   tracer_fixup_line_body<STAGE>(P, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, P.idWV, k, j, R.e0 + el);
+}
+template <int STAGE>
+__global__ void __launch_bounds__(256) awfl_trfix_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                         const double *__restrict__ prim0, double *prim_out,
+                                                         const double *__restrict__ fx, const double *__restrict__ fy,
+                                                         const double *__restrict__ fz, const double *__restrict__ mult,
+                                                         FctRows rows, double *__restrict__ seed, double dt_dyn) {
+  fct_rows_resolve(rows);
+  trfix_block<STAGE>(P, R, prim_in, prim0, prim_out, fx, fy, fz, mult, rows, seed, dt_dyn, (int)blockIdx.x);
+}
+// NT > 1, member-lane sweeps: the LAST three launches of a stage in one -- phase 2 of the further tracers' x sweeps (SINGLES: one tracer
+// per wavefront, else pairs), the pressure pass and water vapour's fix-up.  They read what the x-sweep and phase 1 wrote and write
+// disjoint things (the further tracers + their seeds; the pressure + density / pressure ghosts; water vapour where its limiter acted), so
+// nothing orders them among themselves: the long phase-2 workgroups are dispatched first, the short pointwise ones fill its tail.  Same
+// bodies, same bits; two launch boundaries and the idle ends of two short launches less per stage (C4 shard: ptail 15 + fix-up 6 us of a
+// 420 us stage).
+//   grid: [0, nb_xtr) phase 2 | [nb_xtr, nb_xtr + nb_pt) pressure pass, nb_pt = ptx * ny * level groups | rest: fix-up
+template <int STAGE, bool SINGLES>
+__global__ void __launch_bounds__(FLUX_THREADS) awfl_xtr2_tail_kernel(Params P, EnsRange R, const double *__restrict__ prim_in,
+                                                                     const double *__restrict__ prim0, double *prim_out,
+                                                                     const double *__restrict__ fx, const double *__restrict__ fy,
+                                                                     const double *__restrict__ fz, double *__restrict__ seed,
+                                                                     double *__restrict__ mult, FctRows rows, FctRows rows_fix, double dt_dyn,
+                                                                     double dt_stage, int ngroups, int span, int nspan, int nb_xtr, int nb_pt,
+                                                                     int ptx) {
+  static_assert(FLUX_THREADS == 256, "the three bodies share workgroups of 256 lanes");
+  __shared__ PowTab sh_tab;
+  const int b = (int)blockIdx.x;
+  if (b < nb_xtr) {
+    fct_rows_resolve(rows);
+    if (SINGLES) xtr_groups_block<STAGE, 2, 1>(P, R, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, ngroups, span, nspan, b);
+    else xtr_pairs_block<STAGE, 2>(P, R, prim_in, prim0, prim_out, fx, fy, fz, seed, mult, rows, dt_dyn, dt_stage, ngroups, span, nspan, b);
+  } else if (b < nb_xtr + nb_pt) {
+    stage_pow_tab(P, &sh_tab);
+    const int q = b - nb_xtr, per_level = ptx * P.ny;
+    const int bz = q / per_level, r = q - bz * per_level, by = r / ptx;
+    ptail_block(P, R, prim_out, (unsigned)(r - by * ptx), by, bz);
+  } else {
+    fct_rows_resolve(rows_fix);
+    trfix_block<STAGE>(P, R, prim_in, prim0, prim_out, fx, fy, fz, mult, rows_fix, seed, dt_dyn, b - nb_xtr - nb_pt);
+  }
 }
 // the same fix-up with one lane per cell (small ensembles; tracer_fixup_cell_body)
 template <int STAGE>
@@ -1055,6 +1131,7 @@ struct pam_amd_awfl {
   double mass_max_rel = 0.0;
   std::string mass_report;
   struct { bool armed = false; int ivar, k, j, i, e; double factor; } fault;   // one-shot test hook
+  int tail_fuse_mode = 0;      // NT > 1: phase 2 + pressure pass + vapour fix-up as one launch: 0 automatic (on), 1 off, 2 on
   int fold_mode = 0;           // y differences of the state folded into the z sweep's output (P.yz_fold): 0 automatic, 1 off, 2 on
   double *rdz = nullptr;       // (nz, nens) fast_rcp(dz)
   bool independent_ranges = true;    // fused stage, several member ranges: each range's whole stage on its own stream
@@ -1350,10 +1427,21 @@ int launch_update(pam_amd_awfl *h, const double *prim_in, const double *prim0, d
   return PAM_AMD_OK;
 }
 
+// Can the last three launches of a stage -- phase 2 of the further tracers, the pressure pass, water vapour's fix-up -- go out as ONE
+// (awfl_xtr2_tail_kernel)?  Member-lane sweeps with further tracers, pairs or singles in phase 2 (the measured defaults), and the stage's
+// x-sweeps and tail on the same stream.
+bool tail_fusable(const pam_amd_awfl *h) {
+  const Params &P = h->P;
+  if (h->tail_fuse_mode == 1 || h->xtile || P.flat_cells || P.nt < 2) return false;
+  if (h->tracers_per_wave == 4 || h->tracer_prefetch) return false;
+  return true;
+}
+
 template <int STAGE>
 int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, double *prim_out, double dt_dyn, double dt_stage,
-                EnsRange r, hipStream_t s) {
+                EnsRange r, hipStream_t s, bool allow_tail_fusion = false, bool *tail_fused = nullptr) {
   const Params &P = h->P;
+  if (tail_fused) *tail_fused = false;
   if (h->xtile) {
     // tile kernels: a lane per cell, the whole ensemble in one launch (small ensembles; launches the sweeps cannot fill the chip with)
     if (r.e0 != 0 || r.ne != P.nens) return fail(PAM_AMD_EINVAL, "x-tile launch: the tile kernels take the whole ensemble in one range");
@@ -1487,7 +1575,35 @@ int launch_xupd(pam_amd_awfl *h, const double *prim_in, const double *prim0, dou
                          npairs, tspan, tnspan);
     HIP_TRY(hipGetLastError());
   }
-  if (npairs > 0) {   // phase 2: their complete update, one wavefront per (line, member block, span, pair)
+  // Phase 2 + the pressure pass + water vapour's fix-up in one launch while the phase-2 launch of this range is less than about two
+  // rounds of wavefronts (256 CUs x 4 SIMDs x 3 wavefronts of this kernel): there the two short pointwise launches and their boundaries
+  // are ~5 % of the stage and hide inside phase 2's tail; on launches that fill the chip several times over the pressure pass runs
+  // faster on its own (8 wavefronts per SIMD instead of 3).  Measured on MI355X (round 6, profiles/r06_ab_experiments.txt): C4 shard
+  // 0.891 -> 0.905 G; C4 whole 1.0925 -> 1.075 G and C3, the 3-D four-tracer grid +-0 when forced on.
+  bool fuse_tail = false;
+  if (npairs > 0 && allow_tail_fusion) {
+    shape(per2);
+    fuse_tail = h->tail_fuse_mode == 2 || tunits < 6144;
+  }
+  if (tail_fused) *tail_fused = fuse_tail;
+  if (npairs > 0 && fuse_tail) {
+    const long long nb_xtr = nblocks(tunits, FLUX_WAVES);
+    const dim3 pg = cell_grid(P, r, (P.nz + TAIL_LEVELS - 1) / TAIL_LEVELS);
+    const long long nb_pt = (long long)pg.x * pg.y * pg.z;
+    const long long nb_fix = nblocks((long long)P.nz * P.ny * ((r.ne + 63) / 64), 4);
+    if (nb_xtr + nb_pt + nb_fix > 0x7fffffffll) return fail(PAM_AMD_EINVAL, "tail launch: more than 2^31 workgroups");
+    ScopedTimer st(h, "xtr2", s);
+    const dim3 grid((unsigned)(nb_xtr + nb_pt + nb_fix));
+    if (singles)
+      hipLaunchKernelGGL((awfl_xtr2_tail_kernel<STAGE, true>), grid, dim3(FLUX_THREADS), 0, s, P, r, prim_in, prim0, prim_out, h->flux_x,
+                         h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), fct_rows(h, r, false), dt_dyn, dt_stage, ngroups, tspan,
+                         tnspan, (int)nb_xtr, (int)nb_pt, (int)pg.x);
+    else
+      hipLaunchKernelGGL((awfl_xtr2_tail_kernel<STAGE, false>), grid, dim3(FLUX_THREADS), 0, s, P, r, prim_in, prim0, prim_out, h->flux_x,
+                         h->flux_y, h->flux_z, h->seed, h->mult, fct_rows(h, r, true), fct_rows(h, r, false), dt_dyn, dt_stage, npairs, tspan,
+                         tnspan, (int)nb_xtr, (int)nb_pt, (int)pg.x);
+    HIP_TRY(hipGetLastError());
+  } else if (npairs > 0) {   // phase 2: their complete update, one wavefront per (line, member block, span, pair)
     shape(per2);
     ScopedTimer st(h, "xtr2", s);
     if (quads)
@@ -2201,18 +2317,22 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
         hipStream_t cs = indep ? c.stream : (forked ? h->chunks[0].fstream : c.stream);
         if (forked && !indep) HIP_TRY(hipStreamWaitEvent(cs, c.upd_done, 0));         // this chunk's previous tail / init
         if ((r2 = launch_flux(h, pin, c.r, cs, 6, true))) return r2;
-        if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
-        else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
-        else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs);
+        const bool allow = (cs == c.stream) && tail_fusable(h);      // (the tail as part of the phase-2 launch)
+        bool fuse_tail = false;
+        if (st == 1) r2 = launch_xupd<1>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs, allow, &fuse_tail);
+        else if (st == 2) r2 = launch_xupd<2>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs, allow, &fuse_tail);
+        else r2 = launch_xupd<3>(h, pin, p0, pout, dt_dyn, dt_stage, c.r, cs, allow, &fuse_tail);
         if (r2) return r2;
         if (forked && !indep) {
           HIP_TRY(hipEventRecord(c.flux_done, cs));
           HIP_TRY(hipStreamWaitEvent(c.stream, c.flux_done, 0));
         }
-        if (st == 1) r2 = launch_tail<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-        else if (st == 2) r2 = launch_tail<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-        else r2 = launch_tail<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
-        if (r2) return r2;
+        if (!fuse_tail) {
+          if (st == 1) r2 = launch_tail<1>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+          else if (st == 2) r2 = launch_tail<2>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+          else r2 = launch_tail<3>(h, pin, p0, pout, dt_dyn, c.r, c.stream);
+          if (r2) return r2;
+        }
         if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
         return PAM_AMD_OK;
       }
@@ -2656,6 +2776,14 @@ int pam_amd_awfl_debug_inject_mass_fault(pam_amd_awfl_t *h, int variable, int k,
   return PAM_AMD_OK;
 }
 
+int pam_amd_awfl_set_tail_fusion(pam_amd_awfl_t *h, int mode) {
+  if (!h) return fail(PAM_AMD_EINVAL, "null handle");
+  if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_tail_fusion: 0 = automatic, 1 = three launches, 2 = one launch");
+  drop_graphs(h);
+  h->tail_fuse_mode = mode;
+  return PAM_AMD_OK;
+}
+
 int pam_amd_awfl_set_yz_fold(pam_amd_awfl_t *h, int mode) {
   if (!h) return fail(PAM_AMD_EINVAL, "null handle");
   if (mode < 0 || mode > 2) return fail(PAM_AMD_EINVAL, "set_yz_fold: 0 = automatic, 1 = off (the x-sweep loads the y and the z differences), 2 = on");
@@ -2754,9 +2882,10 @@ int pam_amd_awfl_debug_stage(pam_amd_awfl_t *h, double dt_dyn) {
   int rc;
   if ((rc = next_fct_stage(h))) return rc;
   if ((rc = launch_flux(h, h->prim0, r, h->stream, h->fused ? 6 : 7, h->fused))) return rc;
-  if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, dt_dyn, r, h->stream))) return rc;
+  bool fuse_tail = false;
+  if (h->fused && (rc = launch_xupd<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, dt_dyn, r, h->stream, tail_fusable(h), &fuse_tail))) return rc;
   if (!h->fused && (rc = launch_fct(h, dt_dyn, r, h->stream))) return rc;
-  if (h->fused) rc = launch_tail<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
+  if (h->fused) rc = fuse_tail ? PAM_AMD_OK : launch_tail<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   else rc = launch_update<1>(h, h->prim0, h->prim0, h->prim1, dt_dyn, r, h->stream);
   if (rc) return rc;
   std::swap(h->prim0, h->prim1);

@@ -260,6 +260,10 @@ class Dycore:
     def debug_fail_next_capture(self, which):
         check(self._lib.pam_amd_awfl_debug_fail_next_capture(self._h, int(which)))
 
+    def set_tail_fusion(self, mode="auto"):
+        """NT > 1, member-lane sweeps: tracer phase 2 + pressure pass + vapour fix-up as one launch ("on" / "auto") or three ("off"); same bits"""
+        check(self._lib.pam_amd_awfl_set_tail_fusion(self._h, {"auto": 0, "off": 1, "on": 2}[mode]))
+
     FOLD = {"auto": 0, "off": 1, "on": 2}
 
     def set_yz_fold(self, mode="auto"):

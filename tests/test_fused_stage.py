@@ -38,7 +38,7 @@ CASES = {
 }
 
 
-def _run(case, fused, chunks=0, want_mult=False, fold=None, lanes=None):
+def _run(case, fused, chunks=0, want_mult=False, fold=None, lanes=None, tail=None):
     import torch
     from pam_amd import Dycore, PamCoupler
     nens, nx, ny, nz, tr, zint, per_ens, mode_a, consts = CASES[case]
@@ -79,6 +79,8 @@ def _run(case, fused, chunks=0, want_mult=False, fold=None, lanes=None):
         dycore.set_lane_mapping(*lanes)
     if fold is not None:
         dycore.set_yz_fold(fold)
+    if tail is not None:
+        dycore.set_tail_fusion(tail)
     coupler.load_fields(f)
     if not mode_a:
         coupler.set_option("balance_hydrostasis_with_gravity", False)
@@ -125,6 +127,20 @@ def test_yz_fold_is_a_schedule_not_an_arithmetic(case):
     default) == the z sweep storing its own differences and the x-sweep loading both (pam_amd_awfl_set_yz_fold), bit for bit"""
     n0, a = _run(case, fused=True, fold="off")
     n1, b = _run(case, fused=True, fold="on")
+    assert n0 == n1
+    for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k] - b[k]).max())
+
+
+@pytest.mark.parametrize("case", ["3d_nt4_whole_flag_rows", "2d_nt10_whole_flag_rows", "3d_nt4_many_lines_inline_tracers",
+                                  "2d_nt10_perens_member_lanes", "3d_nt4_perens_member_lanes"])
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_tail_fusion_is_a_schedule_not_an_arithmetic(case, chunks):
+    """NT > 1, member-lane sweeps: phase 2 of the further tracers + the pressure pass + water vapour's fix-up as ONE launch
+    (awfl_xtr2_tail_kernel: three further tracers go one per wavefront, nine in pairs) == three launches, one and two member ranges"""
+    n0, a = _run(case, fused=True, tail="off", chunks=chunks)
+    n1, b = _run(case, fused=True, tail="on", chunks=chunks)
     assert n0 == n1
     for k in ("density_dry", "uvel", "vvel", "wvel", "temp", "tracers"):
         assert np.isfinite(a[k]).all(), k

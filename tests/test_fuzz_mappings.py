@@ -78,6 +78,8 @@ def draw_knobs(rng, s):
         k["launch_tuning"] = (pick(0, 64, 100000), pick(-1, 0, 10 ** 9), pick(-1, 0, 10 ** 9))
     if rng.random() < 0.15:
         k["fused_stage"] = (False,)
+    if rng.random() < 0.4:        # (round 6) tracer phase 2 + pressure pass + fix-up as one launch or three
+        k["tail_fusion"] = (pick("on", "off"),)
     if rng.random() < 0.4:        # (round 6) the y differences of the state folded into the z sweep's output: 3-D member-lane stages only
         k["yz_fold"] = (pick("on", "on", "off"),)
     return k
@@ -98,7 +100,7 @@ def describe(s):
 
 # (order matters where one knob's validity depends on another: the lane mapping first)
 ORDER = ["fused_stage", "lane_mapping", "x_tile", "x_exchange", "flux_tile", "flux_tile_parts", "tile_state_parts", "tile_fusion",
-         "graph_replay", "ensemble_chunks", "range_schedule", "flux_segment", "flux_span", "tracer_grouping", "launch_tuning", "yz_fold"]
+         "graph_replay", "ensemble_chunks", "range_schedule", "flux_segment", "flux_span", "tracer_grouping", "launch_tuning", "tail_fusion", "yz_fold"]
 
 
 def run(s, f, xlen, ylen, knobs):
