@@ -28,20 +28,29 @@ struct FieldPtrs { double *p[MAX_FIELDS]; };
 // on this runtime made the C++ driver's CRM loop irreproducible from run to run (tools/ci_variants.sh: the sponge layer relaxing
 // towards garbage means whenever the host synchronised between modules).
 constexpr int MOD_NS = 16;     // sponge_layer
-constexpr int GCM_NS = 8;      // gcm_forcing: ten fields per cell and three divisions -- workgroups of 512 lanes (a budget of 256 registers)
+// gcm_forcing: ten fields per cell and three divisions.  Slots per member chosen by measurement at 1024 x 32x32x60 (round 6): the
+// column averages (reads only) 8 slots, no unrolling: 0.89 ms (16 slots: 1.19; 4: 1.06); the apply pass (every field read and written)
+// 16 slots, no unrolling: 2.15 ms (8 slots: 2.30-2.42; 4: 2.26)
+constexpr int GCM_NS = 8;
+constexpr int GCM_NS_APPLY = 16;
 // v[0..NQ) of every thread -> the member's totals (all NS threads of a member get them); red: NQ * NS * blockDim.x doubles of LDS
 template <int NQ, int NS = MOD_NS>
 __device__ __forceinline__ void slot_reduce(double (&v)[NQ], double *red) {
   constexpr int MOD_NS = NS;
-  const int ME = blockDim.x, m = threadIdx.x, slot = threadIdx.y;
+  // rows of 64 members whatever the workgroup's width: every LDS address is the lane's own + a compile-time offset (with the runtime
+  // width as the stride the compiler formed all NQ x NS addresses in registers first: 178 registers in the averages kernel, 684 B of
+  // scratch per lane in the 1024-lane apply kernel)
+  const int m = threadIdx.x, slot = threadIdx.y;
 #pragma unroll
-  for (int q = 0; q < NQ; q++) red[(q * MOD_NS + slot) * ME + m] = v[q];
+  for (int q = 0; q < NQ; q++) red[(q * MOD_NS + slot) * 64 + m] = v[q];
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
     double a = 0.0;
-#pragma unroll
-    for (int sl = 0; sl < MOD_NS; sl++) a += red[(q * MOD_NS + sl) * ME + m];
+    // (a rolled loop, four reads in flight: unrolled, the compiler requests all NQ x NS values at once -- 2 x NQ x NS registers -- and
+    // spills them; the sum runs once per thread)
+#pragma unroll 4
+    for (int sl = 0; sl < MOD_NS; sl++) a += red[(q * MOD_NS + sl) * 64 + m];
     v[q] = a;
   }
   __syncthreads();
@@ -258,6 +267,9 @@ __device__ __forceinline__ void gcm_forcing_compute_finish(const Gcm10 &gcm, con
 }
 
 // compute_gcm_forcing_tendencies (gcm_forcing.h:17-210): column averages; grid (member blocks, levels), block (members, GCM_NS slots)
+// IDX: unsigned when a field is below 2^29 doubles (byte offsets fit 32 bits: one register of address for all ten fields on top of
+// their scalar bases), long long otherwise
+template <class IDX>
 __global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_compute_kernel(int nens, int ncol, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
                                                                    double r_dt_gcm) {
   __shared__ double red[5 * GCM_NS * 64];
@@ -270,10 +282,10 @@ __global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_compute_kernel(int ne
   double ca[10];
 #pragma unroll
   for (int f = 0; f < 10; f++) ca[f] = 0;
-  const long long base = (long long)k * ncol * nens + e;
-#pragma unroll 2
+  const IDX base = (IDX)k * (IDX)ncol * (IDX)nens + (IDX)e;
+#pragma clang loop unroll(disable)
   for (int c = slot; c < ncol; c += GCM_NS) {
-    const long long o = base + (long long)c * nens;
+    const IDX o = base + (IDX)c * (IDX)nens;
     const double rd = crm.p[GF_RHOD][o], rv = crm.p[GF_RV][o];
     ca[GF_RHOD] += rd * r_nx_ny;
     ca[GF_U] += crm.p[GF_U][o] * r_nx_ny;
@@ -310,12 +322,13 @@ __device__ __forceinline__ void gcm_forcing_apply_finish(const Gcm10 &gcm, const
     if (neg[s] > pos[s]) atomicOr(&flags[3 + s], 1);
   }
 }
-// grid (member blocks, levels), block (members, GCM_NS slots): every cell is read and written once, the nine sums of a
+// grid (member blocks, levels), block (members, GCM_NS_APPLY slots): every cell is read and written once, the nine sums of a
 // (level, member) pair -- colavg[3], neg[3], pos[3] -- go through slot_reduce
-__global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_apply_kernel(int nens, int ncol, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
+template <class IDX>
+__global__ void __launch_bounds__(64 * GCM_NS_APPLY) gcm_forcing_apply_kernel(int nens, int ncol, int nz, Gcm10 crm, Gcm10 gcm, Gcm14 tend,
                                                                  const double *__restrict__ dz, double dt, double r_dt_gcm,
                                                                  double *__restrict__ work, int *__restrict__ flags) {
-  __shared__ double red[5 * GCM_NS * 64];
+  __shared__ double red[3 * GCM_NS_APPLY * 64];
   const int ME = blockDim.x, slot = threadIdx.y;
   const int e0 = (int)blockIdx.x * ME + (int)threadIdx.x;
   const bool ok = e0 < nens;
@@ -328,11 +341,11 @@ __global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_apply_kernel(int nens
   const double t_qv = tend.p[GT_QV][t] * dt, t_ql = tend.p[GT_QL][t] * dt, t_qi = tend.p[GT_QI][t] * dt;
   const double t_nc = tend.p[GT_NC][t] * dt, t_ni = tend.p[GT_NI][t] * dt, t_nr = tend.p[GT_NR][t] * dt;
   double colavg[3] = {0, 0, 0}, neg[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
-  const long long base = (long long)k * ncol * nens + e;
+  const IDX base = (IDX)k * (IDX)ncol * (IDX)nens + (IDX)e;
   if (ok) {
-#pragma unroll 2
-    for (int c = slot; c < ncol; c += GCM_NS) {
-      const long long o = base + (long long)c * nens;
+#pragma clang loop unroll(disable)
+    for (int c = slot; c < ncol; c += GCM_NS_APPLY) {
+      const IDX o = base + (IDX)c * (IDX)nens;
       const double rho_d_old = crm.p[GF_RHOD][o];
       const double rho_d = rho_d_old + t_rd;
       crm.p[GF_RHOD][o] = rho_d;
@@ -361,13 +374,11 @@ __global__ void __launch_bounds__(64 * GCM_NS) gcm_forcing_apply_kernel(int nens
       }
     }
   }
-  double a5[5] = {colavg[0], colavg[1], colavg[2], neg[0], neg[1]}, b4[4] = {neg[2], pos[0], pos[1], pos[2]};
-  slot_reduce<5, GCM_NS>(a5, red);
-  slot_reduce<4, GCM_NS>(b4, red);
-  if (slot == 0 && ok) {
-    const double ca[3] = {a5[0], a5[1], a5[2]}, ng[3] = {a5[3], a5[4], b4[0]}, ps[3] = {b4[1], b4[2], b4[3]};
-    gcm_forcing_apply_finish(gcm, tend, ca, ng, ps, t, n2, r_dt_gcm, work, flags);
-  }
+  // (three quantities at a time: 3 x 16 LDS values in flight per lane fit the 128 registers of a 1024-lane workgroup)
+  slot_reduce<3, GCM_NS_APPLY>(colavg, red);
+  slot_reduce<3, GCM_NS_APPLY>(neg, red);
+  slot_reduce<3, GCM_NS_APPLY>(pos, red);
+  if (slot == 0 && ok) gcm_forcing_apply_finish(gcm, tend, colavg, neg, pos, t, n2, r_dt_gcm, work, flags);
 }
 
 // fill_holes, level pass (:243-250)
@@ -637,7 +648,9 @@ extern "C" int pam_amd_gcm_forcing_compute(int nens, int nx, int ny, int nz, con
   hipStream_t s = (hipStream_t)stream;
   const int ME = nens < 64 ? nens : 64;
   const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)nz), block((unsigned)ME, (unsigned)GCM_NS);
-  hipLaunchKernelGGL(gcm_forcing_compute_kernel, grid, block, 0, s, nens, nx * ny, nz, C, G, T, 1.0 / gcm_physics_dt);
+  const bool small = (long long)nz * ny * nx * nens < (1ll << 29);
+  if (small) hipLaunchKernelGGL(gcm_forcing_compute_kernel<unsigned>, grid, block, 0, s, nens, nx * ny, nz, C, G, T, 1.0 / gcm_physics_dt);
+  else hipLaunchKernelGGL(gcm_forcing_compute_kernel<long long>, grid, block, 0, s, nens, nx * ny, nz, C, G, T, 1.0 / gcm_physics_dt);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   return PAM_AMD_OK;
@@ -659,9 +672,13 @@ extern "C" int pam_amd_gcm_forcing_apply(int nens, int nx, int ny, int nz, doubl
   int *flags = (int *)(glob + 2 * (long long)nens);
   if (hipMemsetAsync(flags, 0, 8 * sizeof(int), s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
   const int ME = nens < 64 ? nens : 64;
-  const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)nz), block((unsigned)ME, (unsigned)GCM_NS);
-  hipLaunchKernelGGL(gcm_forcing_apply_kernel, grid, block, 0, s, nens, nx * ny, nz, C, G, T, dz, crm_dt, 1.0 / gcm_physics_dt, workspace,
-                     flags);
+  const dim3 grid((unsigned)((nens + ME - 1) / ME), (unsigned)nz), block((unsigned)ME, (unsigned)GCM_NS_APPLY);
+  if (ncell < (1ll << 29))
+    hipLaunchKernelGGL(gcm_forcing_apply_kernel<unsigned>, grid, block, 0, s, nens, nx * ny, nz, C, G, T, dz, crm_dt, 1.0 / gcm_physics_dt,
+                       workspace, flags);
+  else
+    hipLaunchKernelGGL(gcm_forcing_apply_kernel<long long>, grid, block, 0, s, nens, nx * ny, nz, C, G, T, dz, crm_dt, 1.0 / gcm_physics_dt,
+                       workspace, flags);
   // "Only do the hole filling if there's negative mass" (:432-436) and ScalarLiveOut neg_too_large (:241,:252): one read-back
   int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
