@@ -26,6 +26,21 @@ def build(out=None, archflags=""):
     return out or os.path.join(_HERE, "libawfl_oracle.so")
 
 
+def _bound_openmp_team():
+    """The oracle's loops are `omp parallel for` with the runtime's default team: every CPU the process SEES.  A GPU box shows the whole
+    host (hundreds of hardware threads) and lets a job use its share (16 cores for one GPU); with busy neighbours a spinning team of that
+    size needs tens of milliseconds per parallel region, and a test of a few thousand regions stops producing output for minutes (round 6:
+    one run of tests/test_reference_ci_run.py was killed as hung at the oracle half).  Unless the caller chose otherwise: at most 8 threads,
+    sleeping instead of spinning at barriers.  Read by libgomp when it is loaded, so it must happen before the CDLL below."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, usable))))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+
+
 def load(path=None):
     global _LIB
     if path is None and _LIB is not None:
@@ -33,6 +48,7 @@ def load(path=None):
     p = path or os.path.join(_HERE, "libawfl_oracle.so")
     if not os.path.exists(p):
         build()
+    _bound_openmp_team()
     lib = C.CDLL(p)
     lib.awfl_oracle_create.restype = C.c_void_p
     lib.awfl_oracle_create.argtypes = [C.c_int] * 5 + [C.c_double] * 2 + [_DP, C.c_char_p, C.c_char_p, C.c_int, _DP]

@@ -115,3 +115,45 @@ def test_ci_run_is_reproducible_when_the_host_synchronises_between_modules(tmp_p
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
     assert 190.0 < outs[0][4].min() and outs[0][4].max() < 320.0
+
+
+def test_yaml_driver_idealized_run_fills_the_state_on_the_device_and_matches_the_oracle(tmp_path):
+    """The other branch of the reference driver (`idealized: true`, driver.cpp:91-94,125-128,220): `standalone_input_file` is handed to
+    the dycore, whose init -- built with -DPAM_STANDALONE like the reference's standalone builds -- reads `initData` from it and fills the
+    coupler state itself (awfl/Dycore.h:986-1090; here on the device), no sponge layer (apply_sponge defaults to !idealized), and the
+    reference's own `vcoords: uniform` grid (driver.cpp:135-153: dz = zlen / (crm_nz - 1), half a cell at the bottom and top)."""
+    from oracle import awfl_oracle as ao
+    nens, nx, ny, nz, zlen, xlen, ylen, dt = 2, 16, 1, 20, 10000.0, 20000.0, 20000.0, 2.0
+    yml = tmp_path / "thermal.yaml"
+    yml.write_text("idealized : true\ninitData : thermal   # awfl/Dycore.h:1021-1088\nsim_time : 4\ncrm_nx : %d\ncrm_ny : %d\nnens : %d\n"
+                   "vcoords : uniform\ncrm_nz : %d\nzlen : %g\nxlen : %g\nylen : %g\ndt_gcm : 4\ndt_crm_phys : %g\nout_freq : 2.\n"
+                   % (nx, ny, nens, nz, zlen, xlen, ylen, dt))
+    outp = str(tmp_path / "out.bin")
+    r = subprocess.run([DRIVER, "--yaml", str(yml), "--check", outp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    stats = json.loads(r.stdout.strip().split("\n")[-1])
+    assert stats["crm_steps"] == 2 and stats["finite"] and stats["conservation_violations"] == 0
+    assert r.stdout.count("Etime , dtphys, maxw:") == 2 and "apply_gcm_forcing" not in r.stdout
+    dz = zlen / (nz - 1)
+    zint = np.array([0.0] + [k * dz - dz / 2 for k in range(1, nz)] + [zlen])
+    zi = np.ascontiguousarray(np.broadcast_to(zint[:, None], (nz + 1, nens)))
+    zm = 0.5 * (zi[:-1] + zi[1:])
+    f = {k: np.zeros((nz, ny, nx, nens)) for k in ("density_dry", "uvel", "vvel", "wvel", "temp")}
+    f["tracers"] = np.zeros((3, nz, ny, nx, nens))
+    o = ao.OracleDycore(nens, nx, ny, nz, xlen, ylen, np.diff(zint), [True] * 3, [True] * 3, 0, consts=CONSTS)
+    o.init_idealized(f, "thermal", zint)
+    o.declare_current_profile_as_hydrostatic(f)
+    nsub = 0
+    for _ in range(2):
+        nsub += o.time_step(f, dt)[0]
+        trc = [np.ascontiguousarray(f["tracers"][t]) for t in range(3)]
+        ao.kessler(trc[0], trc[1], trc[2], f["density_dry"], f["temp"], zm, dt, CONSTS)
+        for t in range(3):
+            f["tracers"][t] = trc[t]
+    assert nsub == stats["substeps"]
+    raw = np.fromfile(outp, dtype="<f8")
+    ncell = nz * ny * nx * nens
+    got = raw[:8 * ncell].reshape(8, nz, ny, nx, nens)
+    g = {"density_dry": got[0], "uvel": got[1], "vvel": got[2], "wvel": got[3], "temp": got[4], "tracers": got[5:]}
+    assert 190.0 < g["temp"].min() and g["temp"].max() < 305.0 and g["wvel"].max() > 0.0     # a warm bubble in a theta = 300 K atmosphere (T = 200 K at 10 km), rising
+    compare(g, f, ["water_vapor", "cloud_liquid", "precip_liquid"], nsub)
