@@ -2917,33 +2917,39 @@ PAMA_D void hydro_mean_from_pint(const Params &P, const double *__restrict__ pri
 
 // horizontal means for level k, member e, accumulated in the reference's serial order (j outer, i inner), which
 // makes the result deterministic (the reference uses atomicAdd, Dycore.h:1487,1499-1500).
+// mode B (no gravity balance): the means of pressure and density, Dycore.h:1492-1501
+PAMA_D void hydro_cell_mean_body(const Params &P, const double *__restrict__ prim, double *__restrict__ hy_dens,
+                                 double *__restrict__ hy_pres, int k, int e) {
+  const double r_nx_ny = 1. / (P.nx * P.ny);
+  const long long ke = (long long)k * P.nens + e;
+  double hp = 0.0, hd = 0.0;
+  for (int j = 0; j < P.ny; j++)
+    for (int i = 0; i < P.nx; i++) {
+      const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
+      hp += prim[P_PRES * P.prim_fs + o] * r_nx_ny;
+      hd += prim[P_RHO * P.prim_fs + o] * r_nx_ny;
+    }
+  hy_pres[ke] = hp;
+  hy_dens[ke] = hd;
+}
+// both modes in one body, mode A with the interface pressures formed in place (Dycore.h:1450-1490).  The device runs mode A in two
+// steps (hydro_pint_face, hydro_mean_from_pint); this direct form is what the host emulation checks the two steps against.
 template <bool VZ_PER_ENS>
 PAMA_D void hydro_mean_body(const Params &P, const double *__restrict__ prim, double *__restrict__ grav_var,
                             double *__restrict__ hy_dens, double *__restrict__ hy_pres, int k, int e) {
+  if (!P.grav_balance) { hydro_cell_mean_body(P, prim, hy_dens, hy_pres, k, e); return; }
   const double r_nx_ny = 1. / (P.nx * P.ny);
   const long long ke = (long long)k * P.nens + e;
-  if (P.grav_balance) {
-    double g = 0.0;
-    const double dzk = P.dz[ke];
-    for (int j = 0; j < P.ny; j++)
-      for (int i = 0; i < P.nx; i++) {
-        const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
-        double dens = prim[P_RHO * P.prim_fs + (long long)(k + HS) * P.sz + c2];
-        double pu = pint_body<VZ_PER_ENS>(P, prim, k + 1, c2, e), pl = pint_body<VZ_PER_ENS>(P, prim, k, c2, e);
-        g += -(pu - pl) / (dens * dzk) * r_nx_ny;
-      }
-    grav_var[ke] = g;
-  } else {
-    double hp = 0.0, hd = 0.0;
-    for (int j = 0; j < P.ny; j++)
-      for (int i = 0; i < P.nx; i++) {
-        const long long o = (long long)(k + HS) * P.sz + (long long)j * P.sy + (long long)i * P.sx + e;
-        hp += prim[P_PRES * P.prim_fs + o] * r_nx_ny;
-        hd += prim[P_RHO * P.prim_fs + o] * r_nx_ny;
-      }
-    hy_pres[ke] = hp;
-    hy_dens[ke] = hd;
-  }
+  double g = 0.0;
+  const double dzk = P.dz[ke];
+  for (int j = 0; j < P.ny; j++)
+    for (int i = 0; i < P.nx; i++) {
+      const long long c2 = (long long)j * P.sy + (long long)i * P.sx + e;
+      double dens = prim[P_RHO * P.prim_fs + (long long)(k + HS) * P.sz + c2];
+      double pu = pint_body<VZ_PER_ENS>(P, prim, k + 1, c2, e), pl = pint_body<VZ_PER_ENS>(P, prim, k, c2, e);
+      g += -(pu - pl) / (dens * dzk) * r_nx_ny;
+    }
+  grav_var[ke] = g;
 }
 
 }  // namespace pama

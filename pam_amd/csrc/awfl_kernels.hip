@@ -1016,23 +1016,22 @@ __global__ void __launch_bounds__(256) awfl_rdz_kernel(const double *__restrict_
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) rdz[t] = fast_rcp(dz[t]);
 }
-template <bool VZ_PER_ENS>
-__global__ void __launch_bounds__(64) awfl_hydro_kernel(Params P, const double *__restrict__ prim, double *grav_var,
-                                                        double *hy_dens, double *hy_pres) {
+// mode B of declare_current_profile_as_hydrostatic: the horizontal means of pressure and density
+__global__ void __launch_bounds__(64) awfl_hydro_kernel(Params P, const double *__restrict__ prim, double *hy_dens, double *hy_pres) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < (long long)P.nz * P.nens)
-    hydro_mean_body<VZ_PER_ENS>(P, prim, grav_var, hy_dens, hy_pres, (int)(idx / P.nens), (int)(idx % P.nens));
+  if (idx < (long long)P.nz * P.nens) hydro_cell_mean_body(P, prim, hy_dens, hy_pres, (int)(idx / P.nens), (int)(idx % P.nens));
 }
 
 // mode A of declare_current_profile_as_hydrostatic in two steps: the interface pressure of every (face, column) in parallel, then
-// the horizontal means in the reference's order (hydro_pint_face, hydro_mean_from_pint)
-template <bool VZ_PER_ENS>
+// the horizontal means in the reference's order (hydro_pint_face, hydro_mean_from_pint).  IDX: 32-bit face index whenever the z
+// flux field it borrows has fewer than 2^32 entries (any field that fits the card), 64-bit otherwise.
+template <bool VZ_PER_ENS, typename IDX>
 __global__ void __launch_bounds__(256) awfl_hydro_pint_kernel(Params P, const double *__restrict__ prim, double *__restrict__ pint) {
-  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned sz = (unsigned)P.sz, sy = (unsigned)P.sy, ne = (unsigned)P.nens;
-  const unsigned kf = t / sz, r = t - kf * sz;
-  if (kf > (unsigned)P.nz) return;
-  const unsigned j = r / sy, r2 = r - j * sy, i = r2 / ne;
+  const IDX t = (IDX)blockIdx.x * blockDim.x + threadIdx.x;
+  const IDX sz = (IDX)P.sz, sy = (IDX)P.sy, ne = (IDX)P.nens;
+  const IDX kf = t / sz, r = t - kf * sz;
+  if (kf > (IDX)P.nz) return;
+  const IDX j = r / sy, r2 = r - j * sy, i = r2 / ne;
   hydro_pint_face<VZ_PER_ENS>(P, prim, pint, (int)kf, (int)j, (int)i, (int)(r2 - i * ne));
 }
 __global__ void __launch_bounds__(64) awfl_hydro_sum_kernel(Params P, const double *__restrict__ prim, const double *__restrict__ pint,
@@ -2195,20 +2194,18 @@ int pam_amd_awfl_declare_current_profile_as_hydrostatic(pam_amd_awfl_t *h, const
   {
     ScopedTimer st(h, "hydro", h->stream);
     const long long n = (long long)h->P.nz * h->P.nens;
-    if (h->P.grav_balance && h->P.fz_fs < (1ll << 32)) {
+    if (h->P.grav_balance) {
       // mode A: the interface pressures in parallel into the (idle) z flux array, then the means in the reference's order
       const long long nf = h->P.fz_fs;       // (nz + 1) faces x columns
-      if (h->P.vz_per_ens)
-        hipLaunchKernelGGL(awfl_hydro_pint_kernel<true>, dim3(nblocks(nf, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->flux_z);
-      else
-        hipLaunchKernelGGL(awfl_hydro_pint_kernel<false>, dim3(nblocks(nf, 256)), dim3(256), 0, h->stream, h->P, h->prim0, h->flux_z);
+      const dim3 grid(nblocks(nf, 256)), block(256);
+      const bool wide = nf >= (1ll << 32);
+      if (h->P.vz_per_ens && wide) hipLaunchKernelGGL((awfl_hydro_pint_kernel<true, unsigned long long>), grid, block, 0, h->stream, h->P, h->prim0, h->flux_z);
+      else if (h->P.vz_per_ens) hipLaunchKernelGGL((awfl_hydro_pint_kernel<true, unsigned>), grid, block, 0, h->stream, h->P, h->prim0, h->flux_z);
+      else if (wide) hipLaunchKernelGGL((awfl_hydro_pint_kernel<false, unsigned long long>), grid, block, 0, h->stream, h->P, h->prim0, h->flux_z);
+      else hipLaunchKernelGGL((awfl_hydro_pint_kernel<false, unsigned>), grid, block, 0, h->stream, h->P, h->prim0, h->flux_z);
       hipLaunchKernelGGL(awfl_hydro_sum_kernel, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->flux_z, h->act_grav_var);
-    } else if (h->P.vz_per_ens)
-      hipLaunchKernelGGL(awfl_hydro_kernel<true>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0,
-                         h->act_grav_var, h->act_hy_dens, h->act_hy_pres);
-    else
-      hipLaunchKernelGGL(awfl_hydro_kernel<false>, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0,
-                         h->act_grav_var, h->act_hy_dens, h->act_hy_pres);
+    } else
+      hipLaunchKernelGGL(awfl_hydro_kernel, dim3(nblocks(n, 64)), dim3(64), 0, h->stream, h->P, h->prim0, h->act_hy_dens, h->act_hy_pres);
     HIP_TRY(hipGetLastError());
   }
   h->hydro_declared = true;
