@@ -672,9 +672,14 @@ def modules_timing(torch, dev):
         dm.get(k).copy_(torch.from_numpy(f[k]).to(dev).repeat(1, 1, 1, nens // 16))
     dm.get("water_vapor").copy_(torch.from_numpy(f["tracers"][0]).to(dev).repeat(1, 1, 1, nens // 16) * 1.3)
     dm.get("precip_liquid").copy_(dm.get("density_dry") * 1e-3)
+    nsplit = micro.timeStep(c)
     t = timeit(lambda: micro.timeStep(c))
-    out["kessler_time_step"] = {"ms": t, "bytes": cells * 26 * 8.0, "GBps": cells * 26 * 8.0 / t / 1e6,
-                                "note": "prep kernel 6 reads + 5 writes, column kernel 11 reads + 4 writes per cell (1 sub-cycle)"}
+    # one sub-cycle: the limit kernel reads rho_r and rho_d; the column kernel reads rho_d, rho_v, rho_c, rho_r, T and writes the
+    # last four.  Each further sub-cycle: 5 reads + 4 writes, and the Exner function written once and read per cycle.
+    kb = cells * 8.0 * (11 if nsplit == 1 else 2 + 10 * nsplit)
+    out["kessler_time_step"] = {"ms": t, "bytes": kb, "GBps": kb / t / 1e6, "hbm_frac": kb / t / 1e6 / HBM_PEAK_GBS, "rainsplit": nsplit,
+                                "note": "limit kernel 2 reads, column kernel 5 reads + 4 writes per cell (rounds 4-5: 26 passes, the "
+                                        "conversions in a kernel of their own)"}
     t = timeit(lambda: modules.sponge_layer(c))
     nsp = 5                   # sponge_layer.h:8-95: the top 5 of 60 levels
     nfld = 5 + len(c.get_tracer_names())          # rho_d, u, v, w, T + every tracer (sponge_layer.h:54-62); w's mean is zero: not read

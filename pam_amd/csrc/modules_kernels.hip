@@ -92,9 +92,7 @@ __global__ void __launch_bounds__(1024) sponge_kernel(FieldPtrs F, int nens, int
 // ---------------------------------------------------------------------------------------------------------------
 // Kessler microphysics (physics/micro/kessler/Microphysics.h:120-268 timeStep, :346-457 kessler()).
 // Columns are independent; col = (j*nx+i)*nens+e is the fastest index of every (nz, ncol) array, so consecutive lanes
-// read consecutive doubles at every level.  The reference's per-step temporaries (qv,qc,qr,theta) live IN PLACE in the
-// coupler arrays between the two kernels; only the old Exner function needs scratch.  velqr, r, rhalf, pc are pure
-// functions of stored values and are recomputed (bitwise the same as the reference's stored temporaries).
+// read consecutive doubles at every level.
 
 // Every x^y of the scheme has a non-negative base: it goes through pow_pos_fast (awfl_device.h: ~65 instructions, 0.52 ulp against
 // 80-bit powl, 0 -> 0) instead of the device library's pow (~260-440 instructions, half of them for negative / special bases) -- six of
@@ -112,38 +110,19 @@ __device__ __forceinline__ double kessler_velqr(double qr, double r, double rhal
   return 36.34 * kpow(qr * r, 0.1364, T) * rhalf;   // :375, :449
 }
 
-// timeStep :167-174 + kessler "main 1" :369-386, in two forms.  WRITE=false only evaluates the sedimentation time-step
-// limit (:376-386, the input of the global minimum) and touches nothing; WRITE=true does the in-place conversions and
-// does not need the limit any more (the sub-cycle count is known by then).
+// The sedimentation time-step limit of kessler "main 1" (:376-386, the input of the global minimum :389-390); touches nothing.
 // The minimum: wavefront shuffle reduce, then an atomicMin ONLY when the wavefront's value undercuts what the slot already
 // holds -- ~1e6 wavefronts hammering one L2 address with unconditional atomics cost 11 ms at 1024 x 32x32x60, ten times
 // the kernel's HBM time; the plain load in front leaves a handful.
-template <bool WRITE>
-__global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long ncol, int nens, double *rho_v, double *rho_c,
-                                                           double *rho_r, const double *__restrict__ rho_dry, double *temp,
-                                                           double *precl, const double *__restrict__ zmid, double dt,
-                                                           double R_d, double R_v, double cp_d, double p0, double *exner_out,
-                                                           unsigned long long *dt_max_bits, const PowTab *__restrict__ tab) {
+__global__ void __launch_bounds__(256) kessler_limit_kernel(int nz, long long ncol, int nens, const double *__restrict__ rho_r,
+                                                            const double *__restrict__ rho_dry, const double *__restrict__ zmid,
+                                                            double dt, unsigned long long *dt_max_bits,
+                                                            const PowTab *__restrict__ tab) {
   __shared__ PowTab sh_tab;
   kessler_stage_tab(tab, &sh_tab);
   const PowTab *PT = &sh_tab;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  if (WRITE) {
-    if (col >= ncol) return;
-    const long long idx = (long long)k * ncol + col;
-    const double rho = rho_dry[idx];
-    const double rv = rho_v[idx], T = temp[idx];
-    const double pressure = R_d * rho * T + R_v * rv * T;
-    const double ex = kpow(pressure / p0, R_d / cp_d, PT);
-    rho_v[idx] = rv / rho;
-    rho_c[idx] = rho_c[idx] / rho;
-    rho_r[idx] = rho_r[idx] / rho;
-    temp[idx] = T / ex;
-    exner_out[idx] = ex;
-    if (k == 0) precl[col] = 0;
-    return;
-  }
   // positive doubles order like their bit patterns; 0 = "this state is not usable" (NaN or negative fall speed), which
   // wins every minimum and fails the host's "limit must be positive" test
   unsigned long long bits = ~0ull;
@@ -166,13 +145,20 @@ __global__ void __launch_bounds__(256) kessler_prep_kernel(int nz, long long nco
     atomicMin(dt_max_bits, bits);
 }
 
-// kessler "main 2" + "main 3" (:394-453) for all sub-cycles, then timeStep :243-250.  One thread marches one column
-// upwards: sed(k) needs the not-yet-adjusted values of levels k and k+1, which an upward march has at hand.
+// The whole of timeStep for one column: the conversions :167-174 (densities -> mixing ratios, T -> theta through the Exner
+// function of the incoming state), kessler "main 2" + "main 3" (:394-453) for all sub-cycles, the conversions back :243-250.  One
+// thread marches one column upwards: sed(k) needs the not-yet-adjusted values of levels k and k+1, which an upward march has at
+// hand.  The FIRST sub-cycle reads the coupler's arrays as they came (rounds 4-5 converted them in place in a kernel of their own:
+// 11 more array passes of the 26); the LAST writes densities and temperature.  SINGLE (one sub-cycle, the usual case): nothing else
+// is stored.  Otherwise the mixing ratios and theta live IN PLACE in the coupler arrays between sub-cycles and the Exner function
+// of the incoming state in `exner` (nz x ncol doubles of scratch).  velqr, r, rhalf, pc are pure functions of stored values and are
+// recomputed (bitwise the same as the reference's stored temporaries).
+template <bool SINGLE>
 __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long ncol, int nens, double *qv_a, double *qc_a,
                                                             double *qr_a, const double *__restrict__ rho_dry, double *theta_a,
-                                                            double *precl, const double *__restrict__ zmid,
-                                                            const double *__restrict__ exner, double dt, int rainsplit,
-                                                            double Rd, double cp, double p0, const PowTab *__restrict__ tab) {
+                                                            double *precl, const double *__restrict__ zmid, double *exner,
+                                                            double dt, int rainsplit, double Rd, double Rv, double cp, double p0,
+                                                            const PowTab *__restrict__ tab) {
   __shared__ PowTab sh_tab;
   kessler_stage_tab(tab, &sh_tab);
   const PowTab *PT = &sh_tab;
@@ -182,11 +168,12 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
   const double psl = p0 / 100, rhoqr = 1000., lv = 2.5e6;
   const double dt0 = dt / (double)rainsplit;
   const double rho0 = rho_dry[col];
-  double pr = precl[col];
-  for (int nt = 0; nt < rainsplit; nt++) {
-    const bool last = nt == rainsplit - 1;
+  double pr = 0;                                                                  // timeStep :176 precl = 0
+  for (int nt = 0; nt < (SINGLE ? 1 : rainsplit); nt++) {
+    const bool first = SINGLE || nt == 0, last = SINGLE || nt == rainsplit - 1;
     // level-k values carried from the previous iteration's "k+1" loads
     double rho_k = rho0, z_k = zmid[e], qr_k = qr_a[col];
+    if (first) qr_k = qr_k / rho_k;                                               // :169
     double r_k = 0.001 * rho_k, rhalf_k = sqrt(rho0 / rho_k);
     double vel_k = kessler_velqr(qr_k, r_k, rhalf_k, PT);
     double z_km1 = 0;
@@ -198,12 +185,21 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
         sed = -dt0 * qr_k * vel_k / (0.5 * (z_k - z_km1));                        // :400
       } else {
         rho_n = rho_dry[idx + ncol]; z_n = zmid[(long long)(k + 1) * nens + e]; qr_n = qr_a[idx + ncol];
+        if (first) qr_n = qr_n / rho_n;
         r_n = 0.001 * rho_n; rhalf_n = sqrt(rho0 / rho_n);
         vel_n = kessler_velqr(qr_n, r_n, rhalf_n, PT);
         sed = dt0 * (r_n * qr_n * vel_n - r_k * qr_k * vel_k) / (r_k * (z_n - z_k));   // :403
       }
-      double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k;
-      const double pk = exner[idx];
+      double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k, pk;
+      if (first) {                                                                // :167-174
+        const double rv = qv, T = theta;
+        const double pressure = Rd * rho_k * T + Rv * rv * T;
+        pk = kpow(pressure / p0, Rd / cp, PT);
+        qv = rv / rho_k; qc = qc / rho_k; theta = T / pk;
+        if (!SINGLE) exner[idx] = pk;
+      } else {
+        pk = exner[idx];
+      }
       const double pc = 3.8 / (kpow(pk, cp / Rd, PT) * psl);                        // :374
       // autoconversion and accretion (:412-414)
       const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * kpow(qr, 0.875, PT));
@@ -579,9 +575,8 @@ extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, c
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
   if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
-  hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
-                     (double *)nullptr, (double *)nullptr, const_cast<double *>(rho_r), rho_dry, (double *)nullptr,
-                     (double *)nullptr, zmid, dt, 1., 1., 1., 1., (double *)nullptr, slot, tab);
+  hipLaunchKernelGGL(kessler_limit_kernel, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry,
+                     zmid, dt, slot, tab);
   return kessler_read_dt_max((const double *)slot, s, dt_max);
 }
 
@@ -599,12 +594,11 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
   int n = rainsplit_hint;
   if (n <= 0) {
     // The sub-cycle count comes from a global minimum (the reference's yakl::intrinsics::minval, :389-390): one 8-byte
-    // read-back.  It is taken with the NON-writing form of the prep kernel, so that a failure here (a NaN state, an absurd
-    // sub-cycle count, a HIP error) leaves the coupler arrays untouched -- the writing form below converts rho_x -> q and
-    // T -> theta in place and cannot be undone from an error path.
+    // read-back.  The kernel that takes it writes nothing, so that a failure here (a NaN state, an absurd sub-cycle count, a HIP
+    // error) leaves the coupler arrays untouched.
     if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
-    hipLaunchKernelGGL(kessler_prep_kernel<false>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens,
-                       rho_v, rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot, tab);
+    hipLaunchKernelGGL(kessler_limit_kernel, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry,
+                       zmid, dt, slot, tab);
     double dt_max;
     if (int rc = kessler_read_dt_max((const double *)slot, s, &dt_max)) return rc;
     const double want = ceil(dt / dt_max);
@@ -612,10 +606,12 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     n = (int)want;
     if (n < 1) n = 1;
   }
-  hipLaunchKernelGGL(kessler_prep_kernel<true>, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_v,
-                     rho_c, rho_r, rho_dry, temp, precl, zmid, dt, R_d, R_v, cp_d, p0, workspace, slot, tab);
-  hipLaunchKernelGGL(kessler_column_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
-                     rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, cp_d, p0, tab);
+  if (n == 1)
+    hipLaunchKernelGGL(kessler_column_kernel<true>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
+                       rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, R_v, cp_d, p0, tab);
+  else
+    hipLaunchKernelGGL(kessler_column_kernel<false>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
+                       rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, R_v, cp_d, p0, tab);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   if (rainsplit) *rainsplit = n;
