@@ -129,7 +129,10 @@ PAMA_D double weno_rcp(double x) {
 struct PowLog { double ic, lh, ll; };
 struct PowExp { double th, tl; };
 struct PowTab { PowLog lg[128]; PowExp ex[64]; };
-PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
+// the two halves of x^y, for callers that raise ONE base to several exponents (the Kessler column kernel): log2 x as a double-double,
+// then 2^(y log2 x).  pow_pos_fast is their composition, operation for operation what it was as one function.
+struct PowLog2 { double hi, lo; };
+PAMA_D PowLog2 pow_log2_dd(double x, const PowTab *T) {
 #pragma clang fp contract(off)
   int e;
   double m = frexp(x, &e) * 2.0;                            // x = m 2^e, m in [1, 2)
@@ -158,10 +161,15 @@ PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
   const double A = (double)e + lh;                          // exact
   const double s = A + th, bb = s - A;                      // two-sum
   const double err = (A - (s - bb)) + (th - bb);
-  const double Lhi = s, Llo = err + lo;
-  const double zh = y * Lhi;
-  double zl = fma(y, Lhi, -zh);
-  zl = fma(y, Llo, zl);
+  PowLog2 L;
+  L.hi = s; L.lo = err + lo;
+  return L;
+}
+PAMA_D double pow_exp2_dd(double x, double y, const PowLog2 L, const PowTab *T) {
+#pragma clang fp contract(off)
+  const double zh = y * L.hi;
+  double zl = fma(y, L.hi, -zh);
+  zl = fma(y, L.lo, zl);
   const double kd = rint(zh * 64.0);
   double f = fma(kd, -0.015625, zh);                        // exact
   f += zl;
@@ -184,6 +192,7 @@ PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) {
   const double t2h = T->ex[j].th, t2l = T->ex[j].tl;
   return ldexp(fma(t2h, p, t2l) + t2h, n);
 }
+PAMA_D double pow_pos_fast(double x, double y, const PowTab *T) { return pow_exp2_dd(x, y, pow_log2_dd(x, T), T); }
 
 PAMA_D double pow_pos(const Params &P, double x, double y) { return pow_pos_fast(x, y, P.pw); }
 

@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(1024) sponge_kernel(FieldPtrs F, int nens, int
 // tables, staged in LDS by the kernels (two dependent per-lane look-ups per pow).
 using pama::PowTab;
 __device__ __forceinline__ double kpow(double x, double y, const PowTab *T) { return pama::pow_pos_fast(x, y, T); }
+__device__ __forceinline__ double krcp(double x) { return pama::fast_rcp(x); }
+__device__ __forceinline__ double kdiv(double a, double b) { return a * pama::fast_rcp(b); }
 __device__ __forceinline__ void kessler_stage_tab(const PowTab *__restrict__ src, PowTab *dst) {
   const double *s = reinterpret_cast<const double *>(src);
   double *d = reinterpret_cast<double *>(dst);
@@ -114,6 +116,8 @@ __device__ __forceinline__ double kessler_velqr(double qr, double r, double rhal
 // The minimum: wavefront shuffle reduce, then an atomicMin ONLY when the wavefront's value undercuts what the slot already
 // holds -- ~1e6 wavefronts hammering one L2 address with unconditional atomics cost 11 ms at 1024 x 32x32x60, ten times
 // the kernel's HBM time; the plain load in front leaves a handful.
+// A workgroup takes 256 columns and every gridDim.y-th level: the pow tables are staged once per workgroup, not once per 256 cells
+// (round 6: 0.63 -> ms at 1024 x 32x32x60, where the staging moved as many bytes as the two fields read).
 __global__ void __launch_bounds__(256) kessler_limit_kernel(int nz, long long ncol, int nens, const double *__restrict__ rho_r,
                                                             const double *__restrict__ rho_dry, const double *__restrict__ zmid,
                                                             double dt, unsigned long long *dt_max_bits,
@@ -122,19 +126,22 @@ __global__ void __launch_bounds__(256) kessler_limit_kernel(int nz, long long nc
   kessler_stage_tab(tab, &sh_tab);
   const PowTab *PT = &sh_tab;
   const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
   // positive doubles order like their bit patterns; 0 = "this state is not usable" (NaN or negative fall speed), which
   // wins every minimum and fails the host's "limit must be positive" test
   unsigned long long bits = ~0ull;
-  if (col < ncol && k < nz - 1) {
-    const long long idx = (long long)k * ncol + col;
+  if (col < ncol) {
     const int e = (int)(col % nens);
-    const double rho = rho_dry[idx];
-    const double qr = rho_r[idx] / rho;
-    const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho_dry[col] / rho), PT);
-    double dt2d = dt;
-    if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
-    bits = (velqr >= 0 && dt2d > 0) ? (unsigned long long)__double_as_longlong(dt2d) : 0ull;
+    const double rho0 = rho_dry[col];
+    for (int k = blockIdx.y; k < nz - 1; k += gridDim.y) {
+      const long long idx = (long long)k * ncol + col;
+      const double rho = rho_dry[idx];
+      const double qr = rho_r[idx] / rho;
+      const double velqr = kessler_velqr(qr, 0.001 * rho, sqrt(rho0 / rho), PT);
+      double dt2d = dt;
+      if (velqr > 1.e-10) dt2d = 0.8 * (zmid[(long long)(k + 1) * nens + e] - zmid[(long long)k * nens + e]) / velqr;
+      const unsigned long long b = (velqr >= 0 && dt2d > 0) ? (unsigned long long)__double_as_longlong(dt2d) : 0ull;
+      bits = b < bits ? b : bits;
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned long long o = __shfl_xor(bits, off);
@@ -153,8 +160,12 @@ __global__ void __launch_bounds__(256) kessler_limit_kernel(int nz, long long nc
 // is stored.  Otherwise the mixing ratios and theta live IN PLACE in the coupler arrays between sub-cycles and the Exner function
 // of the incoming state in `exner` (nz x ncol doubles of scratch).  velqr, r, rhalf, pc are pure functions of stored values and are
 // recomputed (bitwise the same as the reference's stored temporaries).
-template <bool SINGLE>
-__global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long ncol, int nens, double *qv_a, double *qc_a,
+// IDX: unsigned when a field is below 2^29 doubles (one register of offset for all six arrays on top of their scalar bases).  The usual
+// instance (one sub-cycle, 32-bit offsets) is held at four wavefronts per SIMD: 16384 single-wavefront workgroups of the C2 grid are
+// then exactly four rounds of the chip (1.41 -> 1.28 ms; 20 bytes of scratch outside the level loop); the others keep three, which they
+// reach without scratch.
+template <bool SINGLE, class IDX>
+__global__ void __launch_bounds__(64, (SINGLE && sizeof(IDX) == 4) ? 4 : 3) kessler_column_kernel(int nz, long long ncol, int nens, double *qv_a, double *qc_a,
                                                             double *qr_a, const double *__restrict__ rho_dry, double *theta_a,
                                                             double *precl, const double *__restrict__ zmid, double *exner,
                                                             double dt, int rainsplit, double Rd, double Rv, double cp, double p0,
@@ -162,62 +173,71 @@ __global__ void __launch_bounds__(64) kessler_column_kernel(int nz, long long nc
   __shared__ PowTab sh_tab;
   kessler_stage_tab(tab, &sh_tab);
   const PowTab *PT = &sh_tab;
-  const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ncol) return;
-  const int e = (int)(col % nens);
-  const double psl = p0 / 100, rhoqr = 1000., lv = 2.5e6;
-  const double dt0 = dt / (double)rainsplit;
+  const long long col_ = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col_ >= ncol) return;
+  const IDX col = (IDX)col_, nc = (IDX)ncol;
+  const int e = (int)(col_ % nens);
+  const double psl = p0 / 100, rhoqr = 1000., lv = 2.5e6, rp0 = 1 / p0;
+  const double dt0 = dt / (double)rainsplit;   // (uniform: scalar-side IEEE divisions stay)
   const double rho0 = rho_dry[col];
   double pr = 0;                                                                  // timeStep :176 precl = 0
   for (int nt = 0; nt < (SINGLE ? 1 : rainsplit); nt++) {
     const bool first = SINGLE || nt == 0, last = SINGLE || nt == rainsplit - 1;
     // level-k values carried from the previous iteration's "k+1" loads
     double rho_k = rho0, z_k = zmid[e], qr_k = qr_a[col];
-    if (first) qr_k = qr_k / rho_k;                                               // :169
-    double r_k = 0.001 * rho_k, rhalf_k = sqrt(rho0 / rho_k);
+    if (first) qr_k = kdiv(qr_k, rho_k);                                               // :169
+    double r_k = 0.001 * rho_k, rhalf_k = sqrt(kdiv(rho0, rho_k));
     double vel_k = kessler_velqr(qr_k, r_k, rhalf_k, PT);
     double z_km1 = 0;
-    pr = pr + rho0 * qr_k * vel_k / rhoqr;                                       // :397
+    pr = pr + rho0 * qr_k * vel_k / rhoqr;   // (a constant divisor: the compiler's reciprocal)                                       // :397
     for (int k = 0; k < nz; k++) {
-      const long long idx = (long long)k * ncol + col;
+      const IDX idx = (IDX)k * nc + col;
       double sed, rho_n = 0, z_n = 0, qr_n = 0, r_n = 0, rhalf_n = 0, vel_n = 0;
       if (k == nz - 1) {
-        sed = -dt0 * qr_k * vel_k / (0.5 * (z_k - z_km1));                        // :400
+        sed = kdiv(-dt0 * qr_k * vel_k, 0.5 * (z_k - z_km1));                        // :400
       } else {
-        rho_n = rho_dry[idx + ncol]; z_n = zmid[(long long)(k + 1) * nens + e]; qr_n = qr_a[idx + ncol];
-        if (first) qr_n = qr_n / rho_n;
-        r_n = 0.001 * rho_n; rhalf_n = sqrt(rho0 / rho_n);
+        rho_n = rho_dry[idx + nc]; z_n = zmid[(long long)(k + 1) * nens + e]; qr_n = qr_a[idx + nc];
+        if (first) qr_n = kdiv(qr_n, rho_n);
+        r_n = 0.001 * rho_n; rhalf_n = sqrt(kdiv(rho0, rho_n));
         vel_n = kessler_velqr(qr_n, r_n, rhalf_n, PT);
-        sed = dt0 * (r_n * qr_n * vel_n - r_k * qr_k * vel_k) / (r_k * (z_n - z_k));   // :403
+        sed = kdiv(dt0 * (r_n * qr_n * vel_n - r_k * qr_k * vel_k), r_k * (z_n - z_k));   // :403
       }
-      double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k, pk;
+      double qc = qc_a[idx], qv = qv_a[idx], theta = theta_a[idx], qr = qr_k, pk, pnorm = 0;
       if (first) {                                                                // :167-174
         const double rv = qv, T = theta;
         const double pressure = Rd * rho_k * T + Rv * rv * T;
-        pk = kpow(pressure / p0, Rd / cp, PT);
-        qv = rv / rho_k; qc = qc / rho_k; theta = T / pk;
+        pnorm = pressure * rp0;
+        pk = kpow(pnorm, Rd / cp, PT);
+        const double rrho = krcp(rho_k);
+        qv = rv * rrho; qc = qc * rrho; theta = kdiv(T, pk);
         if (!SINGLE) exner[idx] = pk;
       } else {
         pk = exner[idx];
       }
-      const double pc = 3.8 / (kpow(pk, cp / Rd, PT) * psl);                        // :374
+      // :374 pc = 3.8 / (pk^(cp/Rd) psl).  pk^(cp/Rd) IS pressure / p0 up to the rounding of two pows (a few ulp): where the pressure
+      // is at hand (a first sub-cycle) the pow is not taken
+      const double pc = kdiv(3.8, (first ? pnorm : kpow(pk, cp / Rd, PT)) * psl);
       // autoconversion and accretion (:412-414)
-      const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * kpow(qr, 0.875, PT));
+      const double qrprod = qc - kdiv(qc - dt0 * fmax(0.001 * (qc - 0.001), 0.), 1 + dt0 * 2.2 * kpow(qr, 0.875, PT));
       qc = fmax(qc - qrprod, 0.);
       qr = fmax(qr + qrprod + sed, 0.);
       // saturation vapour mixing ratio (:417-422)
       const double tmp = pk * theta - 36.;
-      const double qvs = pc * exp(17.27 * (pk * theta - 273.) / tmp);
-      const double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+      const double rtmp = krcp(tmp);
+      const double qvs = pc * exp(17.27 * (pk * theta - 273.) * rtmp);
+      const double prod = kdiv(qv - qvs, 1. + qvs * (4093. * lv / cp) * (rtmp * rtmp));
       // evaporation of rain (:425-430)
       const double rq = r_k * qr;
-      const double tmp1 = dt0 * (((1.6 + 124.9 * kpow(rq, 0.2046, PT)) * kpow(rq, 0.525, PT)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
-                          (fmax(qvs - qv, 0.) / (r_k * qvs));
+      const double rqvs = krcp(qvs);
+      const pama::PowLog2 lrq = pama::pow_log2_dd(rq, PT);      // one logarithm for the two powers of rq
+      const double tmp1 = dt0 * kdiv((1.6 + 124.9 * pama::pow_exp2_dd(rq, 0.2046, lrq, PT)) * pama::pow_exp2_dd(rq, 0.525, lrq, PT),
+                                     2550000. * pc * (rqvs * (1 / 3.8)) + 540000.) *
+                          (fmax(qvs - qv, 0.) * kdiv(rqvs, r_k));
       const double tmp2 = fmax(-prod - qc, 0.);
       const double ern = fmin(tmp1, fmin(tmp2, qr));
       // saturation adjustment (:433-439)
       const double cond = fmax(prod, -qc);
-      theta = theta + lv / (cp * pk) * (cond - ern);
+      theta = theta + kdiv(lv, cp * pk) * (cond - ern);
       qv = fmax(qv - cond + ern, 0.);
       qc = qc + cond;
       qr = qr - ern;
@@ -541,6 +561,15 @@ const PowTab *kessler_pow_tab(const void *ref) {
   return g_tabs[dev];
 }
 
+// grid of kessler_limit_kernel: 256 columns per workgroup; the levels are dealt to as few workgroups as still give ~4096 of them
+dim3 kessler_limit_grid(long long ncol, int nz) {
+  const long long nxb = (ncol + 255) / 256;
+  long long nyb = (4096 + nxb - 1) / nxb;
+  if (nyb > nz - 1) nyb = nz - 1;
+  if (nyb < 1) nyb = 1;
+  return dim3((unsigned)nxb, (unsigned)nyb);
+}
+
 int kessler_read_dt_max(const double *slot, hipStream_t s, double *out) {
   double v = 0;
   if (hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
@@ -575,8 +604,7 @@ extern "C" int pam_amd_kessler_max_stable_dt(int nens, int nx, int ny, int nz, c
   const long long ncol = (long long)ny * nx * nens;
   unsigned long long *slot = (unsigned long long *)(workspace + (long long)nz * ncol);
   if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
-  hipLaunchKernelGGL(kessler_limit_kernel, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry,
-                     zmid, dt, slot, tab);
+  hipLaunchKernelGGL(kessler_limit_kernel, kessler_limit_grid(ncol, nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry, zmid, dt, slot, tab);
   return kessler_read_dt_max((const double *)slot, s, dt_max);
 }
 
@@ -597,8 +625,7 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     // read-back.  The kernel that takes it writes nothing, so that a failure here (a NaN state, an absurd sub-cycle count, a HIP
     // error) leaves the coupler arrays untouched.
     if (hipMemsetAsync(slot, 0x7f, 8, s) != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(hipGetLastError()));
-    hipLaunchKernelGGL(kessler_limit_kernel, dim3((unsigned)((ncol + 255) / 256), nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry,
-                       zmid, dt, slot, tab);
+    hipLaunchKernelGGL(kessler_limit_kernel, kessler_limit_grid(ncol, nz), dim3(256), 0, s, nz, ncol, nens, rho_r, rho_dry, zmid, dt, slot, tab);
     double dt_max;
     if (int rc = kessler_read_dt_max((const double *)slot, s, &dt_max)) return rc;
     const double want = ceil(dt / dt_max);
@@ -606,12 +633,16 @@ extern "C" int pam_amd_kessler_time_step(int nens, int nx, int ny, int nz, doubl
     n = (int)want;
     if (n < 1) n = 1;
   }
-  if (n == 1)
-    hipLaunchKernelGGL(kessler_column_kernel<true>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
-                       rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, R_v, cp_d, p0, tab);
-  else
-    hipLaunchKernelGGL(kessler_column_kernel<false>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, s, nz, ncol, nens, rho_v, rho_c,
-                       rho_r, rho_dry, temp, precl, zmid, workspace, dt, n, R_d, R_v, cp_d, p0, tab);
+  const dim3 cgrid((unsigned)((ncol + 63) / 64)), cblock(64);
+  const bool narrow = (long long)nz * ncol < (1ll << 29);
+#define PAMA_KESSLER_COLUMN(SINGLE, IDX)                                                                                         \
+  hipLaunchKernelGGL((kessler_column_kernel<SINGLE, IDX>), cgrid, cblock, 0, s, nz, ncol, nens, rho_v, rho_c, rho_r, rho_dry, temp, \
+                     precl, zmid, workspace, dt, n, R_d, R_v, cp_d, p0, tab)
+  if (n == 1 && narrow) PAMA_KESSLER_COLUMN(true, unsigned);
+  else if (n == 1) PAMA_KESSLER_COLUMN(true, long long);
+  else if (narrow) PAMA_KESSLER_COLUMN(false, unsigned);
+  else PAMA_KESSLER_COLUMN(false, long long);
+#undef PAMA_KESSLER_COLUMN
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return pam_amd_set_last_error_(PAM_AMD_ENOGPU, hipGetErrorString(err));
   if (rainsplit) *rainsplit = n;
