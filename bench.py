@@ -680,6 +680,14 @@ def modules_timing(torch, dev):
     out["kessler_time_step"] = {"ms": t, "bytes": kb, "GBps": kb / t / 1e6, "hbm_frac": kb / t / 1e6 / HBM_PEAK_GBS, "rainsplit": nsplit,
                                 "note": "limit kernel 2 reads, column kernel 5 reads + 4 writes per cell (rounds 4-5: 26 passes, the "
                                         "conversions in a kernel of their own)"}
+    # the same call on a rain-free, cloud-free state (most columns of a real run): wavefronts without rain skip the powers of rain amounts
+    dm.get("water_vapor").copy_(torch.from_numpy(f["tracers"][0]).to(dev).repeat(1, 1, 1, nens // 16) * 0.5)
+    dm.get("precip_liquid").zero_()
+    dm.get("cloud_liquid").zero_()
+    micro.timeStep(c)
+    t = timeit(lambda: micro.timeStep(c))
+    out["kessler_time_step_no_rain"] = {"ms": t, "bytes": cells * 8.0 * 11, "GBps": cells * 8.0 * 11 / t / 1e6,
+                                        "hbm_frac": cells * 8.0 * 11 / t / 1e6 / HBM_PEAK_GBS}
     t = timeit(lambda: modules.sponge_layer(c))
     nsp = 5                   # sponge_layer.h:8-95: the top 5 of 60 levels
     nfld = 5 + len(c.get_tracer_names())          # rho_d, u, v, w, T + every tracer (sponge_layer.h:54-62); w's mean is zero: not read

@@ -108,8 +108,16 @@ __device__ __forceinline__ void kessler_stage_tab(const PowTab *__restrict__ src
   for (int i = threadIdx.x; i < (int)(sizeof(PowTab) / sizeof(double)); i += blockDim.x) d[i] = s[i];
   __syncthreads();
 }
+// x^y (y > 0) where the base is an amount of rain: most cells of most columns hold none and 0^y = 0 exactly, so a wavefront without rain
+// skips the evaluation (a branch over ~65 instructions: taken per wavefront); any other base -- negative and NaN included -- goes
+// through kpow as before.  Same values either way.
+__device__ __forceinline__ double kpow_rain(double x, double y, const PowTab *T) {
+  double r = 0.0;
+  if (x != 0.0) r = kpow(x, y, T);
+  return r;
+}
 __device__ __forceinline__ double kessler_velqr(double qr, double r, double rhalf, const PowTab *T) {
-  return 36.34 * kpow(qr * r, 0.1364, T) * rhalf;   // :375, :449
+  return 36.34 * kpow_rain(qr * r, 0.1364, T) * rhalf;   // :375, :449
 }
 
 // The sedimentation time-step limit of kessler "main 1" (:376-386, the input of the global minimum :389-390); touches nothing.
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(64, (SINGLE && sizeof(IDX) == 4) ? 4 : 3) kess
       // is at hand (a first sub-cycle) the pow is not taken
       const double pc = kdiv(3.8, (first ? pnorm : kpow(pk, cp / Rd, PT)) * psl);
       // autoconversion and accretion (:412-414)
-      const double qrprod = qc - kdiv(qc - dt0 * fmax(0.001 * (qc - 0.001), 0.), 1 + dt0 * 2.2 * kpow(qr, 0.875, PT));
+      const double qrprod = qc - kdiv(qc - dt0 * fmax(0.001 * (qc - 0.001), 0.), 1 + dt0 * 2.2 * kpow_rain(qr, 0.875, PT));
       qc = fmax(qc - qrprod, 0.);
       qr = fmax(qr + qrprod + sed, 0.);
       // saturation vapour mixing ratio (:417-422)
@@ -229,9 +237,13 @@ __global__ void __launch_bounds__(64, (SINGLE && sizeof(IDX) == 4) ? 4 : 3) kess
       // evaporation of rain (:425-430)
       const double rq = r_k * qr;
       const double rqvs = krcp(qvs);
-      const pama::PowLog2 lrq = pama::pow_log2_dd(rq, PT);      // one logarithm for the two powers of rq
-      const double tmp1 = dt0 * kdiv((1.6 + 124.9 * pama::pow_exp2_dd(rq, 0.2046, lrq, PT)) * pama::pow_exp2_dd(rq, 0.525, lrq, PT),
-                                     2550000. * pc * (rqvs * (1 / 3.8)) + 540000.) *
+      double rq_a = 0.0, rq_b = 0.0;                            // rq^0.2046, rq^0.525: one logarithm for the two; none without rain
+      if (rq != 0.0) {
+        const pama::PowLog2 lrq = pama::pow_log2_dd(rq, PT);
+        rq_a = pama::pow_exp2_dd(rq, 0.2046, lrq, PT);
+        rq_b = pama::pow_exp2_dd(rq, 0.525, lrq, PT);
+      }
+      const double tmp1 = dt0 * kdiv((1.6 + 124.9 * rq_a) * rq_b, 2550000. * pc * (rqvs * (1 / 3.8)) + 540000.) *
                           (fmax(qvs - qv, 0.) * kdiv(rqvs, r_k));
       const double tmp2 = fmax(-prod - qc, 0.);
       const double ern = fmin(tmp1, fmin(tmp2, qr));
