@@ -949,13 +949,16 @@ __global__ void __launch_bounds__(256) awfl_d2c_arrays_kernel(Params P, EnsRange
   if (grid_cell(P, R, c)) halo_arrays_to_coupler_body(P, state, tracers, rho_d, u, v, w, temp, trc, c);
 }
 
-// CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, one atomicMin per wavefront on the
-// bit pattern (positive doubles order like unsigned integers).
+// CFL reduction (Dycore.h:86-101): grid-stride min, wavefront shuffle reduce, the workgroup's four values through LDS, ONE atomicMin
+// per workgroup on the bit pattern (positive doubles order like unsigned integers) -- and only when the value undercuts what the slot
+// already holds: every wavefront of a launch updating one L2 address one after the other was ~90 us of this kernel at every size
+// (100 us of a 10 ms step at one GPU's shard of C4, where all 8192 wavefronts are resident at once and finish together).
 __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *__restrict__ rho_d,
                                                        const double *__restrict__ u, const double *__restrict__ v,
                                                        const double *__restrict__ w, const double *__restrict__ temp,
                                                        const double *__restrict__ rho_v, double cfl,
                                                        unsigned long long *result) {
+  __shared__ double wave_min[4];
   double m = INFINITY;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < P.ncell;
        idx += (long long)gridDim.x * blockDim.x)
@@ -967,9 +970,16 @@ __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *_
     const double o = __shfl_down(m, off, 64);
     m = (o != o || m != m) ? NAN : fmin(m, o);
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (!(m > 0.0)) m = 0.0;   // NaN or non-positive anywhere in the wavefront's cells: reported as 0 (the host refuses it)
-    atomicMin(result, (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0) wave_min[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int wv = 1; wv < 4; wv++) {
+      const double o = wave_min[wv];
+      m = (o != o || m != m) ? NAN : fmin(m, o);
+    }
+    if (!(m > 0.0)) m = 0.0;   // NaN or non-positive anywhere in the workgroup's cells: reported as 0 (the host refuses it)
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    if (b < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, b);
   }
 }
 
