@@ -1101,6 +1101,8 @@ struct pam_amd_awfl {
   double *act_grav_var = nullptr, *act_hy_dens = nullptr, *act_hy_pres = nullptr, *act_vert_s2c = nullptr, *act_vert_wrl = nullptr;
   size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
+  unsigned long long *dt_host = nullptr;   // pinned: the CFL minimum read back without blocking the host (time_step)
+  hipEvent_t ev_cfl = nullptr;
   int *fct_flags = nullptr;     // row flags of the FCT multiplier (FctRows in awfl_device.h)
   size_t n_fct_flags = 0, n_fct_lines = 0, n_fct_any = 0;
   int fct_seq = 0;              // launch number of the current stage's FCT kernel: the value a flag must hold to count
@@ -1697,7 +1699,10 @@ int evaluate_mass(pam_amd_awfl *h) {
   return PAM_AMD_OK;
 }
 
-int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, double *dt) {
+// The CFL minimum over this handle's members (Dycore.h:86-101) in two halves: the reduction and its read-back into pinned host memory
+// are queued on the caller's stream (launch); the host waits for that read-back alone (finish) -- time_step queues the conversion of
+// the coupler state in between, so the device works while the host wakes up and issues the stages.
+int launch_cfl(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl) {
   if (!f || !f->tracers) return fail(PAM_AMD_EINVAL, "fields: null pointer");
   const unsigned long long init = 0x7FF0000000000000ull;   // +inf
   HIP_TRY(hipMemcpyAsync(h->dt_bits, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
@@ -1709,13 +1714,20 @@ int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl,
                        f->temp, f->tracers[h->P.idWV], cfl, h->dt_bits);
     HIP_TRY(hipGetLastError());
   }
-  unsigned long long bits = 0;
-  HIP_TRY(hipMemcpyAsync(&bits, h->dt_bits, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpyAsync(h->dt_host, h->dt_bits, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipEventRecord(h->ev_cfl, h->stream));
+  return PAM_AMD_OK;
+}
+int finish_cfl(pam_amd_awfl *h, double *dt) {
+  HIP_TRY(hipEventSynchronize(h->ev_cfl));
   double v;
-  std::memcpy(&v, &bits, sizeof(v));
+  std::memcpy(&v, h->dt_host, sizeof(v));
   *dt = v;
   return PAM_AMD_OK;
+}
+int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, double *dt) {
+  if (int rc = launch_cfl(h, f, cfl)) return rc;
+  return finish_cfl(h, dt);
 }
 
 void destroy_chunks(pam_amd_awfl *h) {
@@ -1940,6 +1952,10 @@ void free_all(pam_amd_awfl *h) {
   }
   if (h->dt_bits) (void)hipFree(h->dt_bits);
   h->dt_bits = nullptr;
+  if (h->dt_host) (void)hipHostFree(h->dt_host);
+  h->dt_host = nullptr;
+  if (h->ev_cfl) (void)hipEventDestroy(h->ev_cfl);
+  h->ev_cfl = nullptr;
   if (h->mass_dev) (void)hipFree(h->mass_dev);
   h->mass_dev = nullptr;
   if (h->pow_tab) (void)hipFree(h->pow_tab);
@@ -2060,6 +2076,8 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->vert_s2c, vt.s2c.size() * 8));
   INIT_TRY(hipMalloc(&h->vert_wrl, vt.wrl.size() * 8));
   INIT_TRY(hipMalloc(&h->dt_bits, 8));
+  INIT_TRY(hipHostMalloc((void **)&h->dt_host, 8, hipHostMallocDefault));
+  INIT_TRY(hipEventCreateWithFlags(&h->ev_cfl, hipEventDisableTiming));
   {
     PowTab pt;
     build_pow_tab(pt);
@@ -2279,16 +2297,34 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   if (rc) return rc;
   // Dycore.h:141-145: the dynamics step comes from the COUPLER fields of every member (before any conversion)
   double dt_dyn = dt_dyn_hint;
-  if (!(dt_dyn > 0)) {
-    rc = local_time_step(h, fields, 0.8, &dt_dyn);
-    if (rc) return rc;
+  int ncycles = 0;
+  // the number of cycles and their length from the dynamics step (Dycore.h:142-145)
+  auto settle_cycles = [&]() -> int {
     if (!(dt_dyn > 0) || !std::isfinite(dt_dyn))
       return fail(PAM_AMD_EINVAL, "time_step: CFL time step is not positive/finite (NaN or non-physical coupler state)");
+    ncycles = (int)std::ceil(crm_dt / dt_dyn);
+    dt_dyn = crm_dt / ncycles;
+    if (ncycles_out) *ncycles_out = ncycles;
+    if (dt_dyn_out) *dt_dyn_out = dt_dyn;
+    return PAM_AMD_OK;
+  };
+  // Without a hint the step comes from a reduction and a read-back.  A step of ONE member range issued eagerly queues the reduction,
+  // then the conversion coupler -> dycore (which does not depend on it), and only then waits for the 8 bytes: the device converts
+  // while the host wakes up and issues the stages (A/B on one box: 32x32x60 with one member 0.669 -> 0.687 G, the reference's
+  // 250x1x50 input shape 0.1405 -> 0.1525 G).  Not with several ranges: their conversions then start together instead of one host
+  // launch apart and the ranges run in lock-step (one GPU's shard of C4: 0.894 -> 0.883 G; started one conversion apart: 0.871).
+  // A replayed graph needs the cycle count before it is chosen: there the wait comes first, too.
+  const bool graph_on = h->graph_mode == 2;
+  bool dt_pending = false;
+  if (!(dt_dyn > 0)) {
+    if ((rc = launch_cfl(h, fields, 0.8))) return rc;
+    if (graph_on || h->chunks.size() > 1) {
+      if ((rc = finish_cfl(h, &dt_dyn))) return rc;
+    } else {
+      dt_pending = true;
+    }
   }
-  const int ncycles = (int)std::ceil(crm_dt / dt_dyn);
-  dt_dyn = crm_dt / ncycles;
-  if (ncycles_out) *ncycles_out = ncycles;
-  if (dt_dyn_out) *dt_dyn_out = dt_dyn;
+  if (!dt_pending && (rc = settle_cycles())) return rc;
   const bool forked = h->chunks.size() > 1;
   if (forked) {   // chunk streams start after everything already queued on the caller's stream
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
@@ -2303,6 +2339,11 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
       if ((rc = launch_init_prim(h, fields, nullptr, !h->P.grav_balance, c.r, c.stream))) return rc;
       if (h->debug_mass && (rc = launch_mass(h, 0, c.r, c.stream))) return rc;      // Dycore.h:136-138 (after the clipping of :130-134)
       if (forked) HIP_TRY(hipEventRecord(c.upd_done, c.stream));
+    }
+    if (dt_pending) {
+      dt_pending = false;
+      if ((rc = finish_cfl(h, &dt_dyn))) return rc;
+      if ((rc = settle_cycles())) return rc;
     }
     // Launches are issued stage by stage, round-robin over the chunks.  With several chunks:
     //  * flux kernels run on each chunk's high-priority flux stream and are chained ACROSS chunks by events
@@ -2411,7 +2452,6 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   // issued eagerly -- 32x32x60 with one member 0.907 -> 1.011 ms, two 1.134 -> 1.249, eight 3.41 -> 3.58, the 250x1x50 shape 0.364 ->
   // 0.425 ms: the gaps between DEPENDENT kernels (~2.3 us each) are the same inside a graph, and the fork / join events cost more
   // than the host-side launch calls they replace (the host is not the bottleneck: launches are issued well ahead of the device).
-  const bool graph_on = h->graph_mode == 2;
   if (graph_on && h->fused && !forked && !h->timing && !h->debug_mass && h->gstream) {
     const int nstages = 3 * ncycles;
     if (h->fct_seq > 0x7fffffff - nstages - 4) {      // the wrap of the stage number cannot happen inside a graph
