@@ -953,12 +953,19 @@ __global__ void __launch_bounds__(256) awfl_d2c_arrays_kernel(Params P, EnsRange
 // per workgroup on the bit pattern (positive doubles order like unsigned integers) -- and only when the value undercuts what the slot
 // already holds: every wavefront of a launch updating one L2 address one after the other was ~90 us of this kernel at every size
 // (100 us of a 10 ms step at one GPU's shard of C4, where all 8192 wavefronts are resident at once and finish together).
+// LEAN (a step of one member range, where the host's wait is on the critical path of every step): no copy in front of or behind the
+// kernel -- it puts +inf into the word the NEXT reduction will use (the host alternates between two) and the workgroup that finishes
+// last publishes the minimum in the host's pinned word.  Otherwise the word is set and read back by copies on the stream (measured: with
+// two member ranges the copy-free form is 1 % SLOWER at one GPU's shard of C4, nine alternating runs each -- not understood, kept apart).
+template <bool LEAN>
 __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *__restrict__ rho_d,
                                                        const double *__restrict__ u, const double *__restrict__ v,
                                                        const double *__restrict__ w, const double *__restrict__ temp,
                                                        const double *__restrict__ rho_v, double cfl,
-                                                       unsigned long long *result) {
+                                                       unsigned long long *result, unsigned long long *next_result,
+                                                       unsigned *done_count, unsigned long long *host_result) {
   __shared__ double wave_min[4];
+  if (LEAN && blockIdx.x == 0 && threadIdx.x == 0) *next_result = 0x7FF0000000000000ull;
   double m = INFINITY;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < P.ncell;
        idx += (long long)gridDim.x * blockDim.x)
@@ -980,6 +987,15 @@ __global__ void __launch_bounds__(256) awfl_cfl_kernel(Params P, const double *_
     if (!(m > 0.0)) m = 0.0;   // NaN or non-positive anywhere in the workgroup's cells: reported as 0 (the host refuses it)
     const unsigned long long b = (unsigned long long)__double_as_longlong(m);
     if (b < __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(result, b);
+    if (!LEAN) return;
+    // the workgroup that finishes last publishes the minimum in the host's pinned word and clears the count
+    __threadfence();
+    if (atomicAdd(done_count, 1u) == gridDim.x - 1) {
+      __threadfence();
+      *host_result = __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *done_count = 0;
+      __threadfence_system();
+    }
   }
 }
 
@@ -1102,6 +1118,8 @@ struct pam_amd_awfl {
   size_t n_vert_s2c = 0, n_vert_wrl = 0;
   unsigned long long *dt_bits = nullptr;
   unsigned long long *dt_host = nullptr;   // pinned: the CFL minimum read back without blocking the host (time_step)
+  unsigned dt_slot = 0;                    // which of the two device words (dt_bits[0 / 1]) the next reduction uses
+  unsigned long long *dt_host_dev = nullptr;   // dt_host as the device sees it
   hipEvent_t ev_cfl = nullptr;
   int *fct_flags = nullptr;     // row flags of the FCT multiplier (FctRows in awfl_device.h)
   size_t n_fct_flags = 0, n_fct_lines = 0, n_fct_any = 0;
@@ -1699,22 +1717,34 @@ int evaluate_mass(pam_amd_awfl *h) {
   return PAM_AMD_OK;
 }
 
-// The CFL minimum over this handle's members (Dycore.h:86-101) in two halves: the reduction and its read-back into pinned host memory
-// are queued on the caller's stream (launch); the host waits for that read-back alone (finish) -- time_step queues the conversion of
+// The CFL minimum over this handle's members (Dycore.h:86-101) in two halves: the reduction, which leaves its result in pinned host
+// memory, is queued on the caller's stream (launch); the host waits for that read-back alone (finish) -- time_step queues the conversion of
 // the coupler state in between, so the device works while the host wakes up and issues the stages.
-int launch_cfl(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl) {
+int launch_cfl(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, bool lean) {
   if (!f || !f->tracers) return fail(PAM_AMD_EINVAL, "fields: null pointer");
-  const unsigned long long init = 0x7FF0000000000000ull;   // +inf
-  HIP_TRY(hipMemcpyAsync(h->dt_bits, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  {
+  int nb = nblocks(h->P.ncell, 256);
+  if (nb > 2048) nb = 2048;
+  if (lean) {
+    // two device words, used in turn: both start from +inf (create), and every reduction puts +inf back into the word of the next one,
+    // whose last user has been read by then (finish_cfl)
+    unsigned long long *word = h->dt_bits + (h->dt_slot & 1u), *next_word = h->dt_bits + ((h->dt_slot + 1u) & 1u);
+    h->dt_slot++;
     ScopedTimer st(h, "cfl", h->stream);
-    int nb = nblocks(h->P.ncell, 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(awfl_cfl_kernel, dim3(nb), dim3(256), 0, h->stream, h->P, f->density_dry, f->uvel, f->vvel, f->wvel,
-                       f->temp, f->tracers[h->P.idWV], cfl, h->dt_bits);
+    hipLaunchKernelGGL(awfl_cfl_kernel<true>, dim3(nb), dim3(256), 0, h->stream, h->P, f->density_dry, f->uvel, f->vvel, f->wvel,
+                       f->temp, f->tracers[h->P.idWV], cfl, word, next_word, (unsigned *)(h->dt_bits + 2), h->dt_host_dev);
     HIP_TRY(hipGetLastError());
+  } else {
+    unsigned long long *word = h->dt_bits + 3;      // (a word of its own: the two forms may alternate on one handle)
+    HIP_TRY(hipMemcpyAsync(word, h->dt_host + 1, sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));   // +inf, pinned
+    {
+      ScopedTimer st(h, "cfl", h->stream);
+      hipLaunchKernelGGL(awfl_cfl_kernel<false>, dim3(nb), dim3(256), 0, h->stream, h->P, f->density_dry, f->uvel, f->vvel, f->wvel,
+                         f->temp, f->tracers[h->P.idWV], cfl, word, (unsigned long long *)nullptr, (unsigned *)nullptr,
+                         (unsigned long long *)nullptr);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(h->dt_host, word, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   }
-  HIP_TRY(hipMemcpyAsync(h->dt_host, h->dt_bits, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipEventRecord(h->ev_cfl, h->stream));
   return PAM_AMD_OK;
 }
@@ -1726,7 +1756,7 @@ int finish_cfl(pam_amd_awfl *h, double *dt) {
   return PAM_AMD_OK;
 }
 int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl, double *dt) {
-  if (int rc = launch_cfl(h, f, cfl)) return rc;
+  if (int rc = launch_cfl(h, f, cfl, h->chunks.size() <= 1)) return rc;
   return finish_cfl(h, dt);
 }
 
@@ -2075,8 +2105,17 @@ int pam_amd_awfl_init(const pam_amd_awfl_config_t *cfg, pam_amd_awfl_t **out) {
   INIT_TRY(hipMalloc(&h->vz, vt.table.size() * 8));
   INIT_TRY(hipMalloc(&h->vert_s2c, vt.s2c.size() * 8));
   INIT_TRY(hipMalloc(&h->vert_wrl, vt.wrl.size() * 8));
-  INIT_TRY(hipMalloc(&h->dt_bits, 8));
-  INIT_TRY(hipHostMalloc((void **)&h->dt_host, 8, hipHostMallocDefault));
+  // CFL minimum: [0], [1] the copy-free form's two words (used in turn), [2] its count of finished workgroups, [3] the other form's word;
+  // on the host (pinned): [0] the minimum as read, [1] +inf
+  INIT_TRY(hipMalloc(&h->dt_bits, 32));
+  INIT_TRY(hipHostMalloc((void **)&h->dt_host, 16, hipHostMallocDefault));
+  h->dt_host[0] = 0;
+  h->dt_host[1] = 0x7FF0000000000000ull;
+  INIT_TRY(hipHostGetDevicePointer((void **)&h->dt_host_dev, h->dt_host, 0));
+  {
+    const unsigned long long w4[4] = {0x7FF0000000000000ull, 0x7FF0000000000000ull, 0ull, 0x7FF0000000000000ull};
+    INIT_TRY(hipMemcpy(h->dt_bits, w4, sizeof(w4), hipMemcpyHostToDevice));
+  }
   INIT_TRY(hipEventCreateWithFlags(&h->ev_cfl, hipEventDisableTiming));
   {
     PowTab pt;
@@ -2317,7 +2356,7 @@ int pam_amd_awfl_time_step(pam_amd_awfl_t *h, const pam_amd_awfl_fields_t *field
   const bool graph_on = h->graph_mode == 2;
   bool dt_pending = false;
   if (!(dt_dyn > 0)) {
-    if ((rc = launch_cfl(h, fields, 0.8))) return rc;
+    if ((rc = launch_cfl(h, fields, 0.8, h->chunks.size() <= 1))) return rc;
     if (graph_on || h->chunks.size() > 1) {
       if ((rc = finish_cfl(h, &dt_dyn))) return rc;
     } else {
