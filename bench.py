@@ -946,11 +946,13 @@ def worker(args):
             except Exception as e:
                 others[key] = {"value": None, "error": repr(e)}
         run_other("c3", "c3", profile="c3")
-        run_other("c4", "c4", profile="c4")
+        # (one GPU's shard of C4 takes 10-12 ms per step: 30 steps behind 3 warm-up steps -- at 10 + 1 the per-member variant came out
+        #  15 % low in 2 of ~12 runs of round 6)
+        run_other("c4", "c4", profile="c4", steps=30, warmup=3)
         # per-member vertical grids (every (level, member) has its own WENO matrices: Dycore.h:897-940, pam_coupler.h:163-181)
         run_other("c2_perens", "c2", perens=True, steps=5, profile="c2_perens",
                   note="C2 with every member on its own vertical grid: the z sweep stages each level's tables in LDS per workgroup (awfl_fluxz_pe_kernel)")
-        run_other("c4_perens", "c4", perens=True, profile="c4_perens", note="C4 (one GPU's shard) with per-member vertical grids")
+        run_other("c4_perens", "c4", perens=True, profile="c4_perens", steps=30, warmup=3, note="C4 (one GPU's shard) with per-member vertical grids")
         # the N = 1 denominators of the two strong-scaling rows and the per-GPU workload of C2 over 8 GPUs
         run_other("c4_full", "c4", nens=4096, steps=10,
                   note="BASELINE config C4 whole (nens = 4096, NT = 10) on ONE GPU: what c4 (one GPU's 512-member shard) is 1/8 of")
