@@ -2917,6 +2917,7 @@ PAMA_D void hydro_pint_face(const Params &P, const double *__restrict__ prim, do
 }
 PAMA_D void hydro_mean_from_pint(const Params &P, const double *__restrict__ prim, const double *__restrict__ pint,
                                  double *__restrict__ grav_var, int k, int e) {
+#pragma clang fp contract(off)
   const double r_nx_ny = 1. / (P.nx * P.ny);
   const long long ke = (long long)k * P.nens + e;
   const double dzk = P.dz[ke];
@@ -2934,8 +2935,11 @@ PAMA_D void hydro_mean_from_pint(const Params &P, const double *__restrict__ pri
 // horizontal means for level k, member e, accumulated in the reference's serial order (j outer, i inner), which
 // makes the result deterministic (the reference uses atomicAdd, Dycore.h:1487,1499-1500).
 // mode B (no gravity balance): the means of pressure and density, Dycore.h:1492-1501
+// (the products are rounded before they are added, as the reference's atomicAdd of `value * r_nx_ny` does: a contracted fma shifts a
+//  level's mean pressure by ~1e-10 Pa, which mode B differences over dz -- 1e-12 m/s in w after one sub-step, fuzz seed 1858)
 PAMA_D void hydro_cell_mean_body(const Params &P, const double *__restrict__ prim, double *__restrict__ hy_dens,
                                  double *__restrict__ hy_pres, int k, int e) {
+#pragma clang fp contract(off)
   const double r_nx_ny = 1. / (P.nx * P.ny);
   const long long ke = (long long)k * P.nens + e;
   double hp = 0.0, hd = 0.0;
@@ -2953,6 +2957,7 @@ PAMA_D void hydro_cell_mean_body(const Params &P, const double *__restrict__ pri
 template <bool VZ_PER_ENS>
 PAMA_D void hydro_mean_body(const Params &P, const double *__restrict__ prim, double *__restrict__ grav_var,
                             double *__restrict__ hy_dens, double *__restrict__ hy_pres, int k, int e) {
+#pragma clang fp contract(off)
   if (!P.grav_balance) { hydro_cell_mean_body(P, prim, hy_dens, hy_pres, k, e); return; }
   const double r_nx_ny = 1. / (P.nx * P.ny);
   const long long ke = (long long)k * P.nens + e;
