@@ -63,6 +63,10 @@ def describe(c):
                c["dxy"], c["lanes"], c["xkernels"], c["xexchange"], c["fusion"]))
 
 
+class IllPosedCase(Exception):
+    """the drawn case is outside what the reference algorithm itself can run"""
+
+
 def run_case(c):
     import torch
     from pam_amd import Dycore, PamCoupler
@@ -121,6 +125,15 @@ def run_case(c):
             n += n_cpu
         return n
 
+    if c["per_ens"] and nens > 60:
+        # members 60+ of a per-member case sit on a grid 1.6 ... 2.3 x the base grid: with 4-5 levels over 15 km the reference's own
+        # arithmetic leaves the numbers there (top layers of > 7 km: the extrapolated ghost pressure of declare_current_profile_as_
+        # hydrostatic is not positive -- NaN in variable_gravity; seeds 2634, 3494, 3980).  Such a case says nothing about parity.
+        probe = copy.deepcopy(f)
+        oracle_run(probe)
+        if not all(np.isfinite(probe[k]).all() for k in ("density_dry", "uvel", "vvel", "wvel", "temp")):
+            dycore.finalize(coupler)
+            raise IllPosedCase("the oracle itself is not finite on this grid")
     if not c["mode_a"]:
         coupler.set_option("balance_hydrostasis_with_gravity", False)
     dycore.declare_current_profile_as_hydrostatic(coupler)
@@ -160,21 +173,28 @@ def test_random_case_matches_oracle(seed):
     c = draw_case(seed)
     try:
         run_case(c)
+    except IllPosedCase as e:
+        pytest.skip(describe(c) + ": " + str(e))
     except AssertionError as e:
         raise AssertionError(describe(c) + "\n" + str(e)) from e
 
 
 if __name__ == "__main__":      # python tests/test_fuzz_parity.py FIRST COUNT: a sweep with one line per seed (tests/ may use the oracle)
     first, count = int(sys.argv[1]), int(sys.argv[2])
-    bad = 0
+    bad = skipped = 0
     for s in range(first, first + count):
         c = draw_case(s)
         try:
-            nsub, mapping, applied, over = run_case(c)
+            try:
+                nsub, mapping, applied, over = run_case(c)
+            except IllPosedCase as e:
+                skipped += 1
+                print("skip %s | %s" % (describe(c), e), flush=True)
+                continue
             note = "".join("; noise floor: %s %.2e (curve %.1e, oracle's own response to 1 ulp %.2e)" % ((k,) + v) for k, v in over.items())
             print("ok   %s | %d sub-steps, forced %s%s" % (describe(c), nsub, ",".join(applied) or "-", note), flush=True)
         except Exception as e:        # noqa: BLE001  (a sweep reports every seed)
             bad += 1
             print("FAIL %s | %s" % (describe(c), str(e).splitlines()[0][:300]), flush=True)
-    print("%d seeds, %d failed" % (count, bad))
+    print("%d seeds, %d failed%s" % (count, bad, (", %d skipped (the oracle itself not finite)" % skipped) if skipped else ""))
     sys.exit(1 if bad else 0)
