@@ -5,7 +5,7 @@ many sub-steps were run.  The small, noise-dominated fields (u, v, w, tracers ot
 curve instead of a flat bound: profiles/r03_error_growth_c1.txt (BASELINE config C1, HIP vs oracle beside the oracle's own response
 to ONE ulp of T) has u, v, w at 4.5e-13 ... 6.8e-12 of their maxima over 3 ... 30 sub-steps, i.e. within 1e-12 (1 + nsub/3)
 throughout -- that is the flow's own sensitivity.  The gate is 1e-11 (1 + nsub/3): the worst of the oracle cases recorded on
-MI355X (profiles/r05_parity_worst.json, written under PAM_AMD_PARITY_RECORD) sits at 0.30 of it, so a 4x regression of the worst
+MI355X (profiles/r05_parity_worst.json, r06_parity_worst.json: written under PAM_AMD_PARITY_RECORD) sits at 0.30-0.43 of it, so a 4x regression of the worst
 case fails, where round 3's flat 1e-9 let 100x through; a relative perturbation of 1e-10 injected into one field turns a case
 red (tests/test_gpu_parity.py).  `factor`: the one exception, the degenerate 3 x 3 x 3 grid (the periodic stencil wraps every line
 twice; w is 1e-3 m/s of noise there), recorded at 1.43 and gated at 4."""
