@@ -25,6 +25,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1760,13 +1761,35 @@ int local_time_step(pam_amd_awfl *h, const pam_amd_awfl_fields_t *f, double cfl,
   return finish_cfl(h, dt);
 }
 
+// The internal streams of the handles of a process are SHARED: the k-th member range of every handle on a device uses the same stream
+// (one per device, kind and priority), created on first use and never destroyed.  The runtime maps streams onto a handful of hardware
+// queues in the order of their creation, and the two member ranges of a handle only overlap when their streams sit on different queues:
+// a process that had created a second set of streams -- another handle alive at the same time, or a handle re-chunked -- ran every
+// later two-range workload in a degraded state for the rest of its life (one GPU's shard of C4 0.90 -> 0.60 G, C2 at 128 members
+// 2.45 -> 2.17 G: tools/probe/two_handles.py; the "slow mode" of bench.py's other configurations in round 6).  Sharing is safe: every
+// time_step forks its ranges from the caller's stream with an event and joins them back into it, so handles that share a range stream
+// are simply ordered on it in the order of their calls.
+struct SharedStream { hipStream_t s; int device, priority, kind, ordinal; };
+static std::mutex g_stream_pool_mutex;
+static std::vector<SharedStream> g_stream_pool;
+static hipError_t shared_stream(int device, int priority, int kind, int ordinal, hipStream_t *out) {
+  std::lock_guard<std::mutex> lk(g_stream_pool_mutex);
+  for (auto &p : g_stream_pool)
+    if (p.device == device && p.priority == priority && p.kind == kind && p.ordinal == ordinal) { *out = p.s; return hipSuccess; }
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+  if (e != hipSuccess) return e;
+  g_stream_pool.push_back({s, device, priority, kind, ordinal});
+  *out = s;
+  return hipSuccess;
+}
+
 void destroy_chunks(pam_amd_awfl *h) {
   for (auto &c : h->chunks) {
     if (c.done) (void)hipEventDestroy(c.done);
     if (c.flux_done) (void)hipEventDestroy(c.flux_done);
     if (c.upd_done) (void)hipEventDestroy(c.upd_done);
-    if (c.fstream && c.fstream != h->stream && c.fstream != c.stream) (void)hipStreamDestroy(c.fstream);
-    if (c.stream && c.stream != h->stream) (void)hipStreamDestroy(c.stream);
+    // (the range streams are shared and stay; what this handle queued on them has been joined into the caller's stream by time_step)
   }
   h->chunks.clear();
 }
@@ -1951,10 +1974,12 @@ int build_chunks(pam_amd_awfl *h) {
     // streams land on one queue run one after the other -- seen in round 4: one more internal stream per handle cost C4 0.80 -> 0.54 G.
     // Independent ranges of the fused stage need ONE stream each; only the shared-compute-stream schedules use a second one.)
     const bool one_stream_per_range = h->fused && h->independent_ranges;
+    int ordinal = 0;
     for (auto &c : h->chunks) {
-      HIP_TRY(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio_low));
+      HIP_TRY(shared_stream(h->device, prio_low, 0, ordinal, &c.stream));
       if (one_stream_per_range) c.fstream = c.stream;
-      else HIP_TRY(hipStreamCreateWithPriority(&c.fstream, hipStreamNonBlocking, h->use_priorities ? prio_high : prio_low));
+      else HIP_TRY(shared_stream(h->device, h->use_priorities ? prio_high : prio_low, 1, ordinal, &c.fstream));
+      ordinal++;
       HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c.flux_done, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c.upd_done, hipEventDisableTiming));
