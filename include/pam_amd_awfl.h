@@ -168,7 +168,11 @@ int pam_amd_awfl_set_flux_span(pam_amd_awfl_t *h, int faces);
  * fused stage from 128 members on, one below; 1-16 for the three-kernel stage, whose HBM-bound
  * update kernel overlaps the FP64-bound flux kernel of another range.  flux_lds_floor_bytes: dynamic LDS requested per flux
  * workgroup when chunks > 1 (the kernel itself uses none: it caps the flux kernel's residency per CU so that another range's
- * blocks can co-reside; default 0 = no cap).  Results do not depend on either. */
+ * blocks can co-reside; default 0 = no cap).  Results do not depend on either.
+ * The internal streams belong to the DEVICE, not to the handle: the k-th range of every handle created on a device uses the same
+ * stream, created on first use and kept for the life of the process (the runtime maps streams onto a few hardware queues in creation
+ * order; a second set of range streams in a process left the ranges of every later handle on one queue).  Handles driven from several
+ * host threads at once are therefore ordered on those streams in the order of their calls; results are unaffected. */
 int pam_amd_awfl_set_ensemble_chunks(pam_amd_awfl_t *h, int chunks, int flux_lds_floor_bytes);
 /* Fused stage with several member ranges: independent = 1 (default) runs every range's whole stage on the range's own stream (no
  * shared compute stream, no events between ranges), so that launches which do not fill the chip overlap their ramp-up and drain

@@ -97,8 +97,8 @@ def test_bench_py_the_drivers_command_prints_a_parseable_line():
         assert o[k] > 0, k
     assert o["c3_ms_per_step"] > 0 and o["c4_ms_per_step"] > 0
     # per-member vertical grids (the coupler's general contract) near the shared-table configurations: 0.88-0.91 x as
-    # a rule; the guard leaves room for the 10-step measurement of the small C4 shard, which came out at 0.75-0.76 x in 2 of ~12 bench
-    # runs of round 6 (right behind the full-power c2_perens run; the same binary gives 0.79-0.81 G in the next run)
+    # a rule; the guard leaves room below that: before the handles of a device shared their range streams the C4 shard's variant came out
+    # at 0.75-0.80 x in ~1 of 5 bench runs (a degraded state of the process)
     assert o["c2_perens"] >= 0.80 * d["value"] and o["c4_perens"] >= 0.68 * o["c4"], (o["c2_perens"], d["value"], o["c4_perens"], o["c4"])
     for k in ("kessler_time_step", "sponge_layer", "compute_gcm_forcing_tendencies", "apply_gcm_forcing_tendencies"):
         assert o["modules_ms"][k] > 0
